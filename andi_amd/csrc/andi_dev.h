@@ -1,0 +1,223 @@
+// andi_dev.h — device-side view of one subject's enhanced suffix array and the
+// interval primitives shared by the index-build and scan kernels (gfx950).
+//
+// Layout in HBM per subject (all hipMalloc'ed, see api.hip):
+//   S    uint8[n+1+PAD]  RS, NUL at n, zero padding so wide loads never fault
+//   SA   int32[n]        suffix array (host-built, src/esa.c:294-304)
+//   LCP  int32[n+1]      LCP[0]=LCP[n]=-1          (K1, src/esa.c:373-426)
+//   CLD  int32[n+1]      child table                (K2, src/esa.c:312-363)
+//   FVC  uint8[n]        S[SA[i]+LCP[i]]            (K3, src/esa.c:229-245)
+//   tab  int4[4^10]      10-mer interval table {l,i,j,m} (K4, src/esa.c:73-215)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ANDI_CACHE_K 10
+#define ANDI_PAD 2048 /* bytes of zero padding behind every byte pool */
+
+struct EsaDev {
+	const uint8_t *S;
+	const int32_t *SA;
+	const int32_t *LCP;
+	const int32_t *CLD;
+	const uint8_t *FVC;
+	const int4 *tab; // x=l y=i z=j w=m
+	int32_t n;
+	int32_t thr;
+};
+
+struct Ival { // lcp_inter_t, src/esa.h:25-34
+	int32_t l, i, j, m;
+};
+
+__device__ __forceinline__ bool ival_empty(const Ival &v) {
+	return v.i == -1 && v.j == -1;
+}
+
+__device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t *p) {
+	uint32_t v;
+	__builtin_memcpy(&v, p, 4);
+	return v;
+}
+
+__device__ __forceinline__ uint64_t ld_u64_unaligned(const uint8_t *p) {
+	uint64_t v;
+	__builtin_memcpy(&v, p, 8);
+	return v;
+}
+
+// true for A C G T; everything else in the alphabet {\0 ! # ;} is below 'A'
+__device__ __forceinline__ bool is_acgt(uint8_t c) {
+	return c >= 'A';
+}
+
+// char2code, src/esa.c:49-58 == nucl2bit, src/model.c:295-299: A0 C1 G2 T3
+__device__ __forceinline__ uint32_t nt_code(uint8_t c) {
+	uint32_t x = c & 6u;
+	return (x ^ (x >> 1)) >> 1;
+}
+
+__device__ __forceinline__ uint8_t code_nt(uint32_t code) {
+	return (uint8_t)((0x54474341u >> (8 * (code & 3u))) & 0xffu); // "ACGT"
+}
+
+// Length of the common prefix of a[0..maxlen) and b[0..maxlen).
+// WAVE=true: all 64 lanes call with identical arguments and share the work
+// (256 B per step, one coalesced 4-byte load per lane and string); the result
+// is wave-uniform.  WAVE=false: one thread, 8 bytes per step.
+// Both strings must be readable ANDI_PAD bytes past maxlen.
+template <bool WAVE>
+__device__ __forceinline__ uint32_t common_prefix(const uint8_t *a, const uint8_t *b,
+												  uint32_t maxlen) {
+	if constexpr (WAVE) {
+		const uint32_t lane = __lane_id();
+		for (uint32_t done = 0; done < maxlen; done += 256) {
+			uint32_t off = done + 4 * lane;
+			uint32_t x = ld_u32_unaligned(a + off) ^ ld_u32_unaligned(b + off);
+			uint64_t diff = __ballot(x != 0);
+			if (diff) {
+				int first = __builtin_ctzll(diff);
+				uint32_t xf = __shfl(x, first);
+				uint32_t pos = done + 4 * first + (__builtin_ctz(xf) >> 3);
+				return pos < maxlen ? pos : maxlen;
+			}
+		}
+		return maxlen;
+	} else {
+		uint32_t k = 0;
+		while (k < maxlen) {
+			uint64_t x = ld_u64_unaligned(a + k) ^ ld_u64_unaligned(b + k);
+			if (x) {
+				k += (uint32_t)(__builtin_ctzll(x) >> 3);
+				return k < maxlen ? k : maxlen;
+			}
+			k += 8;
+		}
+		return maxlen;
+	}
+}
+
+__device__ __forceinline__ Ival esa_root(const EsaDev &E) {
+	Ival r;
+	r.i = 0;
+	r.j = E.n - 1;
+	r.m = E.CLD[E.n - 1]; // L(CLD, n), src/esa.c:82-83
+	r.l = E.LCP[r.m];
+	return r;
+}
+
+// get_interval, src/esa.c:441-511: the child of `ij` whose next character is a.
+__device__ __forceinline__ Ival esa_child(const EsaDev &E, Ival ij, uint8_t a) {
+	int32_t i = ij.i;
+	const int32_t j = ij.j;
+	if (i == j) {
+		if (E.S[E.SA[i] + ij.l] != a) ij.i = ij.j = -1;
+		return ij;
+	}
+	int32_t m = ij.m;
+	const int32_t l = ij.l;
+	uint8_t c = E.S[E.SA[i] + l];
+	for (;;) {
+		if (c == a) {
+			Ival r;
+			if (i != m - 1) {
+				int32_t nm = E.CLD[m - 1];
+				r.i = i, r.j = m - 1, r.m = nm, r.l = E.LCP[nm];
+			} else {
+				r.i = i, r.j = i, r.m = -1, r.l = E.LCP[i];
+			}
+			return r;
+		}
+		if (c > a) break;
+		i = m;
+		if (i == j) break;
+		m = E.CLD[m];
+		if (E.LCP[m] != l) break;
+		c = E.FVC[i];
+	}
+	bool hit = (i != ij.i) ? (E.FVC[i] == a) : (E.S[E.SA[i] + l] == a);
+	if (hit) {
+		ij.i = i;
+		ij.l = E.LCP[m];
+		ij.m = m;
+	} else {
+		ij.i = ij.j = -1;
+	}
+	return ij;
+}
+
+// get_match_from, src/esa.c:531-601
+template <bool WAVE>
+__device__ __forceinline__ Ival esa_match_from(const EsaDev &E, const uint8_t *q, uint32_t qlen,
+											   int32_t k, Ival ij) {
+	if (ival_empty(ij)) return ij;
+	if (ij.i == ij.j) {
+		// singleton: plain extension along the one suffix.  RS's NUL can never
+		// equal a query byte, so the `S[p+k]` stop of the reference is implied.
+		uint32_t from = (uint32_t)ij.l;
+		if (from < qlen)
+			from += common_prefix<WAVE>(q + from, E.S + E.SA[ij.i] + from, qlen - from);
+		ij.l = (int32_t)from;
+		return ij;
+	}
+	Ival res = ij;
+	do {
+		ij = esa_child(E, ij, q[k]);
+		if (ival_empty(ij)) {
+			res.l = k;
+			return res;
+		}
+		res.i = ij.i;
+		res.j = ij.j;
+		int32_t lim = (int32_t)qlen;
+		if (ij.i < ij.j && ij.l < lim) lim = ij.l;
+		++k;
+		if (k < lim) {
+			k += (int32_t)common_prefix<WAVE>(q + k, E.S + E.SA[ij.i] + k, (uint32_t)(lim - k));
+			if (k < lim) {
+				res.l = k;
+				return res;
+			}
+		}
+	} while (k < (int32_t)qlen);
+	res.l = (int32_t)qlen;
+	return res;
+}
+
+// get_match, src/esa.c:615-624
+template <bool WAVE>
+__device__ __forceinline__ Ival esa_match(const EsaDev &E, const uint8_t *q, uint32_t qlen) {
+	return esa_match_from<WAVE>(E, q, qlen, 0, esa_root(E));
+}
+
+// 2-bit code of the first 10 characters, first character most significant
+// (src/esa.c:639-643); returns false if any of them is not ACGT.
+__device__ __forceinline__ bool kmer10_code(const uint8_t *q, uint32_t &code) {
+	uint32_t w0 = ld_u32_unaligned(q), w1 = ld_u32_unaligned(q + 4), w2 = ld_u32_unaligned(q + 8);
+	w2 &= 0x0000ffffu;
+	// every ACGT byte has bit 6 set, no separator has
+	bool ok = ((w0 & 0x40404040u) == 0x40404040u) && ((w1 & 0x40404040u) == 0x40404040u) &&
+			  ((w2 & 0x00004040u) == 0x00004040u);
+	auto pack4 = [](uint32_t w) {
+		uint32_t x = w & 0x06060606u;
+		x ^= x >> 1;
+		x = (x >> 1) & 0x03030303u; // 2-bit code per byte, byte 0 = first char
+		return ((x & 0xffu) << 6) | (((x >> 8) & 0xffu) << 4) | (((x >> 16) & 0xffu) << 2) |
+			   (x >> 24);
+	};
+	code = (pack4(w0) << 12) | (pack4(w1) << 4) | (pack4(w2) >> 4);
+	return ok;
+}
+
+// get_match_cached, src/esa.c:636-656
+template <bool WAVE>
+__device__ __forceinline__ Ival esa_match_cached(const EsaDev &E, const uint8_t *q, uint32_t qlen) {
+	if (qlen <= ANDI_CACHE_K) return esa_match<WAVE>(E, q, qlen);
+	uint32_t code;
+	if (!kmer10_code(q, code)) return esa_match<WAVE>(E, q, qlen);
+	int4 t = E.tab[code];
+	Ival ij;
+	ij.l = t.x, ij.i = t.y, ij.j = t.z, ij.m = t.w;
+	if (ival_empty(ij)) return esa_match<WAVE>(E, q, qlen);
+	return esa_match_from<WAVE>(E, q, qlen, ij.l, ij);
+}

@@ -1,0 +1,727 @@
+// api.hip — the C-ABI of libandihip.so (include/andi_hip.h): device objects,
+// staging, kernel orchestration and the one-call replacement of
+// distMatrix/distMatrixLM (src/dist_hack.h:34-96).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "andi_dev.h"
+#include "andi_hip.h"
+#include "esa_build.h"
+#include "scan.h"
+
+#define ANDI_DEFAULT_SEGMENT 16384u
+
+static_assert(sizeof(andi_hip_model) == 68, "struct model must be 17 x u32 (src/model.h:52-57)");
+static_assert(sizeof(andi_hip_interval) == 16, "lcp_inter_t is 4 x int32 (src/esa.h:25-34)");
+static_assert(sizeof(ChainState) == 32, "ChainState is padded to 32 bytes");
+
+struct EventPair {
+	hipEvent_t a, b;
+	int kind; // 0 build, 1 scan, 2 stitch
+};
+
+struct andi_hip_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	// scan scratch
+	void *scratch = nullptr;
+	size_t scratch_bytes = 0;
+	// descriptor staging (pinned host + device), guarded by desc_done
+	void *desc_host = nullptr;
+	void *desc_dev = nullptr;
+	size_t desc_bytes = 0;
+	hipEvent_t desc_done = nullptr;
+	unsigned long long *d_fixups = nullptr;
+	std::vector<EventPair> pending;
+	andi_hip_timings acc{};
+};
+
+struct andi_hip_esa {
+	uint8_t *S = nullptr;
+	int32_t *SA = nullptr, *LCP = nullptr, *CLD = nullptr;
+	uint8_t *FVC = nullptr;
+	int4 *tab = nullptr;
+	int32_t *min_scratch = nullptr;
+	int32_t n = 0;
+	int32_t thr = 0;
+	bool built = false;
+	size_t bytes = 0;
+};
+
+struct andi_hip_queries {
+	uint8_t *pool = nullptr;
+	uint64_t *d_off = nullptr;
+	uint32_t *d_len = nullptr;
+	std::vector<uint64_t> off;
+	std::vector<uint32_t> len;
+	size_t nq = 0;
+	uint64_t total_nt = 0;
+	// segmentation cache
+	uint32_t seg = 0;
+	uint32_t *d_qseg_start = nullptr;
+	uint32_t *d_seg2query = nullptr;
+	uint32_t total_segs = 0;
+};
+
+namespace {
+
+void set_err(char *buf, size_t len, const char *fmt, ...) {
+	if (!buf || !len) return;
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, len, fmt, ap);
+	va_end(ap);
+}
+
+int fail(andi_hip_ctx *ctx, const char *what, hipError_t e) {
+	if (ctx) {
+		ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+	}
+	return 1;
+}
+
+#define HIP_TRY(ctx, call)                                                                         \
+	do {                                                                                           \
+		hipError_t e__ = (call);                                                                   \
+		if (e__ != hipSuccess) return fail((ctx), #call, e__);                                     \
+	} while (0)
+
+template <typename T>
+hipError_t dmalloc(T **p, size_t count) {
+	return hipMalloc((void **)p, count * sizeof(T));
+}
+
+void resolve_events(andi_hip_ctx *ctx) {
+	for (auto &ev : ctx->pending) {
+		float ms = 0.f;
+		if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+			if (ev.kind == 0) {
+				ctx->acc.build_ms += ms;
+				ctx->acc.build_launches++;
+			} else if (ev.kind == 1) {
+				ctx->acc.scan_ms += ms;
+				ctx->acc.scan_launches++;
+			} else {
+				ctx->acc.stitch_ms += ms;
+				ctx->acc.stitch_launches++;
+			}
+		}
+		(void)hipEventDestroy(ev.a);
+		(void)hipEventDestroy(ev.b);
+	}
+	ctx->pending.clear();
+}
+
+struct Timed {
+	andi_hip_ctx *ctx;
+	EventPair ev;
+	bool ok;
+	Timed(andi_hip_ctx *c, int kind) : ctx(c), ok(false) {
+		ev.kind = kind;
+		if (hipEventCreate(&ev.a) != hipSuccess) return;
+		if (hipEventCreate(&ev.b) != hipSuccess) {
+			(void)hipEventDestroy(ev.a);
+			return;
+		}
+		ok = hipEventRecord(ev.a, c->stream) == hipSuccess;
+	}
+	void stop() {
+		if (!ok) return;
+		(void)hipEventRecord(ev.b, ctx->stream);
+		ctx->pending.push_back(ev);
+		ok = false;
+		if (ctx->pending.size() > 256) resolve_events(ctx);
+	}
+};
+
+EsaDev esa_view(const andi_hip_esa *e) {
+	EsaDev v;
+	v.S = e->S, v.SA = e->SA, v.LCP = e->LCP, v.CLD = e->CLD, v.FVC = e->FVC, v.tab = e->tab;
+	v.n = e->n, v.thr = e->thr;
+	return v;
+}
+
+} // namespace
+
+extern "C" {
+
+int andi_hip_abi_version(void) {
+	return ANDI_HIP_ABI_VERSION;
+}
+
+void andi_hip_default_opts(andi_hip_opts *o) {
+	if (!o) return;
+	memset(o, 0, sizeof *o);
+	o->p_value = 0.025; // ANCHOR_P_VALUE, src/andi.c:48
+	o->model = ANDI_M_JC;
+	o->device = 0;
+	o->host_threads = 0;
+	o->low_memory = 0;
+	o->segment = 0;
+}
+
+int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errlen) {
+	if (!out) return 1;
+	*out = nullptr;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0) {
+		set_err(errbuf, errlen, "no HIP device available (%s); the anchor-distance engine has no CPU path",
+				e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+		return 1;
+	}
+	if (device < 0 || device >= count) {
+		set_err(errbuf, errlen, "HIP device %d out of range (have %d)", device, count);
+		return 1;
+	}
+	e = hipSetDevice(device);
+	if (e != hipSuccess) {
+		set_err(errbuf, errlen, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+		return 1;
+	}
+	auto *ctx = new andi_hip_ctx;
+	ctx->device = device;
+	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
+	if (e != hipSuccess) {
+		set_err(errbuf, errlen, "context setup: %s", hipGetErrorString(e));
+		andi_hip_ctx_destroy(ctx);
+		return 1;
+	}
+	*out = ctx;
+	return 0;
+}
+
+void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	resolve_events(ctx);
+	if (ctx->scratch) (void)hipFree(ctx->scratch);
+	if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
+	if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
+	if (ctx->d_fixups) (void)hipFree(ctx->d_fixups);
+	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+const char *andi_hip_last_error(const andi_hip_ctx *ctx) {
+	return ctx ? ctx->err.c_str() : "no context";
+}
+
+int andi_hip_sync(andi_hip_ctx *ctx) {
+	if (!ctx) return 1;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return 0;
+}
+
+int andi_hip_dev_alloc(andi_hip_ctx *ctx, size_t bytes, void **dptr) {
+	if (!ctx || !dptr) return 1;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+	return 0;
+}
+
+void andi_hip_dev_free(andi_hip_ctx *ctx, void *dptr) {
+	if (!ctx || !dptr) return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipFree(dptr);
+}
+
+int andi_hip_copy_to_host(andi_hip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+	if (!ctx) return 1;
+	HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return 0;
+}
+
+// ------------------------------------------------------------------ subjects
+int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, size_t n,
+					   size_t threshold, andi_hip_esa **out) {
+	if (!ctx || !RS || !SA || !out || n == 0 || n >= (size_t)INT32_MAX) {
+		if (ctx) ctx->err = "andi_hip_esa_stage: bad arguments";
+		return 1;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	auto *e = new andi_hip_esa;
+	e->n = (int32_t)n;
+	e->thr = (int32_t)threshold;
+	const size_t tab_entries = (size_t)1 << (2 * ANDI_CACHE_K);
+	const size_t mins = andi_min_tree_entries(e->n);
+	hipError_t err = hipSuccess;
+	auto chk = [&](hipError_t x) {
+		if (err == hipSuccess) err = x;
+	};
+	chk(dmalloc(&e->S, n + 1 + ANDI_PAD));
+	chk(dmalloc(&e->SA, n));
+	chk(dmalloc(&e->LCP, n + 1));
+	chk(dmalloc(&e->CLD, n + 1));
+	chk(dmalloc(&e->FVC, n + ANDI_PAD));
+	chk(dmalloc(&e->tab, tab_entries));
+	chk(dmalloc(&e->min_scratch, mins));
+	e->bytes = (n + 1 + ANDI_PAD) + 4 * n + 8 * (n + 1) + n + ANDI_PAD + 16 * tab_entries + 4 * mins;
+	if (err == hipSuccess) err = hipMemsetAsync(e->S + n, 0, 1 + ANDI_PAD, ctx->stream);
+	if (err == hipSuccess) err = hipMemcpyAsync(e->S, RS, n, hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess)
+		err = hipMemcpyAsync(e->SA, SA, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+	// the caller may release RS/SA as soon as this returns
+	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+	if (err != hipSuccess) {
+		andi_hip_esa_free(ctx, e);
+		return fail(ctx, "andi_hip_esa_stage", err);
+	}
+	*out = e;
+	return 0;
+}
+
+int andi_hip_esa_build(andi_hip_ctx *ctx, andi_hip_esa *e) {
+	if (!ctx || !e) return 1;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	EsaBuildArgs a;
+	a.S = e->S, a.SA = e->SA, a.LCP = e->LCP, a.CLD = e->CLD, a.FVC = e->FVC, a.tab = e->tab;
+	a.min_scratch = e->min_scratch;
+	a.n = e->n;
+	Timed t(ctx, 0);
+	hipError_t err = andi_launch_esa_build(a, ctx->stream);
+	t.stop();
+	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build", err);
+	e->built = true;
+	return 0;
+}
+
+int andi_hip_esa_download(andi_hip_ctx *ctx, const andi_hip_esa *e, int32_t *LCP, int32_t *CLD,
+						  uint8_t *FVC, andi_hip_interval *cache) {
+	if (!ctx || !e) return 1;
+	const size_t n = (size_t)e->n;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (LCP) HIP_TRY(ctx, hipMemcpy(LCP, e->LCP, (n + 1) * 4, hipMemcpyDeviceToHost));
+	if (CLD) HIP_TRY(ctx, hipMemcpy(CLD, e->CLD, (n + 1) * 4, hipMemcpyDeviceToHost));
+	if (FVC) HIP_TRY(ctx, hipMemcpy(FVC, e->FVC, n, hipMemcpyDeviceToHost));
+	if (cache)
+		HIP_TRY(ctx, hipMemcpy(cache, e->tab, ((size_t)16 << (2 * ANDI_CACHE_K)), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
+	if (!e) return;
+	if (ctx) {
+		(void)hipSetDevice(ctx->device);
+		(void)hipStreamSynchronize(ctx->stream);
+	}
+	(void)hipFree(e->S);
+	(void)hipFree(e->SA);
+	(void)hipFree(e->LCP);
+	(void)hipFree(e->CLD);
+	(void)hipFree(e->FVC);
+	(void)hipFree(e->tab);
+	(void)hipFree(e->min_scratch);
+	delete e;
+}
+
+size_t andi_hip_esa_bytes(const andi_hip_esa *e) {
+	return e ? e->bytes : 0;
+}
+
+// ------------------------------------------------------------------ queries
+int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n,
+						   andi_hip_queries **out) {
+	if (!ctx || !seqs || !out || n == 0 || n >= (size_t)UINT32_MAX) {
+		if (ctx) ctx->err = "andi_hip_queries_stage: bad arguments";
+		return 1;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	auto *q = new andi_hip_queries;
+	q->nq = n;
+	q->off.resize(n);
+	q->len.resize(n);
+	uint64_t cursor = 0;
+	for (size_t i = 0; i < n; ++i) {
+		if (!seqs[i].seq || seqs[i].len == 0 || seqs[i].len > (size_t)(INT32_MAX - 1) / 2) {
+			ctx->err = "andi_hip_queries_stage: empty or oversized sequence";
+			delete q;
+			return 1;
+		}
+		q->off[i] = cursor;
+		q->len[i] = (uint32_t)seqs[i].len;
+		q->total_nt += seqs[i].len;
+		cursor += (seqs[i].len + 1 + 15) & ~(uint64_t)15; // NUL + 16-byte aligned starts
+	}
+	const size_t pool_bytes = cursor + ANDI_PAD;
+	hipError_t err = hipSuccess;
+	auto chk = [&](hipError_t x) {
+		if (err == hipSuccess) err = x;
+	};
+	chk(dmalloc(&q->pool, pool_bytes));
+	chk(dmalloc(&q->d_off, n));
+	chk(dmalloc(&q->d_len, n));
+	if (err == hipSuccess) err = hipMemsetAsync(q->pool, 0, pool_bytes, ctx->stream);
+	for (size_t i = 0; i < n && err == hipSuccess; ++i)
+		err = hipMemcpyAsync(q->pool + q->off[i], seqs[i].seq, seqs[i].len, hipMemcpyHostToDevice,
+							 ctx->stream);
+	if (err == hipSuccess)
+		err = hipMemcpyAsync(q->d_off, q->off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess)
+		err = hipMemcpyAsync(q->d_len, q->len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+	if (err != hipSuccess) {
+		andi_hip_queries_free(ctx, q);
+		return fail(ctx, "andi_hip_queries_stage", err);
+	}
+	*out = q;
+	return 0;
+}
+
+void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q) {
+	if (!q) return;
+	if (ctx) {
+		(void)hipSetDevice(ctx->device);
+		(void)hipStreamSynchronize(ctx->stream);
+	}
+	(void)hipFree(q->pool);
+	(void)hipFree(q->d_off);
+	(void)hipFree(q->d_len);
+	(void)hipFree(q->d_qseg_start);
+	(void)hipFree(q->d_seg2query);
+	delete q;
+}
+
+static int ensure_segmentation(andi_hip_ctx *ctx, andi_hip_queries *q, uint32_t seg) {
+	if (q->seg == seg && q->d_qseg_start) return 0;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	(void)hipFree(q->d_qseg_start);
+	(void)hipFree(q->d_seg2query);
+	q->d_qseg_start = q->d_seg2query = nullptr;
+	std::vector<uint32_t> start(q->nq + 1);
+	uint64_t total = 0;
+	for (size_t i = 0; i < q->nq; ++i) {
+		start[i] = (uint32_t)total;
+		total += (q->len[i] + (uint64_t)seg - 1) / seg;
+		if (total >= UINT32_MAX) {
+			ctx->err = "too many scan segments; raise opts.segment";
+			return 1;
+		}
+	}
+	start[q->nq] = (uint32_t)total;
+	std::vector<uint32_t> s2q((size_t)total);
+	for (size_t i = 0; i < q->nq; ++i)
+		for (uint32_t w = start[i]; w < start[i + 1]; ++w) s2q[w] = (uint32_t)i;
+	HIP_TRY(ctx, dmalloc(&q->d_qseg_start, q->nq + 1));
+	HIP_TRY(ctx, dmalloc(&q->d_seg2query, (size_t)total));
+	HIP_TRY(ctx, hipMemcpy(q->d_qseg_start, start.data(), (q->nq + 1) * 4, hipMemcpyHostToDevice));
+	HIP_TRY(ctx, hipMemcpy(q->d_seg2query, s2q.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+	q->seg = seg;
+	q->total_segs = (uint32_t)total;
+	return 0;
+}
+
+int andi_hip_match_positions(andi_hip_ctx *ctx, const andi_hip_esa *esa, const andi_hip_queries *q,
+							 size_t qidx, size_t first, size_t count, int cached,
+							 andi_hip_interval *out_host) {
+	if (!ctx || !esa || !q || !out_host || qidx >= q->nq || !esa->built) {
+		if (ctx) ctx->err = "andi_hip_match_positions: bad arguments (index not built?)";
+		return 1;
+	}
+	if (first + count > q->len[qidx]) {
+		ctx->err = "andi_hip_match_positions: range beyond the query";
+		return 1;
+	}
+	if (count == 0) return 0;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	andi_hip_interval *d_out = nullptr;
+	HIP_TRY(ctx, dmalloc(&d_out, count));
+	hipError_t e = andi_launch_match_positions(esa_view(esa), q->pool + q->off[qidx], q->len[qidx],
+											   (uint32_t)first, (uint32_t)count, cached, d_out,
+											   ctx->stream);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(out_host, d_out, count * sizeof(andi_hip_interval), hipMemcpyDeviceToHost,
+						   ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d_out);
+	if (e != hipSuccess) return fail(ctx, "andi_hip_match_positions", e);
+	return 0;
+}
+
+// ------------------------------------------------------------------ scan
+int andi_hip_scan_rows(andi_hip_ctx *ctx, const andi_hip_esa *const *subjects, const int64_t *self,
+					   size_t nsub, const andi_hip_queries *q_const, int model, uint32_t segment,
+					   andi_hip_model *M_dev) {
+	if (!ctx || !subjects || !q_const || !M_dev || nsub == 0 || nsub > 65535) {
+		if (ctx) ctx->err = "andi_hip_scan_rows: bad arguments";
+		return 1;
+	}
+	if (model != ANDI_M_RAW && model != ANDI_M_JC && model != ANDI_M_KIMURA) {
+		// LogDet/ANI count anchor bytes individually (src/model.c:256-278);
+		// that variant of the equal-run attribution is not on the device yet.
+		ctx->err = "andi_hip_scan_rows: only the RAW, JC and Kimura models are supported";
+		return 1;
+	}
+	auto *q = const_cast<andi_hip_queries *>(q_const);
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (segment == 0) segment = ANDI_DEFAULT_SEGMENT;
+	if (ensure_segmentation(ctx, q, segment)) return 1;
+
+	// descriptors: [EsaDev x nsub][int64 x nsub]
+	const size_t desc_need = nsub * (sizeof(EsaDev) + sizeof(int64_t));
+	if (ctx->desc_bytes < desc_need) {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
+		if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
+		ctx->desc_dev = ctx->desc_host = nullptr;
+		ctx->desc_bytes = 0;
+		HIP_TRY(ctx, hipMalloc(&ctx->desc_dev, desc_need));
+		HIP_TRY(ctx, hipHostMalloc(&ctx->desc_host, desc_need, hipHostMallocDefault));
+		ctx->desc_bytes = desc_need;
+	} else {
+		HIP_TRY(ctx, hipEventSynchronize(ctx->desc_done)); // previous upload consumed
+	}
+	auto *h_esa = (EsaDev *)ctx->desc_host;
+	auto *h_self = (int64_t *)(h_esa + nsub);
+	uint64_t pairs = 0, nt = 0;
+	for (size_t s = 0; s < nsub; ++s) {
+		if (!subjects[s] || !subjects[s]->built) {
+			ctx->err = "andi_hip_scan_rows: subject index not built";
+			return 1;
+		}
+		h_esa[s] = esa_view(subjects[s]);
+		h_self[s] = self ? self[s] : -1;
+		bool has_self = h_self[s] >= 0 && (size_t)h_self[s] < q->nq;
+		pairs += q->nq - (has_self ? 1 : 0);
+		nt += q->total_nt - (has_self ? q->len[(size_t)h_self[s]] : 0);
+	}
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->desc_dev, ctx->desc_host, desc_need, hipMemcpyHostToDevice,
+								ctx->stream));
+	HIP_TRY(ctx, hipEventRecord(ctx->desc_done, ctx->stream));
+
+	// scratch: per (subject, segment) two states and two count vectors
+	const size_t slots = nsub * (size_t)q->total_segs;
+	const size_t need = slots * (2 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t));
+	if (ctx->scratch_bytes < need) {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->scratch) (void)hipFree(ctx->scratch);
+		ctx->scratch = nullptr;
+		ctx->scratch_bytes = 0;
+		HIP_TRY(ctx, hipMalloc(&ctx->scratch, need));
+		ctx->scratch_bytes = need;
+	}
+
+	ScanArgs a;
+	a.subjects = (const EsaDev *)ctx->desc_dev;
+	a.self = (const int64_t *)((const EsaDev *)ctx->desc_dev + nsub);
+	a.nsub = (uint32_t)nsub;
+	a.qpool = q->pool, a.qoff = q->d_off, a.qlen = q->d_len, a.nq = (uint32_t)q->nq;
+	a.qseg_start = q->d_qseg_start, a.seg2query = q->d_seg2query;
+	a.total_segs = q->total_segs, a.seg = segment;
+	char *p = (char *)ctx->scratch;
+	a.cold_exit = (ChainState *)p;
+	p += slots * sizeof(ChainState);
+	a.true_exit = (ChainState *)p;
+	p += slots * sizeof(ChainState);
+	a.cold_counts = (uint32_t *)p;
+	p += slots * 16 * sizeof(uint32_t);
+	a.owned = (uint32_t *)p;
+	a.M = M_dev;
+	a.fixups = ctx->d_fixups;
+
+	{
+		Timed t(ctx, 1);
+		hipError_t e = andi_launch_scan_cold(a, ctx->stream);
+		t.stop();
+		if (e != hipSuccess) return fail(ctx, "scan pass A", e);
+	}
+	{
+		Timed t(ctx, 2);
+		hipError_t e = andi_launch_scan_stitch(a, ctx->stream);
+		if (e == hipSuccess) e = andi_launch_scan_reduce(a, ctx->stream);
+		t.stop();
+		if (e != hipSuccess) return fail(ctx, "scan passes B/C", e);
+	}
+	ctx->acc.scan_pairs += pairs;
+	ctx->acc.scan_query_nt += nt;
+	return 0;
+}
+
+int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t) {
+	if (!ctx || !t) return 1;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	resolve_events(ctx);
+	unsigned long long fx = 0;
+	HIP_TRY(ctx, hipMemcpy(&fx, ctx->d_fixups, sizeof fx, hipMemcpyDeviceToHost));
+	ctx->acc.fixups = fx;
+	*t = ctx->acc;
+	return 0;
+}
+
+void andi_hip_timings_reset(andi_hip_ctx *ctx) {
+	if (!ctx) return;
+	(void)hipStreamSynchronize(ctx->stream);
+	resolve_events(ctx);
+	(void)hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
+	ctx->acc = andi_hip_timings{};
+}
+
+// ------------------------------------------------------------------ the seam
+// distMatrix / distMatrixLM, src/dist_hack.h:34-96: for every subject build the
+// index and compare every other sequence against it.  Host threads prepare RS
+// and the suffix array (seq_subject_init + esa_init_SA); the calling thread
+// feeds the device in subject order.
+namespace {
+struct Prepared {
+	size_t idx = 0;
+	char *RS = nullptr;
+	size_t n = 0, thr = 0;
+	std::vector<int32_t> SA;
+	int rc = 0;
+};
+} // namespace
+
+int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
+						 const andi_hip_opts *opts_in, char *errbuf, size_t errlen) {
+	if (!M || !seqs || n == 0) {
+		set_err(errbuf, errlen, "andi_hip_dist_matrix: bad arguments");
+		return 1;
+	}
+	andi_hip_opts o;
+	if (opts_in) {
+		o = *opts_in;
+	} else {
+		andi_hip_default_opts(&o);
+	}
+	for (size_t i = 0; i < n; ++i) {
+		if (!seqs[i].seq || seqs[i].len == 0) {
+			set_err(errbuf, errlen, "sequence %zu is empty", i); // src/andi.c:302-304
+			return 1;
+		}
+		if (seqs[i].len > (size_t)(INT32_MAX - 1) / 2) { // src/andi.c:296-300
+			set_err(errbuf, errlen, "sequence %zu is too long. The technical limit is %zu.", i,
+					(size_t)(INT32_MAX - 1) / 2);
+			return 1;
+		}
+	}
+
+	andi_hip_ctx *ctx = nullptr;
+	if (andi_hip_ctx_create(&ctx, o.device, errbuf, errlen)) return 1;
+	andi_hip_queries *Q = nullptr;
+	andi_hip_model *d_row = nullptr;
+	int rc = 0;
+	auto bail = [&](const char *what) {
+		set_err(errbuf, errlen, "%s: %s", what, andi_hip_last_error(ctx));
+		rc = 1;
+	};
+
+	if (andi_hip_queries_stage(ctx, seqs, n, &Q)) bail("staging queries");
+	if (!rc && andi_hip_dev_alloc(ctx, n * sizeof(andi_hip_model), (void **)&d_row)) bail("row buffer");
+
+	// host pool: subject preparation + suffix sorting, bounded look-ahead
+	int threads = o.host_threads > 0 ? o.host_threads : (int)std::thread::hardware_concurrency();
+	if (threads < 1) threads = 1;
+	if ((size_t)threads > n) threads = (int)n;
+	const size_t window = (size_t)threads + 2;
+
+	std::mutex mu;
+	std::condition_variable cv;
+	std::deque<Prepared *> ready; // any order
+	std::atomic<size_t> next{0};
+	size_t consumed = 0; // guarded by mu
+	bool abort_flag = false;
+
+	auto worker = [&]() {
+		for (;;) {
+			size_t i = next.fetch_add(1);
+			if (i >= n) return;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return abort_flag || i < consumed + window; });
+				if (abort_flag) return;
+			}
+			auto *p = new Prepared;
+			p->idx = i;
+			double gc;
+			p->rc = andi_hip_subject_prepare(seqs[i].seq, seqs[i].len, o.p_value, &p->RS, &p->n, &gc,
+											 &p->thr);
+			if (!p->rc) {
+				p->SA.resize(p->n);
+				p->rc = andi_hip_suffix_array((const unsigned char *)p->RS, p->SA.data(), (int32_t)p->n);
+			}
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				ready.push_back(p);
+			}
+			cv.notify_all();
+		}
+	};
+	std::vector<std::thread> pool;
+	if (!rc)
+		for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+
+	for (size_t i = 0; i < n && !rc; ++i) {
+		Prepared *p = nullptr;
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] {
+				for (auto *c : ready)
+					if (c->idx == i) return true;
+				return false;
+			});
+			for (auto it = ready.begin(); it != ready.end(); ++it)
+				if ((*it)->idx == i) {
+					p = *it;
+					ready.erase(it);
+					break;
+				}
+		}
+		if (p->rc) {
+			set_err(errbuf, errlen, "Failed to create index for sequence %zu.", i); // src/dist_hack.h:53
+			rc = 1;
+		}
+		andi_hip_esa *E = nullptr;
+		if (!rc && andi_hip_esa_stage(ctx, p->RS, p->SA.data(), p->n, p->thr, &E)) bail("staging subject");
+		if (!rc && andi_hip_esa_build(ctx, E)) bail("index build");
+		int64_t self = (int64_t)i;
+		const andi_hip_esa *subj[1] = {E};
+		if (!rc && andi_hip_scan_rows(ctx, subj, &self, 1, Q, o.model, o.segment, d_row)) bail("scan");
+		if (!rc && andi_hip_copy_to_host(ctx, M + i * n, d_row, n * sizeof(andi_hip_model))) bail("row copy");
+		if (E) andi_hip_esa_free(ctx, E);
+		andi_hip_free(p->RS);
+		delete p;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			consumed = i + 1;
+			if (rc) abort_flag = true;
+		}
+		cv.notify_all();
+		if (!rc && o.progress) o.progress((i + 1) * (n - 1), n * n - n, o.ud);
+	}
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		abort_flag = abort_flag || rc;
+		consumed = n; // release any waiting worker
+	}
+	cv.notify_all();
+	for (auto &t : pool) t.join();
+	for (auto *p : ready) {
+		andi_hip_free(p->RS);
+		delete p;
+	}
+	if (d_row) andi_hip_dev_free(ctx, d_row);
+	if (Q) andi_hip_queries_free(ctx, Q);
+	andi_hip_ctx_destroy(ctx);
+	return rc;
+}
+
+} // extern "C"

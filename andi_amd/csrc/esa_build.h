@@ -1,0 +1,27 @@
+// esa_build.h — launch interface of the device index build (esa_build.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ANDI_MIN_LEVELS 6 /* 64^5 > 2^30 covers every int32-indexable text */
+
+// 64-ary pyramid of minima over LCP[0..n]; lv[0] is LCP itself.
+struct MinTree {
+	const int32_t *lv[ANDI_MIN_LEVELS];
+	int32_t cnt[ANDI_MIN_LEVELS];
+	int levels;
+};
+
+struct EsaBuildArgs {
+	const uint8_t *S;   // n + 1 + pad
+	const int32_t *SA;  // n
+	int32_t *LCP;       // n + 1   (out)
+	int32_t *CLD;       // n + 1   (out; doubles as PLCP scratch)
+	uint8_t *FVC;       // n       (out)
+	int4 *tab;          // 4^10    (out)
+	int32_t *min_scratch; // andi_min_tree_entries(n) ints
+	int32_t n;
+};
+
+size_t andi_min_tree_entries(int32_t n);
+hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st);

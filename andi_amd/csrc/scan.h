@@ -1,0 +1,48 @@
+// scan.h — launch interface of the anchor-scan kernels (scan.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "andi_dev.h"
+#include "andi_hip.h"
+
+// Loop-top state of dist_anchor's while loop (src/process.c:153): the query
+// position about to be examined plus everything the next iterations read.
+struct __attribute__((aligned(16))) ChainState {
+	uint32_t p;       // this_match.pos_Q
+	uint32_t lastS;   // last_match.pos_S
+	uint32_t lastQ;   // last_match.pos_Q
+	uint32_t lastLen; // last_match.length
+	uint32_t lwra;    // last_was_right_anchor
+	uint32_t pad[3];
+};
+
+struct ScanArgs {
+	const EsaDev *subjects; // [nsub] device array
+	const int64_t *self;    // [nsub] query index of the subject itself or -1
+	uint32_t nsub;
+	// query pool
+	const uint8_t *qpool;
+	const uint64_t *qoff; // [nq]
+	const uint32_t *qlen; // [nq]
+	uint32_t nq;
+	// segmentation of the queries into work items
+	const uint32_t *qseg_start; // [nq+1]
+	const uint32_t *seg2query;  // [total_segs]
+	uint32_t total_segs;
+	uint32_t seg; // nucleotides per segment
+	// per (subject, segment) scratch
+	ChainState *cold_exit; // state when the cold chain leaves the segment
+	uint32_t *cold_counts; // [..][16] counts the cold chain added inside the segment
+	ChainState *true_exit; // state of the true chain when it leaves the segment
+	uint32_t *owned;       // [..][16] counts the true chain adds inside the segment
+	andi_hip_model *M;     // [nsub][nq]
+	unsigned long long *fixups;
+};
+
+hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st);
+hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st);
+hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st);
+hipError_t andi_launch_match_positions(const EsaDev &E, const uint8_t *q, uint32_t qlen,
+									   uint32_t first, uint32_t count, int cached,
+									   andi_hip_interval *out, hipStream_t st);

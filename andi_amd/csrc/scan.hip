@@ -1,0 +1,352 @@
+// scan.hip — the anchor scan (dist_anchor, src/process.c:141-214) on gfx950.
+//
+// dist_anchor is a sequential chain over one query: every iteration either
+// continues on the last anchor's diagonal by direct comparison ("lucky",
+// src/process.c:82-100) or asks the ESA for the longest match
+// (src/process.c:113-123), pairs equidistant anchors and counts the
+// substitutions between them (src/model.c:246-337).  The chain is made parallel
+// by cutting each query into segments:
+//
+//   pass A  k_scan_cold    one wavefront per (subject, query segment) runs the
+//                          chain from a cold state at the segment start and
+//                          records the counts it adds and the state in which
+//                          it leaves the segment.
+//   pass B  k_scan_stitch  the true chain enters segment s in the state the
+//                          chain of segment s-1 left in.  It is replayed next
+//                          to the cold chain until both are in the same state;
+//                          from there on the cold chain's counts are the true
+//                          ones.  This pass assumes the predecessor's cold exit
+//                          state IS the true entry state.
+//   pass C  k_scan_reduce  one wavefront per pair checks that assumption for
+//                          every segment (true exit of s-1 == cold exit of
+//                          s-1), sums the per-segment counts, re-stitches the
+//                          rare segments whose assumption failed, and applies
+//                          the loop epilogue (src/process.c:199-211).
+//
+// A chain step is wave-uniform control flow; the 64 lanes share the byte
+// comparisons (common_prefix<true>) and the substitution counting (LDS
+// histogram).  The result is bit-identical to the sequential loop.
+#include "scan.h"
+
+#define WAVES_PER_BLOCK 4
+#define BLOCK (64 * WAVES_PER_BLOCK)
+
+#define CHECK_LAUNCH()                                                                             \
+	do {                                                                                           \
+		hipError_t e_ = hipGetLastError();                                                         \
+		if (e_ != hipSuccess) return e_;                                                           \
+	} while (0)
+
+struct PairCtx {
+	EsaDev E;
+	const uint8_t *Q;
+	uint32_t qlen;
+	uint32_t thr;
+	uint32_t border; // n / 2, src/process.c:149
+};
+
+__device__ __forceinline__ bool same_state(const ChainState &a, const ChainState &b) {
+	return a.p == b.p && a.lastS == b.lastS && a.lastQ == b.lastQ && a.lastLen == b.lastLen &&
+		   a.lwra == b.lwra;
+}
+
+__device__ __forceinline__ ChainState initial_state() {
+	ChainState s;
+	s.p = s.lastS = s.lastQ = s.lastLen = s.lwra = 0;
+	s.pad[0] = s.pad[1] = s.pad[2] = 0;
+	return s;
+}
+
+// A state no real chain can be in: the "last anchor" sits at RS offset n, so
+// neither the lucky test (try_pos_S >= len, src/process.c:90) nor the
+// right-anchor test (pos_S > end_S, src/process.c:160) can fire until a real
+// anchor has replaced it, and its length 0 never gets counted.
+__device__ __forceinline__ ChainState cold_state(uint32_t start, uint32_t n) {
+	ChainState s = initial_state();
+	s.p = start;
+	s.lastS = n;
+	return s;
+}
+
+// model_count_equal for RAW/JC/Kimura, src/model.c:247-253
+__device__ __forceinline__ void count_equal(uint32_t *hist, uint32_t len) {
+	uint32_t lane = __lane_id();
+	if (lane < 4) atomicAdd(&hist[5 * lane], len / 4 + (lane == 3 ? (len & 3u) : 0u));
+}
+
+// model_count, src/model.c:309-337
+__device__ __forceinline__ void count_gap(uint32_t *hist, const uint8_t *s, const uint8_t *q,
+										  uint32_t len) {
+	for (uint32_t off = __lane_id(); off < len; off += 64) {
+		int8_t a = (int8_t)s[off], b = (int8_t)q[off];
+		if (a >= 'A' && b >= 'A')
+			atomicAdd(&hist[(nt_code((uint8_t)a) << 2) + nt_code((uint8_t)b)], 1u);
+	}
+}
+
+// One trip of the while loop, src/process.c:153-197.  Wave-uniform.
+__device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st, uint32_t *hist) {
+	const uint32_t n = (uint32_t)c.E.n;
+	uint32_t curS = 0, curLen = 0;
+	bool found = false;
+
+	// lucky_anchor, src/process.c:82-100
+	uint32_t advance = st.p - st.lastQ;
+	uint32_t gap = advance - st.lastLen;
+	uint32_t tryS = st.lastS + advance;
+	if (tryS < n && gap <= c.thr) {
+		curS = tryS;
+		curLen = common_prefix<true>(c.Q + st.p, c.E.S + tryS, c.qlen - st.p);
+		found = curLen >= c.thr;
+	}
+	// anchor, src/process.c:113-123
+	if (!found) {
+		Ival in = esa_match_cached<true>(c.E, c.Q + st.p, c.qlen - st.p);
+		curS = (uint32_t)c.E.SA[in.i];
+		curLen = in.l <= 0 ? 0u : (uint32_t)in.l;
+		found = in.i == in.j && curLen >= c.thr;
+	}
+
+	if (found) {
+		uint32_t endS = st.lastS + st.lastLen;
+		uint32_t endQ = st.lastQ + st.lastLen;
+		if (curS > endS && st.p - endQ == curS - endS &&
+			(curS < c.border) == (st.lastS < c.border)) {
+			count_equal(hist, st.lastLen);
+			count_gap(hist, c.E.S + endS, c.Q + endQ, st.p - endQ);
+			st.lwra = 1;
+		} else {
+			if (st.lwra || st.lastLen >= 2 * c.thr) count_equal(hist, st.lastLen);
+			st.lwra = 0;
+		}
+		st.lastS = curS;
+		st.lastQ = st.p;
+		st.lastLen = curLen;
+	}
+	st.p += curLen + 1;
+	return st;
+}
+
+__device__ __forceinline__ void hist_zero(uint32_t *hist) {
+	if (__lane_id() < 16) hist[__lane_id()] = 0;
+}
+
+struct WorkItem {
+	uint32_t sub, w, qidx, seg_in_q, start, end;
+	bool valid, is_self;
+};
+
+__device__ __forceinline__ PairCtx make_ctx(const ScanArgs &a, uint32_t sub, uint32_t qidx) {
+	PairCtx c;
+	c.E = a.subjects[sub];
+	c.Q = a.qpool + a.qoff[qidx];
+	c.qlen = a.qlen[qidx];
+	c.thr = (uint32_t)c.E.thr;
+	c.border = (uint32_t)c.E.n / 2;
+	return c;
+}
+
+__device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {
+	WorkItem it;
+	it.sub = blockIdx.y;
+	it.w = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+	it.valid = it.w < a.total_segs;
+	it.qidx = it.seg_in_q = it.start = it.end = 0;
+	it.is_self = false;
+	if (it.valid) {
+		it.qidx = a.seg2query[it.w];
+		it.seg_in_q = it.w - a.qseg_start[it.qidx];
+		uint32_t qlen = a.qlen[it.qidx];
+		it.start = it.seg_in_q * a.seg;
+		uint32_t e = it.start + a.seg;
+		it.end = e < qlen ? e : qlen;
+		it.is_self = a.self[it.sub] == (int64_t)it.qidx;
+	}
+	return it;
+}
+
+// ------------------------------------------------------------------ pass A
+__global__ __launch_bounds__(BLOCK) void k_scan_cold(ScanArgs a) {
+	__shared__ uint32_t s_hist[WAVES_PER_BLOCK][16];
+	WorkItem it = decode_item(a);
+	if (!it.valid || it.is_self) return;
+	uint32_t *hist = s_hist[threadIdx.x >> 6];
+	hist_zero(hist);
+
+	PairCtx c = make_ctx(a, it.sub, it.qidx);
+	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, (uint32_t)c.E.n);
+	while (st.p < it.end) st = chain_step(c, st, hist);
+
+	size_t slot = (size_t)it.sub * a.total_segs + it.w;
+	uint32_t lane = __lane_id();
+	if (lane == 0) a.cold_exit[slot] = st;
+	if (lane < 16) a.cold_counts[slot * 16 + lane] = hist[lane];
+}
+
+// Replays the true chain (entering in state T) through [start, end) next to the
+// segment's cold chain.  On return T is the true chain's state on leaving the
+// segment and histT[0..16) the counts it added inside the segment.
+__device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, uint32_t start,
+											   uint32_t end, const ChainState &coldExit,
+											   const uint32_t *coldCounts, uint32_t *histT,
+											   uint32_t *histC) {
+	hist_zero(histT);
+	hist_zero(histC);
+	ChainState C = cold_state(start, (uint32_t)c.E.n);
+	bool synced = false;
+	for (;;) {
+		if (same_state(T, C)) {
+			synced = true;
+			break;
+		}
+		if (T.p >= end) break;
+		if (C.p >= end || T.p <= C.p) {
+			T = chain_step(c, T, histT);
+		} else {
+			C = chain_step(c, C, histC);
+		}
+	}
+	if (synced) {
+		// from the meeting point on, the cold chain's trajectory is the true one
+		uint32_t lane = __lane_id();
+		if (lane < 16) histT[lane] += coldCounts[lane] - histC[lane];
+		T = coldExit;
+	}
+}
+
+// ------------------------------------------------------------------ pass B
+__global__ __launch_bounds__(BLOCK) void k_scan_stitch(ScanArgs a) {
+	__shared__ uint32_t s_hist[WAVES_PER_BLOCK][2][16];
+	WorkItem it = decode_item(a);
+	if (!it.valid || it.is_self) return;
+	size_t slot = (size_t)it.sub * a.total_segs + it.w;
+	uint32_t lane = __lane_id();
+
+	if (it.seg_in_q == 0) { // the first segment's "cold" chain is the true chain
+		if (lane == 0) a.true_exit[slot] = a.cold_exit[slot];
+		if (lane < 16) a.owned[slot * 16 + lane] = a.cold_counts[slot * 16 + lane];
+		return;
+	}
+	uint32_t *histT = s_hist[threadIdx.x >> 6][0], *histC = s_hist[threadIdx.x >> 6][1];
+	PairCtx c = make_ctx(a, it.sub, it.qidx);
+	ChainState T = a.cold_exit[slot - 1]; // assumed entry; verified in pass C
+	stitch_segment(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
+				   histC);
+	if (lane == 0) a.true_exit[slot] = T;
+	if (lane < 16) a.owned[slot * 16 + lane] = histT[lane];
+}
+
+// ------------------------------------------------------------------ pass C
+__global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
+	__shared__ uint32_t s_hist[WAVES_PER_BLOCK][3][16];
+	uint32_t sub = blockIdx.y;
+	uint32_t qidx = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+	if (qidx >= a.nq) return;
+	uint32_t lane = __lane_id();
+	andi_hip_model *out = a.M + (size_t)sub * a.nq + qidx;
+
+	if (a.self[sub] == (int64_t)qidx) { // src/dist_hack.h:61-64
+		if (lane < 17) {
+			uint32_t *o = (uint32_t *)out;
+			o[lane] = (lane == 0 || lane == 16) ? 9u : 0u;
+		}
+		return;
+	}
+
+	uint32_t *total = s_hist[threadIdx.x >> 6][0];
+	uint32_t *histT = s_hist[threadIdx.x >> 6][1], *histC = s_hist[threadIdx.x >> 6][2];
+	hist_zero(total);
+
+	const uint32_t base = a.qseg_start[qidx];
+	const uint32_t nseg = a.qseg_start[qidx + 1] - base;
+	const size_t row = (size_t)sub * a.total_segs + base;
+	PairCtx c = make_ctx(a, sub, qidx);
+
+	// every segment k >= 1 was stitched assuming it is entered in cold_exit[k-1]
+	bool ok = true;
+	for (uint32_t k = 1 + lane; k < nseg; k += 64)
+		ok = ok && same_state(a.true_exit[row + k - 1], a.cold_exit[row + k - 1]);
+	ChainState fin;
+	if (__all(ok)) {
+		for (uint32_t k = lane; k < nseg; k += 64) {
+			const uint32_t *o = a.owned + (row + k) * 16;
+			for (int t = 0; t < 16; ++t) atomicAdd(&total[t], o[t]);
+		}
+		fin = a.true_exit[row + nseg - 1];
+	} else {
+		ChainState st = initial_state();
+		for (uint32_t k = 0; k < nseg; ++k) {
+			ChainState assumed = k == 0 ? initial_state() : a.cold_exit[row + k - 1];
+			if (same_state(st, assumed)) {
+				if (lane < 16) total[lane] += a.owned[(row + k) * 16 + lane];
+				st = a.true_exit[row + k];
+			} else {
+				if (lane == 0) atomicAdd(a.fixups, 1ull);
+				uint32_t start = k * a.seg;
+				uint32_t e = start + a.seg;
+				uint32_t end = e < c.qlen ? e : c.qlen;
+				stitch_segment(c, st, start, end, a.cold_exit[row + k],
+							   a.cold_counts + (row + k) * 16, histT, histC);
+				if (lane < 16) total[lane] += histT[lane];
+			}
+		}
+		fin = st;
+	}
+
+	// src/process.c:199-211
+	if (fin.lastLen >= c.qlen) {
+		count_equal(total, c.qlen);
+	} else if (fin.lwra || fin.lastLen >= 2 * c.thr) {
+		count_equal(total, fin.lastLen);
+	}
+	if (lane < 16) out->counts[lane] = total[lane];
+	if (lane == 0) out->seq_len = c.qlen;
+}
+
+// ------------------------------------------------------------------ K5 hook
+// get_match / get_match_cached for consecutive suffixes of one query, one
+// thread per suffix (test hook and building block; src/esa.c:615-656).
+__global__ __launch_bounds__(256) void k_match_positions(EsaDev E, const uint8_t *q, uint32_t qlen,
+														 uint32_t first, uint32_t count, int cached,
+														 andi_hip_interval *out) {
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= count) return;
+	uint32_t pos = first + k;
+	Ival r = cached ? esa_match_cached<false>(E, q + pos, qlen - pos)
+					: esa_match<false>(E, q + pos, qlen - pos);
+	andi_hip_interval o;
+	o.l = r.l, o.i = r.i, o.j = r.j;
+	o.m = r.i >= 0 ? E.SA[r.i] : -1;
+	out[k] = o;
+}
+
+// ------------------------------------------------------------------ launchers
+hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
+	dim3 grid((a.total_segs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.nsub);
+	k_scan_cold<<<grid, BLOCK, 0, st>>>(a);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
+	dim3 grid((a.total_segs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.nsub);
+	k_scan_stitch<<<grid, BLOCK, 0, st>>>(a);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st) {
+	dim3 grid((a.nq + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.nsub);
+	k_scan_reduce<<<grid, BLOCK, 0, st>>>(a);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_match_positions(const EsaDev &E, const uint8_t *q, uint32_t qlen,
+									   uint32_t first, uint32_t count, int cached,
+									   andi_hip_interval *out, hipStream_t st) {
+	if (count == 0) return hipSuccess;
+	k_match_positions<<<(count + 255) / 256, 256, 0, st>>>(E, q, qlen, first, count, cached, out);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}

@@ -1,0 +1,174 @@
+/*
+ * andi_hip.h — C-ABI of libandihip.so, the MI355X (gfx950) engine behind
+ * andi's anchor-distance hot path.
+ *
+ * The reference has no FFI for this path; its seam is internal:
+ * calculate_distances() (src/process.c:230) allocates the n*n `struct model`
+ * matrix and calls distMatrix()/distMatrixLM() (src/dist_hack.h:34), which per
+ * subject run seq_subject_init (src/sequence.c:210), esa_init
+ * (src/esa.c:254) and, per query, dist_anchor (src/process.c:141).  Every
+ * entry point below names the reference function it replaces.  All
+ * signatures are plain C: pointers, sizes, PODs.  Functions return 0 on
+ * success; on failure they return non-zero and write a message to
+ * errbuf (when given).  Nothing here falls back to a CPU implementation of a
+ * device step: without a usable HIP device the device entry points fail.
+ */
+#ifndef ANDI_HIP_H
+#define ANDI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANDI_HIP_ABI_VERSION 1
+
+/* enum in src/global.h:50 */
+enum { ANDI_M_RAW = 0, ANDI_M_JC = 1, ANDI_M_KIMURA = 2, ANDI_M_LOGDET = 3, ANDI_M_ANI = 4 };
+
+/* seq_t (src/sequence.h:18-25) without the name: NUL-terminated, over
+ * {A,C,G,T,!} as produced by normalize() (src/sequence.c:260-282). */
+typedef struct {
+	const char *seq;
+	size_t len;
+} andi_hip_seq;
+
+/* struct model (src/model.h:52-57): counts[4*from+to], then the query length.
+ * 68 bytes, no padding. */
+typedef struct {
+	uint32_t counts[16];
+	uint32_t seq_len;
+} andi_hip_model;
+
+/* lcp_inter_t (src/esa.h:25-34) */
+typedef struct {
+	int32_t l, i, j, m;
+} andi_hip_interval;
+
+/* The globals the reference reads deep inside the path, made explicit:
+ * ANCHOR_P_VALUE (src/andi.c:48), MODEL (src/andi.c:50; selects the equal-run
+ * attribution of src/model.c:247), THREADS (src/andi.c:46), F_LOW_MEMORY
+ * (src/global.h:63), the progress line of src/dist_hack.h:40-43,74-87. */
+typedef struct {
+	double p_value;
+	int model;
+	int device;        /* HIP device ordinal */
+	int host_threads;  /* <=0: all cores (suffix sorting pool) */
+	int low_memory;    /* bound the number of resident subject indexes */
+	uint32_t segment;  /* query nucleotides per scan work item; 0 = default */
+	void (*progress)(size_t done, size_t total, void *ud);
+	void *ud;
+} andi_hip_opts;
+
+void andi_hip_default_opts(andi_hip_opts *o);
+int andi_hip_abi_version(void);
+
+/* ------------------------------------------------------------------ */
+/* The seam: replaces distMatrix / distMatrixLM (src/dist_hack.h:34-96) */
+/* as called from calculate_distances (src/process.c:247-251).         */
+/* M is caller-owned, n*n row-major, M[i*n+j] = subject i vs query j,  */
+/* diagonal = {counts[0]=9, seq_len=9} (src/dist_hack.h:61-64).        */
+/* ------------------------------------------------------------------ */
+int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
+						 const andi_hip_opts *opts, char *errbuf, size_t errlen);
+
+/* ------------------------------------------------------------------ */
+/* Host pieces of the path (stay on the host, same libm)               */
+/* ------------------------------------------------------------------ */
+/* seq_subject_init (src/sequence.c:210-219): RS = revcomp(S) '#' S '\0'
+ * (malloc'ed, free with andi_hip_free), RSlen = 2*len+1, gc, threshold. */
+int andi_hip_subject_prepare(const char *seq, size_t len, double p_value,
+							 char **RS, size_t *RSlen, double *gc, size_t *threshold);
+void andi_hip_free(void *p);
+/* min_anchor_length / shustring_cum_prob (src/sequence.c:296-304,353-373) */
+size_t andi_hip_min_anchor_length(double p, double g, size_t l);
+double andi_hip_shustring_cum_prob(size_t x, double p, size_t l);
+/* divsufsort() as called at src/esa.c:303: T[0..n) unsigned bytes, T[n]
+ * must be readable; SA[0..n).  Re-entrant. */
+int andi_hip_suffix_array(const unsigned char *T, int32_t *SA, int32_t n);
+/* model_average / model_coverage / estimate_* (src/model.c:39-210) */
+andi_hip_model andi_hip_model_average(const andi_hip_model *a, const andi_hip_model *b);
+double andi_hip_model_coverage(const andi_hip_model *m);
+double andi_hip_estimate(const andi_hip_model *m, int model);
+/* print_distances (src/io.c:246-322) into a caller buffer: PHYLIP text of the
+ * n*n matrix.  names[i] as seq_t.name.  Returns the number of bytes needed
+ * (excluding NUL); writes at most cap.  *warn_flags gets bit0 = a NaN was
+ * reported, bit1 = coverage < 0.2 reported; warning lines go to warnbuf. */
+size_t andi_hip_format_distances(const andi_hip_model *M, const char *const *names, size_t n,
+								 int model, int extra_verbose, int truncate_names, int warnings,
+								 char *out, size_t cap, char *warnbuf, size_t warncap,
+								 int *warn_flags);
+
+/* ------------------------------------------------------------------ */
+/* Device-resident objects                                             */
+/* ------------------------------------------------------------------ */
+typedef struct andi_hip_ctx andi_hip_ctx;         /* device + streams + scratch */
+typedef struct andi_hip_esa andi_hip_esa;         /* one subject's esa_s (src/esa.h:42-59) in HBM */
+typedef struct andi_hip_queries andi_hip_queries; /* all query sequences in HBM */
+
+int andi_hip_ctx_create(andi_hip_ctx **ctx, int device, char *errbuf, size_t errlen);
+void andi_hip_ctx_destroy(andi_hip_ctx *ctx);
+const char *andi_hip_last_error(const andi_hip_ctx *ctx);
+int andi_hip_sync(andi_hip_ctx *ctx);
+
+/* Upload RS (n bytes + NUL) and its suffix array (esa_init_SA's output,
+ * src/esa.c:294-304).  Host→device copies only. */
+int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, size_t n,
+					   size_t threshold, andi_hip_esa **out);
+/* esa_init_LCP, _CLD, _FVC, _cache (src/esa.c:373-426, 312-363, 229-245,
+ * 73-215) as HIP kernels on the context's stream (asynchronous). */
+int andi_hip_esa_build(andi_hip_ctx *ctx, andi_hip_esa *esa);
+/* Test hook: copy the built arrays back.  Any pointer may be NULL.
+ * LCP/CLD have n+1 entries, FVC n, cache 4^10. */
+int andi_hip_esa_download(andi_hip_ctx *ctx, const andi_hip_esa *esa, int32_t *LCP,
+						  int32_t *CLD, uint8_t *FVC, andi_hip_interval *cache);
+void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *esa);
+size_t andi_hip_esa_bytes(const andi_hip_esa *esa);
+
+int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n,
+						   andi_hip_queries **out);
+void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q);
+
+/* get_match_cached / get_match (src/esa.c:615-656) for `count` consecutive
+ * suffixes of query `qidx`: out[k] = match of Q[first+k ..] (fields l,i,j;
+ * m = SA[i], the pos_S dist_anchor would use, src/process.c:120). */
+int andi_hip_match_positions(andi_hip_ctx *ctx, const andi_hip_esa *esa,
+							 const andi_hip_queries *q, size_t qidx, size_t first, size_t count,
+							 int cached, andi_hip_interval *out_host);
+
+/* dist_anchor (src/process.c:141-214) for every (subject, query) pair of
+ * `nsub` staged+built subjects against all queries.  self[s] = index of the
+ * query that is subject s itself (gets the diagonal placeholder) or -1.
+ * M_dev: device pointer, nsub * nq models, row s = subject s.  Asynchronous
+ * on the context's stream. */
+int andi_hip_scan_rows(andi_hip_ctx *ctx, const andi_hip_esa *const *subjects,
+					   const int64_t *self, size_t nsub, const andi_hip_queries *q, int model,
+					   uint32_t segment, andi_hip_model *M_dev);
+
+/* plain device memory helpers so callers need no HIP headers */
+int andi_hip_dev_alloc(andi_hip_ctx *ctx, size_t bytes, void **dptr);
+void andi_hip_dev_free(andi_hip_ctx *ctx, void *dptr);
+int andi_hip_copy_to_host(andi_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* Kernel timing, measured with HIP events on the stream the kernels run on.
+ * Accumulates since the last reset; read after andi_hip_sync(). */
+typedef struct {
+	double build_ms;      /* K1-K4 */
+	uint64_t build_launches;
+	double scan_ms;       /* anchor scan pass A (the dominant kernel) */
+	uint64_t scan_launches;
+	double stitch_ms;     /* passes B + C */
+	uint64_t stitch_launches;
+	uint64_t scan_query_nt; /* sum of query lengths over scanned pairs */
+	uint64_t scan_pairs;
+	uint64_t fixups;      /* segments whose speculative entry state was wrong */
+} andi_hip_timings;
+int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t);
+void andi_hip_timings_reset(andi_hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

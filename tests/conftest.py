@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def unpack(packed, length):
+    """2-bit packed golden sequence -> ACGT bytes."""
+    p = np.asarray(packed, np.uint8)
+    codes = np.stack([(p >> s) & 3 for s in (0, 2, 4, 6)], axis=1).reshape(-1)[:length]
+    return np.frombuffer(b"ACGT", np.uint8)[codes].tobytes()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import orc as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def golden_s42():
+    z = np.load(os.path.join(GOLDEN, "testfasta_s42.npz"))
+    n = int(z["length"][0])
+    out = {"s0": unpack(z["s0"], n)}
+    for d in ("0.1", "0.01", "0.001"):
+        out["s1_" + d] = unpack(z["s1_" + d], n)
+        out["counts_" + d] = z["counts_" + d]
+        out["stats_" + d] = z["stats_" + d]
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden_s1729():
+    z = np.load(os.path.join(GOLDEN, "testfasta_s1729.npz"))
+    n = int(z["length"][0])
+    return {"seqs": [unpack(z["s%d" % k], n) for k in range(3)], "counts_jc": z["counts_jc"]}
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One device context for the whole GPU session (fails loudly without a GPU)."""
+    import andi_amd
+    c = andi_amd.Context(0)
+    yield c
+    c.close()
+
+
+def rand_dna(rng, n, alphabet=b"ACGT"):
+    return rng.choice(np.frombuffer(alphabet, np.uint8), n).tobytes()

@@ -1,0 +1,120 @@
+"""Device index build (K1-K4) and longest-match queries (K5) against the oracle.
+Bit-exact; calls go through the C-ABI."""
+import numpy as np
+import pytest
+
+from conftest import rand_dna
+from test_oracle_pins import FIX200, FIX200_SEP
+
+pytestmark = pytest.mark.gpu
+
+
+def _subjects():
+    from andi_amd import synth
+    rng = np.random.default_rng(21)
+    yield "tiny", b"ACGTTGCA"
+    yield "one-char", b"A"
+    yield "homopolymer", b"A" * 500
+    yield "fix200", FIX200
+    yield "fix200-sep", FIX200_SEP
+    yield "random-3k", rand_dna(rng, 3000)
+    yield "two-letter", rand_dna(rng, 5000, b"AT")
+    yield "repeats", rand_dna(rng, 700) * 9 + rand_dna(rng, 300)
+    yield "joined", synth.join_contigs(rand_dna(rng, 40000), 12)
+    yield "random-300k", rand_dna(rng, 300000)
+    yield "palindromic", (lambda s: s + s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")))(rand_dna(rng, 20000))
+
+
+@pytest.mark.parametrize("name,seq", list(_subjects()), ids=[n for n, _ in _subjects()])
+def test_index_arrays_bit_exact(ctx, orc, name, seq):
+    import andi_amd
+    O = orc.OracleEsa(seq)
+    E = andi_amd.Esa(ctx, seq)
+    assert E.RS == O.RS and E.threshold == O.threshold
+    LCP, CLD, FVC, cache = E.download()
+    assert (LCP == O.LCP).all()
+    # FVC[0] = S[SA[0]-1] is never consulted; both sides compute it the same way
+    assert (FVC == O.FVC).all()
+    # child table: identical on every slot the sweep writes; unwritten = -1 on both sides
+    assert (CLD == O.CLD).all()
+    # 10-mer table: the fields callers use (src/test/test_esa.c:32-36) plus m
+    assert (cache == O.cache).all()
+    E.close()
+    O.close()
+
+
+@pytest.mark.parametrize("fix", [FIX200, FIX200_SEP], ids=["fix200", "fix200-sep"])
+def test_all_11mers_cached_equals_uncached(ctx, orc, fix):
+    """test/test_esa.c:172-192 (prefix_dfs over ALL 4^11 11-mers): cached ==
+    uncached on (l,i,j), the match is a true and maximal prefix match; on the
+    device, and a 1/61 sample of them also against the oracle.
+
+    The 11-mers are laid out in one query as XXXXXXXXXXXN: 'N' never occurs in
+    RS, so the match of the suffix starting at an 11-mer ends exactly where a
+    query of length 11 would end."""
+    import andi_amd
+    E = andi_amd.Esa(ctx, fix)
+    O = orc.OracleEsa(fix)
+    rs = np.frombuffer(O.RS + b"\0", np.uint8)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    shifts = 2 * (10 - np.arange(11))
+    block = 4 ** 9
+    for start in range(0, 4 ** 11, block):
+        codes = np.arange(start, start + block, dtype=np.int64)
+        kmers = acgt[(codes[:, None] >> shifts[None, :]) & 3]
+        text = np.concatenate([kmers, np.full((block, 1), ord("N"), np.uint8)], axis=1)
+        Q = andi_amd.Queries(ctx, [text.tobytes()])
+        a = andi_amd.match_positions(E, Q, 0, 0, 12 * block, cached=True)[::12]
+        b = andi_amd.match_positions(E, Q, 0, 0, 12 * block, cached=False)[::12]
+        Q.close()
+        assert (a == b).all()
+        l, pos = a[:, 0].astype(np.int64), a[:, 3].astype(np.int64)
+        assert (l >= 0).all() and (l <= 11).all()
+        # true prefix match ...
+        for t in range(11):
+            sel = l > t
+            assert (rs[pos[sel] + t] == kmers[sel, t]).all()
+        # ... and maximal
+        sel = l < 11
+        assert (rs[pos[sel] + l[sel]] != kmers[sel, l[sel]]).all()
+        for k in range(start % 61, block, 61):
+            assert tuple(a[k][:3]) == O.get_match(kmers[k].tobytes(), True)
+    E.close()
+    O.close()
+
+
+def _match_all_positions(ctx, orc, subject, query):
+    import andi_amd
+    E = andi_amd.Esa(ctx, subject)
+    O = orc.OracleEsa(subject)
+    Q = andi_amd.Queries(ctx, [query])
+    n = len(query)
+    for cached in (True, False):
+        got = andi_amd.match_positions(E, Q, 0, 0, n, cached=cached)
+        step = 1 if n <= 4000 else max(1, n // 4000)
+        for p in list(range(0, n, step)) + list(range(max(0, n - 15), n)):
+            l, i, j = O.get_match(query[p:], cached)
+            assert tuple(got[p][:3]) == (l, i, j), (cached, p)
+            assert got[p][3] == O.SA[i]
+    Q.close()
+    E.close()
+    O.close()
+
+
+def test_match_every_position_small(ctx, orc):
+    from andi_amd import synth
+    a, b = synth.pair(3000, 0.05, seed=5)
+    _match_all_positions(ctx, orc, a, b)
+    _match_all_positions(ctx, orc, FIX200_SEP, FIX200)
+    _match_all_positions(ctx, orc, FIX200, FIX200_SEP)  # '!' inside the query
+
+
+def test_match_positions_joined_and_unrelated(ctx, orc):
+    from andi_amd import synth
+    rng = np.random.default_rng(8)
+    g = rand_dna(rng, 120000)
+    a = synth.join_contigs(g, 7, seed=1)
+    b = synth.join_contigs(synth.to_bytes(synth.mutate_codes(
+        np.frombuffer(g.translate(bytes.maketrans(b"ACGT", bytes(range(4)))), np.uint8), 0.02, 3)), 5, seed=2)
+    _match_all_positions(ctx, orc, a, b)
+    _match_all_positions(ctx, orc, rand_dna(rng, 50000), rand_dna(rng, 20000))

@@ -1,0 +1,117 @@
+"""Host side of the product (libandihip.so) against the oracle; C-ABI surface.
+No GPU needed: nothing here launches a kernel."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rand_dna
+
+
+def test_library_exports_every_declared_symbol():
+    from andi_amd import lib
+    L = lib.load()
+    header = open(os.path.join(ROOT, "include", "andi_hip.h")).read()
+    declared = set(re.findall(r"\b(andi_hip_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.andi_hip_abi_version() == 1
+    assert C.sizeof(lib.Model) == 68 and C.sizeof(lib.Interval) == 16
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    from andi_amd import lib
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(lib.AndiHipError):
+        lib.Context(0)
+    with pytest.raises(lib.AndiHipError):
+        lib.dist_matrix([b"ACGTACGTACGT", b"ACGTACGAACGT"])
+
+
+def test_subject_prepare_matches_oracle(orc):
+    from andi_amd import lib
+    rng = np.random.default_rng(3)
+    assert lib.subject_prepare(b"ACGTTGCA")[0] == b"TGCAACGT#ACGTTGCA"  # test/test_seq.c:34
+    assert lib.subject_prepare(b"ACGT!TGCA")[0] == b"TGCA;ACGT#ACGT!TGCA"  # test/test_seq.c:69
+    for trial in range(60):
+        n = int(rng.integers(1, 5000))
+        s = rand_dna(rng, n, [b"ACGT", b"AC", b"GGC", b"ACGT!"][trial % 4])
+        if not s.replace(b"!", b""):
+            continue
+        RS, gc, thr = lib.subject_prepare(s, 0.025)
+        E = orc.OracleEsa(s)
+        assert RS == E.RS and gc == E.gc and thr == E.threshold
+    for p in (0.5, 0.1, 0.025, 1e-3, 1e-6):
+        for g in (0.2, 0.5, 0.7):
+            for l in (100, 20001, 9800001):
+                assert lib.min_anchor_length(p, g, l) == orc.lib().orc_min_anchor_length(p, g, l)
+                x = lib.min_anchor_length(p, g, l)
+                assert lib.shustring_cum_prob(x, g / 2, l) == orc.lib().orc_shustring_cum_prob(x, g / 2, l)
+
+
+def test_threshold_minimal():
+    # test/test_process.c:16-29 against the product's host code
+    from andi_amd import lib
+    thr = lib.min_anchor_length(0.025, 0.5, 100000)
+    assert 0.975 < lib.shustring_cum_prob(thr + 1, 0.25, 100000)
+    assert 0.975 <= lib.shustring_cum_prob(thr, 0.25, 100000)
+    assert 0.975 > lib.shustring_cum_prob(thr - 1, 0.25, 100000)
+
+
+def test_suffix_array_matches_oracle_sorter(orc):
+    from andi_amd import lib
+    rng = np.random.default_rng(5)
+    cases = [b"A", b"AA", b"AAAAAAAAAAAAAAAA", b"ACGT", b"TGCA", b"ABABABABAB", b"banana", b"mississippi"]
+    for trial in range(80):
+        n = int(rng.integers(1, 3000))
+        cases.append(rand_dna(rng, n, [b"ACGT", b"AC", b"A", b"ACGT!#;"][trial % 4]))
+    cases.append(rand_dna(rng, 50, b"ACGT") * 40)  # long repeats
+    cases.append(lib.subject_prepare(rand_dna(rng, 200000, b"ACGT"))[0])
+    for t in cases:
+        assert (lib.suffix_array(t) == orc.suffix_array(t)).all()
+
+
+def test_estimators_and_printer_match_oracle(orc):
+    from andi_amd import lib
+    rng = np.random.default_rng(9)
+    n = 5
+    M = rng.integers(0, 2000, size=(n, n, 17), dtype=np.uint32)
+    M[:, :, [0, 5, 10, 15]] += 40000
+    M[:, :, 16] = 200000
+    M[1, 2, :16] = 0  # NaN pair in one direction only
+    M[3, 4, :16] //= 100  # low coverage
+    for model in (lib.M_RAW, lib.M_JC, lib.M_KIMURA, lib.M_LOGDET, lib.M_ANI):
+        for i in range(n):
+            for j in range(n):
+                a, b = lib.estimate(M[i, j], model), orc.estimate(M[i, j], model)
+                assert (np.isnan(a) and np.isnan(b)) or a == b
+    assert lib.coverage(M[0, 1]) == orc.coverage(M[0, 1])
+    names = ["S%d" % k for k in range(n - 1)] + ["a_rather_long_name"]
+    text, warn, flags = lib.format_distances(M, names, lib.M_JC)
+    lines = text.splitlines()
+    assert lines[0] == str(n) and len(lines) == n + 1
+    assert lines[1].startswith("S0         0.0000 ")
+    assert lines[n].startswith("a_rather_long_name ")
+    avg = M[0, 1].astype(np.uint64) + M[1, 0]
+    assert lines[1].split()[2] == "%1.4f" % orc.estimate(avg, orc.M_JC)
+    assert "very little homology" in warn and flags & 2
+    text_t, _, _ = lib.format_distances(M, names, lib.M_JC, truncate_names=True)
+    assert text_t.splitlines()[n].startswith("a_rather_l ")
+    # scientific notation as soon as one distance is in (0, 0.001)  (src/io.c:280-282)
+    M2 = M.copy()
+    M2[0, 1, :16] = M2[1, 0, :16] = 0
+    M2[0, 1, [0, 5, 10, 15]] = M2[1, 0, [0, 5, 10, 15]] = 50000
+    M2[0, 1, 1] = 3
+    text2, _, _ = lib.format_distances(M2, names, lib.M_JC)
+    assert "e-0" in text2.splitlines()[1]
+    # all-zero counts -> nan + warning (src/io.c:284-291)
+    M3 = M.copy()
+    M3[1, 2, :16] = M3[2, 1, :16] = 0
+    text3, warn3, flags3 = lib.format_distances(M3, names, lib.M_JC)
+    assert "nan" in text3 and "reported as nan" in warn3 and flags3 & 1

@@ -1,0 +1,166 @@
+"""Anchor scan (dist_anchor, K5-K7) on the device against the oracle and the
+golden vectors: bit-exact 17 x u32 per ordered pair, through the C-ABI."""
+import numpy as np
+import pytest
+
+from conftest import rand_dna
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_rows(ctx, seqs, subjects=None, model=1, segment=0, p_value=0.025):
+    import andi_amd
+    subjects = list(range(len(seqs))) if subjects is None else subjects
+    Q = andi_amd.Queries(ctx, seqs)
+    esas = [andi_amd.Esa(ctx, seqs[i], p_value) for i in subjects]
+    out = andi_amd.scan_rows(ctx, esas, subjects, Q, model, segment)
+    t = ctx.timings()
+    for e in esas:
+        e.close()
+    Q.close()
+    return out, t
+
+
+def _check_set(ctx, orc, seqs, segments=(0,), model=1):
+    want = orc.dist_matrix(seqs, model=model, threads=4)
+    for seg in segments:
+        got, _ = _gpu_rows(ctx, seqs, model=model, segment=seg)
+        assert got.shape == want.shape
+        bad = np.argwhere((got != want).any(axis=2))
+        assert len(bad) == 0, (seg, bad[:5], got[tuple(bad[0])] if len(bad) else None,
+                               want[tuple(bad[0])] if len(bad) else None)
+
+
+def test_pair_ladder(ctx, orc):
+    """test/test_random.sh's divergence ladder, counts bit-exact instead of +-5.5 %."""
+    from andi_amd import synth
+    for d in (0.0, 0.001, 0.01, 0.02, 0.05, 0.1, 0.2, 0.3):
+        a, b = synth.pair(100000, d, seed=100 + int(d * 1000))
+        _check_set(ctx, orc, [a, b], segments=(0, 4096))
+
+
+def test_tiny_segments_stress_stitching(ctx, orc):
+    """Segments far shorter than the resynchronisation distance force the
+    fix-up path of pass C; the counts must not change."""
+    from andi_amd import synth
+    a, b = synth.pair(60000, 0.03, seed=77)
+    c = synth.to_bytes(synth.mutate_codes(synth.base_codes(60000, 77), 0.002, 9))
+    want = orc.dist_matrix([a, b, c], threads=3)
+    for seg in (64, 300, 1000, 1 << 20):
+        got, t = _gpu_rows(ctx, [a, b, c], segment=seg)
+        assert (got == want).all(), seg
+
+
+def test_identical_unrelated_short(ctx, orc):
+    rng = np.random.default_rng(31)
+    g = rand_dna(rng, 50000)
+    # identical sequences (src/process.c:199-203), unrelated (test/nan.sh), low homology (test/low_homo.sh)
+    h = rand_dna(rng, 50000)
+    low = g[:100] + rand_dna(rng, 49900)
+    _check_set(ctx, orc, [g, g, h, low], segments=(0, 1024))
+    # sequences shorter than 1000 nt only warn in the reference (src/andi.c:306-316)
+    _check_set(ctx, orc, [rand_dna(rng, 40), rand_dna(rng, 11), rand_dna(rng, 10), rand_dna(rng, 300), b"ACGT"],
+               segments=(0, 16))
+
+
+def test_join_mode_and_revcomp(ctx, orc):
+    """'!' separators (test/test_join.sh) and a query on the reverse strand."""
+    from andi_amd import synth
+    base = synth.base_codes(150000, 5)
+    a = synth.join_contigs(synth.to_bytes(base), 3, seed=1)
+    b = synth.join_contigs(synth.to_bytes(synth.mutate_codes(base, 0.1, 6, raw=True)), 2, seed=2)
+    c = synth.join_contigs(synth.to_bytes(synth.mutate_codes(base, 0.1, 7, raw=True)), 40, seed=3)
+    rc = synth.to_bytes(synth.mutate_codes(base, 0.05, 8))[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+    _check_set(ctx, orc, [a, b, c, rc], segments=(0, 2048))
+
+
+def test_repeats_and_models(ctx, orc):
+    rng = np.random.default_rng(41)
+    unit = rand_dna(rng, 3000)
+    from andi_amd import synth
+    g = rand_dna(rng, 30000) + unit + rand_dna(rng, 20000) + unit + rand_dna(rng, 10000) + unit
+    codes = np.frombuffer(g.translate(bytes.maketrans(b"ACGT", bytes(range(4)))), np.uint8)
+    h = synth.to_bytes(synth.mutate_codes(codes, 0.02, 4))
+    for model in (0, 1, 2):
+        _check_set(ctx, orc, [g, h], segments=(0, 512), model=model)
+
+
+def test_anchor_significance_parameter(ctx, orc):
+    from andi_amd import synth
+    a, b = synth.pair(80000, 0.05, seed=12)
+    for p in (0.5, 1e-4):
+        want = orc.dist_matrix([a, b], p_value=p, threads=2)
+        import andi_amd
+        Q = andi_amd.Queries(ctx, [a, b])
+        esas = [andi_amd.Esa(ctx, s, p) for s in (a, b)]
+        got = andi_amd.scan_rows(ctx, esas, [0, 1], Q)
+        assert (got == want).all(), p
+        for e in esas:
+            e.close()
+        Q.close()
+
+
+def test_unsupported_models_fail_loudly(ctx):
+    import andi_amd
+    from andi_amd import synth
+    a, b = synth.pair(5000, 0.05)
+    Q = andi_amd.Queries(ctx, [a, b])
+    E = andi_amd.Esa(ctx, a)
+    with pytest.raises(andi_amd.AndiHipError):
+        andi_amd.scan_rows(ctx, [E], [0], Q, model=andi_amd.M_LOGDET)
+    E.close()
+    Q.close()
+
+
+def test_golden_testfasta_s42(ctx, golden_s42):
+    """Inputs from the reference's generator; expected counts committed in
+    tests/golden (the oracle's, itself pinned to the reference's statistics)."""
+    import andi_amd
+    s0 = golden_s42["s0"]
+    E = andi_amd.Esa(ctx, s0)
+    assert E.threshold == 14
+    for d in ("0.1", "0.01", "0.001"):
+        q = golden_s42["s1_" + d]
+        Q = andi_amd.Queries(ctx, [q])
+        for seg in (0, 5000):
+            got = andi_amd.scan_rows(ctx, [E], [-1], Q, andi_amd.M_JC, seg)
+            assert (got[0, 0] == golden_s42["counts_" + d]).all(), (d, seg)
+        Q.close()
+    E.close()
+
+
+def test_golden_testfasta_s1729_dist_matrix(golden_s1729):
+    """The one-call seam (distMatrix) on the 3 x 1 Mbp plumbing case
+    (BASELINE.json configs[0]); PHYLIP text equals what andi printed."""
+    import andi_amd
+    seqs = golden_s1729["seqs"]
+    M = andi_amd.dist_matrix(seqs, model=andi_amd.M_JC, host_threads=3)
+    assert (M == golden_s1729["counts_jc"]).all()
+    text, warn, flags = andi_amd.format_distances(M, ["S0", "S1", "S2"], andi_amd.M_JC)
+    rows = [l.split() for l in text.splitlines()[1:]]
+    assert [rows[0][2], rows[0][3], rows[1][3]] == ["0.0982", "0.0984", "0.1955"]
+    assert flags == 0 and warn == ""
+
+
+def test_full_size_properties(ctx, orc):
+    """BASELINE.json configs[1] genome length (4.9 Mbp): a pair at full size,
+    checked through size-independent properties and against the oracle."""
+    from andi_amd import synth
+    import andi_amd
+    n = 4_900_000
+    base = synth.base_codes(n, 1729)
+    a = synth.to_bytes(synth.mutate_codes(base, 0.004, 1))
+    b = synth.to_bytes(synth.mutate_codes(base, 0.02, 2))
+    got, t = _gpu_rows(ctx, [a, b], segment=0)
+    # diagonal placeholder, seq_len, coverage <= 1, symmetric-ish distances
+    assert got[0, 0, 0] == 9 and got[0, 0, 16] == 9 and got[1, 1, 16] == 9
+    assert got[0, 1, 16] == n and got[1, 0, 16] == n
+    assert got[0, 1, :16].sum() <= n and got[1, 0, :16].sum() <= n
+    d01 = andi_amd.estimate(got[0, 1]), andi_amd.estimate(got[1, 0])
+    assert abs(d01[0] - 0.024) < 0.0015 and abs(d01[1] - 0.024) < 0.0015
+    # independent of the segmentation (idempotence of the stitching)
+    got2, _ = _gpu_rows(ctx, [a, b], segment=100_000)
+    assert (got == got2).all()
+    # and equal to the sequential oracle
+    want = orc.dist_matrix([a, b], threads=2)
+    assert (got == want).all()
