@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Benchmark of the anchor-distance hot path on MI355X.
+
+Metric (BASELINE.json): ordered genome-pairs/sec over the N x N loop
+(n^2 - n comparisons, the unit of the reference's progress counter,
+src/dist_hack.h:41-42), plus the achieved HBM GB/s of the anchor-scan kernel
+against the 8 TB/s roofline.
+
+Workload at --gpus 1: BASELINE.json configs[1] as synthetic data ("C2-synth",
+SURVEY.md §8d): 29 genomes of 4.9 Mbp, each diverged from a common base by
+d_k ~ U[0.0004, 0.03], JC model.  One step = one pass of the device path over
+the whole set: per subject the index build (LCP, child table, FVC, 10-mer
+table; K1-K4) from the resident RS + suffix array, then the anchor scan of every
+query against every subject (K5-K7), then (N > 1) the RCCL gather of the row
+blocks on rank 0.  Suffix arrays are built on the host and uploaded before the
+timed region (north_star: "SA ... on host"); their cost is reported under
+"end_to_end", never in "value".
+
+N > 1 (one process per GPU, launched by torch.distributed.run): one G x G
+matrix with G ~ 29*sqrt(N) genomes, rows block-partitioned over the ranks, so
+per-GPU work stays that of one 29 x 29 set ("weak").  No data-path collective;
+one gather at the end.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genomes", type=int, default=0, help="genomes in the set (default: 29 at 1 GPU)")
+    ap.add_argument("--length", type=int, default=4_900_000)
+    ap.add_argument("--dlo", type=float, default=0.0004)
+    ap.add_argument("--dhi", type=float, default=0.03)
+    ap.add_argument("--segment", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1729)
+    return ap.parse_args()
+
+
+def set_size(n_gpus):
+    table = {1: 29, 2: 42, 4: 60, 8: 80}
+    if n_gpus in table:
+        return table[n_gpus]
+    return n_gpus * max(1, round(29 / math.sqrt(n_gpus)))
+
+
+def row_block(total, world, rank):
+    """Contiguous block of subject rows owned by `rank` (sizes differ by <= 1)."""
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def cpu_baseline(seqs, p_value, model):
+    """The oracle (a port of the reference's OpenMP path, subject-parallel like
+    distMatrix) on this box's host cores, whole workload.  Checker code: timed
+    as a baseline only, never part of the product path."""
+    from oracle import orc
+    cores = os.cpu_count() or 1
+    threads = min(cores, len(seqs))
+    t0 = time.time()
+    M, (t_build, t_scan) = orc.dist_matrix(seqs, p_value=p_value, model=model, threads=threads, times=True)
+    wall = time.time() - t0
+    n = len(seqs)
+    return M, {
+        "value": (n * n - n) / wall, "unit": "pairs/s", "cores": threads, "kind": "port",
+        "sample": "whole workload: %d genomes, %d ordered pairs, index build (own suffix sorter, not "
+                  "libdivsufsort) + scan, %.1f s wall" % (n, n * n - n, wall),
+        "host_cores_available": cores,
+        "index_build_core_s": t_build, "scan_core_s": t_scan,
+        "scan_only_pairs_per_s_per_core": (n * n - n) / t_scan if t_scan > 0 else None,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = max(args.gpus, 1)
+    if world != n_gpus and world > 1:
+        n_gpus = world
+
+    import numpy as np
+    import torch
+
+    import andi_amd
+    from andi_amd import lib, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the anchor-distance engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    G = args.genomes or set_size(world)
+    model = andi_amd.M_JC
+    p_value = 0.025
+    t_gen = time.time()
+    seqs, ds = synth.genome_set(G, args.length, args.dlo, args.dhi, seed=args.seed)
+    t_gen = time.time() - t_gen
+
+    r0, r1 = row_block(G, world, rank)
+    ctx = andi_amd.Context(local_rank)
+    # ---- untimed staging: queries, and for the owned rows RS + host suffix array
+    t_stage = time.time()
+    Q = andi_amd.Queries(ctx, seqs)
+    esas = [andi_amd.Esa(ctx, seqs[i], p_value, build=False) for i in range(r0, r1)]
+    ctx.sync()
+    t_stage = time.time() - t_stage
+    nsub = r1 - r0
+    rows_max = max(row_block(G, world, r)[1] - row_block(G, world, r)[0] for r in range(world))
+    block = torch.zeros((rows_max, G, 17), dtype=torch.int32, device="cuda")
+    gathered = None
+    if world > 1:
+        gathered = torch.zeros((world, rows_max, G, 17), dtype=torch.int32, device="cuda")
+    selfs = list(range(r0, r1))
+    dptr = andi_amd.lib._P(block.data_ptr())
+
+    def step():
+        for e in esas:
+            e.build()  # K1-K4
+        lib.scan_rows_dev(ctx, esas, selfs, Q, model, args.segment, dptr)  # K5-K7
+        ctx.sync()  # the engine's stream is not torch's: finish before the collective
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, block)  # RCCL over xGMI; rank 0 keeps the matrix
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.timings_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tm = ctx.timings()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pairs_total = G * G - G
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = pairs_total / (elapsed / args.steps)
+
+    # roofline of the dominant kernel (pass A of the scan) from HIP events on
+    # the engine's own stream: algorithmic bytes = 2 * query length per pair
+    launches = max(int(tm["scan_launches"]), 1)
+    scan_ms = tm["scan_ms"] / launches
+    alg_bytes = 2.0 * tm["scan_query_nt"] / launches
+    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(prof):
+        try:
+            rec = json.load(open(prof))
+            key = "G%d_L%d_seg%d" % (G, args.length, args.segment)
+            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = None
+    if rank == 0:
+        full = block[:nsub].cpu().numpy().view(np.uint32) if world == 1 else None
+        if world > 1:
+            parts = []
+            for r in range(world):
+                a, b = row_block(G, world, r)
+                parts.append(gathered[r, : b - a].cpu().numpy().view(np.uint32))
+            full = np.concatenate(parts, axis=0)
+        dmat = [andi_amd.estimate(full[0, j].astype(np.uint64) + full[j, 0], model) for j in range(1, min(G, 4))]
+        out = {
+            "metric": "genome-pairs/sec (ordered pairs, n^2-n) over the N x N anchor-distance loop",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C2-synth: %d genomes x %d nt, d~U[%g,%g] from a common base, JC, "
+                                   "seed %d; rows block-partitioned over %d GPU(s)"
+                                   % (G, args.length, args.dlo, args.dhi, args.seed, world),
+                       "genomes": G, "length": args.length, "model": "JC", "pairs": pairs_total,
+                       "segment": args.segment or 16384},
+            "roofline": {"bound": "hbm", "kernel": "k_scan_cold", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_ms,
+                         "launches": int(tm["scan_launches"])},
+            "breakdown_ms_per_step": {"index_build_K1_K4": tm["build_ms"] / args.steps,
+                                      "scan_cold_pass": tm["scan_ms"] / args.steps,
+                                      "scan_stitch_reduce": tm["stitch_ms"] / args.steps,
+                                      "fixups": int(tm["fixups"])},
+            "end_to_end": {"note": "rank 0, untimed staging: host RS + suffix arrays (SA-IS, 1 thread) + H2D",
+                           "staging_s": t_stage, "generate_s": t_gen,
+                           "pairs_per_s_incl_staging": (nsub * (G - 1)) / (t_stage + elapsed / args.steps)},
+            "sample_distances": dmat,
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        Mcpu, base = cpu_baseline(seqs, p_value, model)
+        out["cpu_baseline"] = base
+        out["parity_vs_cpu_baseline"] = bool((Mcpu == full).all())
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    for e in esas:
+        e.close()
+    Q.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
