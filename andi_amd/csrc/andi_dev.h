@@ -26,7 +26,30 @@ struct EsaDev {
 	int32_t thr;
 };
 
-struct Ival { // lcp_inter_t, src/esa.h:25-34
+// Device code addresses the index through global-address-space pointers so
+// the compiler emits global_load (not flat_load) for them.
+#define ANDI_GLOBAL __attribute__((address_space(1)))
+typedef ANDI_GLOBAL const uint8_t *g_u8p;
+typedef ANDI_GLOBAL const int32_t *g_i32p;
+typedef ANDI_GLOBAL const int4 *g_i4p;
+
+struct EsaG {
+	g_u8p S;
+	g_i32p SA, LCP, CLD;
+	g_u8p FVC;
+	g_i4p tab;
+	int32_t n, thr;
+};
+
+__device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
+	EsaG g;
+	g.S = (g_u8p)e.S, g.SA = (g_i32p)e.SA, g.LCP = (g_i32p)e.LCP, g.CLD = (g_i32p)e.CLD;
+	g.FVC = (g_u8p)e.FVC, g.tab = (g_i4p)e.tab;
+	g.n = e.n, g.thr = e.thr;
+	return g;
+}
+
+struct alignas(16) Ival { // lcp_inter_t, src/esa.h:25-34
 	int32_t l, i, j, m;
 };
 
@@ -34,13 +57,13 @@ __device__ __forceinline__ bool ival_empty(const Ival &v) {
 	return v.i == -1 && v.j == -1;
 }
 
-__device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t *p) {
+__device__ __forceinline__ uint32_t ld_u32_unaligned(g_u8p p) {
 	uint32_t v;
 	__builtin_memcpy(&v, p, 4);
 	return v;
 }
 
-__device__ __forceinline__ uint64_t ld_u64_unaligned(const uint8_t *p) {
+__device__ __forceinline__ uint64_t ld_u64_unaligned(g_u8p p) {
 	uint64_t v;
 	__builtin_memcpy(&v, p, 8);
 	return v;
@@ -61,29 +84,45 @@ __device__ __forceinline__ uint8_t code_nt(uint32_t code) {
 	return (uint8_t)((0x54474341u >> (8 * (code & 3u))) & 0xffu); // "ACGT"
 }
 
+__device__ __forceinline__ uint4 ld_u128_unaligned(g_u8p p) {
+	uint4 v;
+	__builtin_memcpy(&v, p, 16);
+	return v;
+}
+
+// Lanes are organised in groups of G consecutive lanes (G = 1, 2, 4 ... 64).
+// All lanes of a group hold the same chain state and execute the same control
+// flow; different groups of one wavefront may diverge.
+template <int G>
+struct Group {
+	static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "group size must be a power of two");
+	static __device__ __forceinline__ uint32_t sub() { return __lane_id() & (G - 1); }
+	static __device__ __forceinline__ uint32_t base() { return __lane_id() & ~(uint32_t)(G - 1); }
+	// the group's slice of a wave-wide ballot
+	static __device__ __forceinline__ uint64_t slice(uint64_t ballot) {
+		if constexpr (G == 64) return ballot;
+		return (ballot >> base()) & ((1ull << G) - 1);
+	}
+};
+
+// byte index of the first non-zero byte of the 16-byte value x, 16 if none
+__device__ __forceinline__ uint32_t first_diff_byte(uint4 x) {
+	if (x.x) return (uint32_t)__builtin_ctz(x.x) >> 3;
+	if (x.y) return 4 + ((uint32_t)__builtin_ctz(x.y) >> 3);
+	if (x.z) return 8 + ((uint32_t)__builtin_ctz(x.z) >> 3);
+	if (x.w) return 12 + ((uint32_t)__builtin_ctz(x.w) >> 3);
+	return 16;
+}
+
 // Length of the common prefix of a[0..maxlen) and b[0..maxlen).
-// WAVE=true: all 64 lanes call with identical arguments and share the work
-// (256 B per step, one coalesced 4-byte load per lane and string); the result
-// is wave-uniform.  WAVE=false: one thread, 8 bytes per step.
+// G == 1: one thread, 8 bytes per step.  G > 1: the G lanes of a group call with
+// identical arguments and share the work, 16 bytes per lane and step (one
+// 16*G-byte window of each string); the result is uniform within the group.
 // Both strings must be readable ANDI_PAD bytes past maxlen.
-template <bool WAVE>
-__device__ __forceinline__ uint32_t common_prefix(const uint8_t *a, const uint8_t *b,
+template <int G>
+__device__ __forceinline__ uint32_t common_prefix(g_u8p a, g_u8p b,
 												  uint32_t maxlen) {
-	if constexpr (WAVE) {
-		const uint32_t lane = __lane_id();
-		for (uint32_t done = 0; done < maxlen; done += 256) {
-			uint32_t off = done + 4 * lane;
-			uint32_t x = ld_u32_unaligned(a + off) ^ ld_u32_unaligned(b + off);
-			uint64_t diff = __ballot(x != 0);
-			if (diff) {
-				int first = __builtin_ctzll(diff);
-				uint32_t xf = __shfl(x, first);
-				uint32_t pos = done + 4 * first + (__builtin_ctz(xf) >> 3);
-				return pos < maxlen ? pos : maxlen;
-			}
-		}
-		return maxlen;
-	} else {
+	if constexpr (G == 1) {
 		uint32_t k = 0;
 		while (k < maxlen) {
 			uint64_t x = ld_u64_unaligned(a + k) ^ ld_u64_unaligned(b + k);
@@ -94,10 +133,26 @@ __device__ __forceinline__ uint32_t common_prefix(const uint8_t *a, const uint8_
 			k += 8;
 		}
 		return maxlen;
+	} else {
+		const uint32_t sub = Group<G>::sub();
+		for (uint32_t done = 0; done < maxlen; done += 16 * G) {
+			uint32_t off = done + 16 * sub;
+			uint4 wa = ld_u128_unaligned(a + off), wb = ld_u128_unaligned(b + off);
+			uint4 x = make_uint4(wa.x ^ wb.x, wa.y ^ wb.y, wa.z ^ wb.z, wa.w ^ wb.w);
+			uint32_t f = first_diff_byte(x);
+			uint64_t diff = Group<G>::slice(__ballot(f < 16));
+			if (diff) {
+				uint32_t first = (uint32_t)__builtin_ctzll(diff);
+				uint32_t ff = (uint32_t)__shfl((int)f, (int)(Group<G>::base() + first));
+				uint32_t pos = done + 16 * first + ff;
+				return pos < maxlen ? pos : maxlen;
+			}
+		}
+		return maxlen;
 	}
 }
 
-__device__ __forceinline__ Ival esa_root(const EsaDev &E) {
+__device__ __forceinline__ Ival esa_root(const EsaG &E) {
 	Ival r;
 	r.i = 0;
 	r.j = E.n - 1;
@@ -107,7 +162,7 @@ __device__ __forceinline__ Ival esa_root(const EsaDev &E) {
 }
 
 // get_interval, src/esa.c:441-511: the child of `ij` whose next character is a.
-__device__ __forceinline__ Ival esa_child(const EsaDev &E, Ival ij, uint8_t a) {
+__device__ __forceinline__ Ival esa_child(const EsaG &E, Ival ij, uint8_t a) {
 	int32_t i = ij.i;
 	const int32_t j = ij.j;
 	if (i == j) {
@@ -147,8 +202,8 @@ __device__ __forceinline__ Ival esa_child(const EsaDev &E, Ival ij, uint8_t a) {
 }
 
 // get_match_from, src/esa.c:531-601
-template <bool WAVE>
-__device__ __forceinline__ Ival esa_match_from(const EsaDev &E, const uint8_t *q, uint32_t qlen,
+template <int G>
+__device__ __forceinline__ Ival esa_match_from(const EsaG &E, g_u8p q, uint32_t qlen,
 											   int32_t k, Ival ij) {
 	if (ival_empty(ij)) return ij;
 	if (ij.i == ij.j) {
@@ -156,7 +211,7 @@ __device__ __forceinline__ Ival esa_match_from(const EsaDev &E, const uint8_t *q
 		// equal a query byte, so the `S[p+k]` stop of the reference is implied.
 		uint32_t from = (uint32_t)ij.l;
 		if (from < qlen)
-			from += common_prefix<WAVE>(q + from, E.S + E.SA[ij.i] + from, qlen - from);
+			from += common_prefix<G>(q + from, E.S + E.SA[ij.i] + from, qlen - from);
 		ij.l = (int32_t)from;
 		return ij;
 	}
@@ -173,7 +228,7 @@ __device__ __forceinline__ Ival esa_match_from(const EsaDev &E, const uint8_t *q
 		if (ij.i < ij.j && ij.l < lim) lim = ij.l;
 		++k;
 		if (k < lim) {
-			k += (int32_t)common_prefix<WAVE>(q + k, E.S + E.SA[ij.i] + k, (uint32_t)(lim - k));
+			k += (int32_t)common_prefix<G>(q + k, E.S + E.SA[ij.i] + k, (uint32_t)(lim - k));
 			if (k < lim) {
 				res.l = k;
 				return res;
@@ -185,14 +240,14 @@ __device__ __forceinline__ Ival esa_match_from(const EsaDev &E, const uint8_t *q
 }
 
 // get_match, src/esa.c:615-624
-template <bool WAVE>
-__device__ __forceinline__ Ival esa_match(const EsaDev &E, const uint8_t *q, uint32_t qlen) {
-	return esa_match_from<WAVE>(E, q, qlen, 0, esa_root(E));
+template <int G>
+__device__ __forceinline__ Ival esa_match(const EsaG &E, g_u8p q, uint32_t qlen) {
+	return esa_match_from<G>(E, q, qlen, 0, esa_root(E));
 }
 
 // 2-bit code of the first 10 characters, first character most significant
 // (src/esa.c:639-643); returns false if any of them is not ACGT.
-__device__ __forceinline__ bool kmer10_code(const uint8_t *q, uint32_t &code) {
+__device__ __forceinline__ bool kmer10_code(g_u8p q, uint32_t &code) {
 	uint32_t w0 = ld_u32_unaligned(q), w1 = ld_u32_unaligned(q + 4), w2 = ld_u32_unaligned(q + 8);
 	w2 &= 0x0000ffffu;
 	// every ACGT byte has bit 6 set, no separator has
@@ -210,14 +265,13 @@ __device__ __forceinline__ bool kmer10_code(const uint8_t *q, uint32_t &code) {
 }
 
 // get_match_cached, src/esa.c:636-656
-template <bool WAVE>
-__device__ __forceinline__ Ival esa_match_cached(const EsaDev &E, const uint8_t *q, uint32_t qlen) {
-	if (qlen <= ANDI_CACHE_K) return esa_match<WAVE>(E, q, qlen);
+template <int G>
+__device__ __forceinline__ Ival esa_match_cached(const EsaG &E, g_u8p q, uint32_t qlen) {
+	if (qlen <= ANDI_CACHE_K) return esa_match<G>(E, q, qlen);
 	uint32_t code;
-	if (!kmer10_code(q, code)) return esa_match<WAVE>(E, q, qlen);
-	int4 t = E.tab[code];
-	Ival ij;
-	ij.l = t.x, ij.i = t.y, ij.j = t.z, ij.m = t.w;
-	if (ival_empty(ij)) return esa_match<WAVE>(E, q, qlen);
-	return esa_match_from<WAVE>(E, q, qlen, ij.l, ij);
+	if (!kmer10_code(q, code)) return esa_match<G>(E, q, qlen);
+	Ival ij; // table entries are {l,i,j,m}, 16-byte aligned
+	__builtin_memcpy(&ij, (g_u8p)(E.tab + code), sizeof ij);
+	if (ival_empty(ij)) return esa_match<G>(E, q, qlen);
+	return esa_match_from<G>(E, q, qlen, ij.l, ij);
 }

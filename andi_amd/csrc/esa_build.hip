@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_plcp_chunks(const uint8_t *__restrict__
 			continue;
 		}
 		// two distinct suffixes differ at or before the NUL at S[n]
-		const uint8_t *a = S + prev + h, *b = S + t + h;
+		g_u8p a = (g_u8p)S + prev + h, b = (g_u8p)S + t + h;
 		for (;;) {
 			uint64_t x = ld_u64_unaligned(a) ^ ld_u64_unaligned(b);
 			if (x) {
@@ -188,9 +188,10 @@ __global__ __launch_bounds__(256) void k_child_table(MinTree t, int32_t *__restr
 // singleton -> depth fixed to pos+1; interval deeper than one character but
 // shallower than 10 -> parent for every 10-mer except the single existing
 // elongation, which is followed (and cut at a separator).
-__global__ __launch_bounds__(256) void k_kmer_table(EsaDev E, int4 *__restrict__ tab) {
+__global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict__ tab) {
 	uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
 	if (code >= (1u << (2 * ANDI_CACHE_K))) return;
+	const EsaG E = esa_global(Ed);
 	auto sym = [&](int pos) { return code_nt(code >> (2 * (ANDI_CACHE_K - 1 - pos))); };
 
 	Ival in = esa_root(E);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev E, int4 *__restrict__
 			break;
 		}
 		// one elongation of length ij.l exists below this prefix
-		const uint8_t *suf = E.S + E.SA[ij.i];
+		g_u8p suf = E.S + E.SA[ij.i];
 		int k = pos + 1;
 		bool decided = false;
 		for (; k < ij.l; ++k) {

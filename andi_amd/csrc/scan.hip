@@ -23,13 +23,18 @@
 //                          rare segments whose assumption failed, and applies
 //                          the loop epilogue (src/process.c:199-211).
 //
-// A chain step is wave-uniform control flow; the 64 lanes share the byte
-// comparisons (common_prefix<true>) and the substitution counting (LDS
-// histogram).  The result is bit-identical to the sequential loop.
+// A chain is run by a group of G consecutive lanes (G = 8 by default, so one
+// wavefront advances 8 segments at once): the chain's control flow is uniform
+// within the group, the G lanes share the byte comparisons (common_prefix<G>,
+// one 16*G-byte window per step) and the substitution counting (LDS histogram
+// per group).  Every step of a chain is a handful of dependent, mostly random
+// memory accesses, so throughput is set by the number of chains in flight; the
+// result is bit-identical to the sequential loop.
 #include "scan.h"
 
 #define WAVES_PER_BLOCK 4
 #define BLOCK (64 * WAVES_PER_BLOCK)
+#define SCAN_G 8 /* lanes per chain in passes A and B */
 
 #define CHECK_LAUNCH()                                                                             \
 	do {                                                                                           \
@@ -38,8 +43,8 @@
 	} while (0)
 
 struct PairCtx {
-	EsaDev E;
-	const uint8_t *Q;
+	EsaG E;
+	g_u8p Q;
 	uint32_t qlen;
 	uint32_t thr;
 	uint32_t border; // n / 2, src/process.c:149
@@ -69,22 +74,26 @@ __device__ __forceinline__ ChainState cold_state(uint32_t start, uint32_t n) {
 }
 
 // model_count_equal for RAW/JC/Kimura, src/model.c:247-253
+template <int G>
 __device__ __forceinline__ void count_equal(uint32_t *hist, uint32_t len) {
-	uint32_t lane = __lane_id();
+	static_assert(G >= 4, "needs four lanes");
+	uint32_t lane = Group<G>::sub();
 	if (lane < 4) atomicAdd(&hist[5 * lane], len / 4 + (lane == 3 ? (len & 3u) : 0u));
 }
 
 // model_count, src/model.c:309-337
-__device__ __forceinline__ void count_gap(uint32_t *hist, const uint8_t *s, const uint8_t *q,
+template <int G>
+__device__ __forceinline__ void count_gap(uint32_t *hist, g_u8p s, g_u8p q,
 										  uint32_t len) {
-	for (uint32_t off = __lane_id(); off < len; off += 64) {
+	for (uint32_t off = Group<G>::sub(); off < len; off += G) {
 		int8_t a = (int8_t)s[off], b = (int8_t)q[off];
 		if (a >= 'A' && b >= 'A')
 			atomicAdd(&hist[(nt_code((uint8_t)a) << 2) + nt_code((uint8_t)b)], 1u);
 	}
 }
 
-// One trip of the while loop, src/process.c:153-197.  Wave-uniform.
+// One trip of the while loop, src/process.c:153-197.  Uniform within the group.
+template <int G>
 __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st, uint32_t *hist) {
 	const uint32_t n = (uint32_t)c.E.n;
 	uint32_t curS = 0, curLen = 0;
@@ -96,12 +105,12 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 	uint32_t tryS = st.lastS + advance;
 	if (tryS < n && gap <= c.thr) {
 		curS = tryS;
-		curLen = common_prefix<true>(c.Q + st.p, c.E.S + tryS, c.qlen - st.p);
+		curLen = common_prefix<G>(c.Q + st.p, c.E.S + tryS, c.qlen - st.p);
 		found = curLen >= c.thr;
 	}
 	// anchor, src/process.c:113-123
 	if (!found) {
-		Ival in = esa_match_cached<true>(c.E, c.Q + st.p, c.qlen - st.p);
+		Ival in = esa_match_cached<G>(c.E, c.Q + st.p, c.qlen - st.p);
 		curS = (uint32_t)c.E.SA[in.i];
 		curLen = in.l <= 0 ? 0u : (uint32_t)in.l;
 		found = in.i == in.j && curLen >= c.thr;
@@ -112,11 +121,11 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 		uint32_t endQ = st.lastQ + st.lastLen;
 		if (curS > endS && st.p - endQ == curS - endS &&
 			(curS < c.border) == (st.lastS < c.border)) {
-			count_equal(hist, st.lastLen);
-			count_gap(hist, c.E.S + endS, c.Q + endQ, st.p - endQ);
+			count_equal<G>(hist, st.lastLen);
+			count_gap<G>(hist, c.E.S + endS, c.Q + endQ, st.p - endQ);
 			st.lwra = 1;
 		} else {
-			if (st.lwra || st.lastLen >= 2 * c.thr) count_equal(hist, st.lastLen);
+			if (st.lwra || st.lastLen >= 2 * c.thr) count_equal<G>(hist, st.lastLen);
 			st.lwra = 0;
 		}
 		st.lastS = curS;
@@ -127,8 +136,9 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 	return st;
 }
 
+template <int G>
 __device__ __forceinline__ void hist_zero(uint32_t *hist) {
-	if (__lane_id() < 16) hist[__lane_id()] = 0;
+	for (uint32_t t = Group<G>::sub(); t < 16; t += G) hist[t] = 0;
 }
 
 struct WorkItem {
@@ -138,18 +148,20 @@ struct WorkItem {
 
 __device__ __forceinline__ PairCtx make_ctx(const ScanArgs &a, uint32_t sub, uint32_t qidx) {
 	PairCtx c;
-	c.E = a.subjects[sub];
-	c.Q = a.qpool + a.qoff[qidx];
+	c.E = esa_global(a.subjects[sub]);
+	c.Q = (g_u8p)(a.qpool + a.qoff[qidx]);
 	c.qlen = a.qlen[qidx];
 	c.thr = (uint32_t)c.E.thr;
 	c.border = (uint32_t)c.E.n / 2;
 	return c;
 }
 
+// work item of this lane's group: segment w of subject blockIdx.y
+template <int G>
 __device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {
 	WorkItem it;
 	it.sub = blockIdx.y;
-	it.w = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+	it.w = (blockIdx.x * BLOCK + threadIdx.x) / G;
 	it.valid = it.w < a.total_segs;
 	it.qidx = it.seg_in_q = it.start = it.end = 0;
 	it.is_self = false;
@@ -166,32 +178,34 @@ __device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {
 }
 
 // ------------------------------------------------------------------ pass A
+template <int G>
 __global__ __launch_bounds__(BLOCK) void k_scan_cold(ScanArgs a) {
-	__shared__ uint32_t s_hist[WAVES_PER_BLOCK][16];
-	WorkItem it = decode_item(a);
+	__shared__ uint32_t s_hist[BLOCK / G][16];
+	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
-	uint32_t *hist = s_hist[threadIdx.x >> 6];
-	hist_zero(hist);
+	uint32_t *hist = s_hist[threadIdx.x / G];
+	hist_zero<G>(hist);
 
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
 	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, (uint32_t)c.E.n);
-	while (st.p < it.end) st = chain_step(c, st, hist);
+	while (st.p < it.end) st = chain_step<G>(c, st, hist);
 
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
-	uint32_t lane = __lane_id();
+	uint32_t lane = Group<G>::sub();
 	if (lane == 0) a.cold_exit[slot] = st;
-	if (lane < 16) a.cold_counts[slot * 16 + lane] = hist[lane];
+	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = hist[t];
 }
 
 // Replays the true chain (entering in state T) through [start, end) next to the
 // segment's cold chain.  On return T is the true chain's state on leaving the
 // segment and histT[0..16) the counts it added inside the segment.
+template <int G>
 __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, uint32_t start,
 											   uint32_t end, const ChainState &coldExit,
 											   const uint32_t *coldCounts, uint32_t *histT,
 											   uint32_t *histC) {
-	hist_zero(histT);
-	hist_zero(histC);
+	hist_zero<G>(histT);
+	hist_zero<G>(histC);
 	ChainState C = cold_state(start, (uint32_t)c.E.n);
 	bool synced = false;
 	for (;;) {
@@ -201,39 +215,39 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 		}
 		if (T.p >= end) break;
 		if (C.p >= end || T.p <= C.p) {
-			T = chain_step(c, T, histT);
+			T = chain_step<G>(c, T, histT);
 		} else {
-			C = chain_step(c, C, histC);
+			C = chain_step<G>(c, C, histC);
 		}
 	}
 	if (synced) {
 		// from the meeting point on, the cold chain's trajectory is the true one
-		uint32_t lane = __lane_id();
-		if (lane < 16) histT[lane] += coldCounts[lane] - histC[lane];
+		for (uint32_t t = Group<G>::sub(); t < 16; t += G) histT[t] += coldCounts[t] - histC[t];
 		T = coldExit;
 	}
 }
 
 // ------------------------------------------------------------------ pass B
+template <int G>
 __global__ __launch_bounds__(BLOCK) void k_scan_stitch(ScanArgs a) {
-	__shared__ uint32_t s_hist[WAVES_PER_BLOCK][2][16];
-	WorkItem it = decode_item(a);
+	__shared__ uint32_t s_hist[BLOCK / G][2][16];
+	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
-	uint32_t lane = __lane_id();
+	uint32_t lane = Group<G>::sub();
 
 	if (it.seg_in_q == 0) { // the first segment's "cold" chain is the true chain
 		if (lane == 0) a.true_exit[slot] = a.cold_exit[slot];
-		if (lane < 16) a.owned[slot * 16 + lane] = a.cold_counts[slot * 16 + lane];
+		for (uint32_t t = lane; t < 16; t += G) a.owned[slot * 16 + t] = a.cold_counts[slot * 16 + t];
 		return;
 	}
-	uint32_t *histT = s_hist[threadIdx.x >> 6][0], *histC = s_hist[threadIdx.x >> 6][1];
+	uint32_t *histT = s_hist[threadIdx.x / G][0], *histC = s_hist[threadIdx.x / G][1];
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
 	ChainState T = a.cold_exit[slot - 1]; // assumed entry; verified in pass C
-	stitch_segment(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
-				   histC);
+	stitch_segment<G>(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
+					  histC);
 	if (lane == 0) a.true_exit[slot] = T;
-	if (lane < 16) a.owned[slot * 16 + lane] = histT[lane];
+	for (uint32_t t = lane; t < 16; t += G) a.owned[slot * 16 + t] = histT[t];
 }
 
 // ------------------------------------------------------------------ pass C
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 
 	uint32_t *total = s_hist[threadIdx.x >> 6][0];
 	uint32_t *histT = s_hist[threadIdx.x >> 6][1], *histC = s_hist[threadIdx.x >> 6][2];
-	hist_zero(total);
+	hist_zero<64>(total);
 
 	const uint32_t base = a.qseg_start[qidx];
 	const uint32_t nseg = a.qseg_start[qidx + 1] - base;
@@ -285,8 +299,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 				uint32_t start = k * a.seg;
 				uint32_t e = start + a.seg;
 				uint32_t end = e < c.qlen ? e : c.qlen;
-				stitch_segment(c, st, start, end, a.cold_exit[row + k],
-							   a.cold_counts + (row + k) * 16, histT, histC);
+				stitch_segment<64>(c, st, start, end, a.cold_exit[row + k],
+								   a.cold_counts + (row + k) * 16, histT, histC);
 				if (lane < 16) total[lane] += histT[lane];
 			}
 		}
@@ -295,9 +309,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 
 	// src/process.c:199-211
 	if (fin.lastLen >= c.qlen) {
-		count_equal(total, c.qlen);
+		count_equal<64>(total, c.qlen);
 	} else if (fin.lwra || fin.lastLen >= 2 * c.thr) {
-		count_equal(total, fin.lastLen);
+		count_equal<64>(total, fin.lastLen);
 	}
 	if (lane < 16) out->counts[lane] = total[lane];
 	if (lane == 0) out->seq_len = c.qlen;
@@ -306,14 +320,16 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 // ------------------------------------------------------------------ K5 hook
 // get_match / get_match_cached for consecutive suffixes of one query, one
 // thread per suffix (test hook and building block; src/esa.c:615-656).
-__global__ __launch_bounds__(256) void k_match_positions(EsaDev E, const uint8_t *q, uint32_t qlen,
+__global__ __launch_bounds__(256) void k_match_positions(EsaDev Ed, const uint8_t *qd, uint32_t qlen,
 														 uint32_t first, uint32_t count, int cached,
 														 andi_hip_interval *out) {
 	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= count) return;
+	const EsaG E = esa_global(Ed);
+	g_u8p q = (g_u8p)qd;
 	uint32_t pos = first + k;
-	Ival r = cached ? esa_match_cached<false>(E, q + pos, qlen - pos)
-					: esa_match<false>(E, q + pos, qlen - pos);
+	Ival r = cached ? esa_match_cached<1>(E, q + pos, qlen - pos)
+					: esa_match<1>(E, q + pos, qlen - pos);
 	andi_hip_interval o;
 	o.l = r.l, o.i = r.i, o.j = r.j;
 	o.m = r.i >= 0 ? E.SA[r.i] : -1;
@@ -322,15 +338,17 @@ __global__ __launch_bounds__(256) void k_match_positions(EsaDev E, const uint8_t
 
 // ------------------------------------------------------------------ launchers
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
-	dim3 grid((a.total_segs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.nsub);
-	k_scan_cold<<<grid, BLOCK, 0, st>>>(a);
+	const uint32_t per_block = BLOCK / SCAN_G;
+	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
+	k_scan_cold<SCAN_G><<<grid, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
 
 hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
-	dim3 grid((a.total_segs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.nsub);
-	k_scan_stitch<<<grid, BLOCK, 0, st>>>(a);
+	const uint32_t per_block = BLOCK / SCAN_G;
+	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
+	k_scan_stitch<SCAN_G><<<grid, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
