@@ -49,7 +49,7 @@ __device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
 	return g;
 }
 
-struct alignas(16) Ival { // lcp_inter_t, src/esa.h:25-34
+struct Ival { // lcp_inter_t, src/esa.h:25-34
 	int32_t l, i, j, m;
 };
 
@@ -270,8 +270,9 @@ __device__ __forceinline__ Ival esa_match_cached(const EsaG &E, g_u8p q, uint32_
 	if (qlen <= ANDI_CACHE_K) return esa_match<G>(E, q, qlen);
 	uint32_t code;
 	if (!kmer10_code(q, code)) return esa_match<G>(E, q, qlen);
-	Ival ij; // table entries are {l,i,j,m}, 16-byte aligned
-	__builtin_memcpy(&ij, (g_u8p)(E.tab + code), sizeof ij);
+	uint4 t = ld_u128_unaligned((g_u8p)(E.tab + code)); // {l,i,j,m}
+	Ival ij;
+	ij.l = (int32_t)t.x, ij.i = (int32_t)t.y, ij.j = (int32_t)t.z, ij.m = (int32_t)t.w;
 	if (ival_empty(ij)) return esa_match<G>(E, q, qlen);
 	return esa_match_from<G>(E, q, qlen, ij.l, ij);
 }

@@ -32,6 +32,8 @@
 // result is bit-identical to the sequential loop.
 #include "scan.h"
 
+#include <cstdlib>
+
 #define WAVES_PER_BLOCK 4
 #define BLOCK (64 * WAVES_PER_BLOCK)
 #define SCAN_G 8 /* lanes per chain in passes A and B */
@@ -337,20 +339,52 @@ __global__ __launch_bounds__(256) void k_match_positions(EsaDev Ed, const uint8_
 }
 
 // ------------------------------------------------------------------ launchers
-hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
-	const uint32_t per_block = BLOCK / SCAN_G;
+// lanes per chain; ANDI_SCAN_G overrides the default for experiments
+static int scan_group() {
+	static int g = [] {
+		const char *e = getenv("ANDI_SCAN_G");
+		int v = e ? atoi(e) : SCAN_G;
+		return (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : SCAN_G;
+	}();
+	return g;
+}
+
+template <int G>
+static hipError_t launch_cold(const ScanArgs &a, hipStream_t st) {
+	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	k_scan_cold<SCAN_G><<<grid, BLOCK, 0, st>>>(a);
+	k_scan_cold<G><<<grid, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
 
-hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
-	const uint32_t per_block = BLOCK / SCAN_G;
+template <int G>
+static hipError_t launch_stitch(const ScanArgs &a, hipStream_t st) {
+	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	k_scan_stitch<SCAN_G><<<grid, BLOCK, 0, st>>>(a);
+	k_scan_stitch<G><<<grid, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	return hipSuccess;
+}
+
+hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
+	switch (scan_group()) {
+		case 4: return launch_cold<4>(a, st);
+		case 16: return launch_cold<16>(a, st);
+		case 32: return launch_cold<32>(a, st);
+		case 64: return launch_cold<64>(a, st);
+		default: return launch_cold<8>(a, st);
+	}
+}
+
+hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
+	switch (scan_group()) {
+		case 4: return launch_stitch<4>(a, st);
+		case 16: return launch_stitch<16>(a, st);
+		case 32: return launch_stitch<32>(a, st);
+		case 64: return launch_stitch<64>(a, st);
+		default: return launch_stitch<8>(a, st);
+	}
 }
 
 hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st) {
