@@ -8,6 +8,13 @@
 //   CLD  int32[n+1]      child table                (K2, src/esa.c:312-363)
 //   FVC  uint8[n]        S[SA[i]+LCP[i]]            (K3, src/esa.c:229-245)
 //   tab  int4[4^10]      10-mer interval table {l,i,j,m} (K4, src/esa.c:73-215)
+//   deep uint2[4^K]      probe table (K4b): for every ACGT K-mer (K = 11..13) the
+//                        outcome of the longest-match search as far as the K-mer
+//                        alone decides it, so most probes cost one random access
+//   side int4[..]        intervals of K-mers that occur more than once
+//   flags int32[4]       [0] != 0: the 10-mer table has an entry spanning a
+//                        separator -> deep table unused
+//                        [1] number of side entries handed out
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,9 +29,20 @@ struct EsaDev {
 	const int32_t *CLD;
 	const uint8_t *FVC;
 	const int4 *tab; // x=l y=i z=j w=m
+	const uint2 *deep; // may be null
+	const int4 *side;
+	const int32_t *flags;
 	int32_t n;
 	int32_t thr;
+	int32_t deepK;    // 0 = no probe table
+	int32_t side_cap;
 };
+
+// probe-table entry: x = payload, y = kind | unique << 2 | l << 8
+#define DEEP_FINAL 0u    /* K-mer absent: match length l < K, x = SA[i] of the matched prefix */
+#define DEEP_SINGLE 1u   /* K-mer occurs once: x = its position in RS */
+#define DEEP_MULTI 2u    /* K-mer occurs more than once: x = index into side[] */
+#define DEEP_FALLBACK 3u /* use the reference walk (side table full) */
 
 // Device code addresses the index through global-address-space pointers so
 // the compiler emits global_load (not flat_load) for them.
@@ -32,20 +50,27 @@ struct EsaDev {
 typedef ANDI_GLOBAL const uint8_t *g_u8p;
 typedef ANDI_GLOBAL const int32_t *g_i32p;
 typedef ANDI_GLOBAL const int4 *g_i4p;
+typedef ANDI_GLOBAL const uint2 *g_u2p;
 
 struct EsaG {
 	g_u8p S;
 	g_i32p SA, LCP, CLD;
 	g_u8p FVC;
 	g_i4p tab;
-	int32_t n, thr;
+	g_u2p deep;
+	g_i4p side;
+	int32_t n, thr, deepK;
 };
 
 __device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
 	EsaG g;
 	g.S = (g_u8p)e.S, g.SA = (g_i32p)e.SA, g.LCP = (g_i32p)e.LCP, g.CLD = (g_i32p)e.CLD;
 	g.FVC = (g_u8p)e.FVC, g.tab = (g_i4p)e.tab;
+	g.deep = (g_u2p)e.deep, g.side = (g_i4p)e.side;
 	g.n = e.n, g.thr = e.thr;
+	// the probe table is only valid when the 10-mer table has no entry spanning
+	// a separator: then get_match_cached == the true longest match everywhere
+	g.deepK = (e.deep && e.deepK > 0 && ((ANDI_GLOBAL const int32_t *)e.flags)[0] == 0) ? e.deepK : 0;
 	return g;
 }
 
@@ -275,4 +300,78 @@ __device__ __forceinline__ Ival esa_match_cached(const EsaG &E, g_u8p q, uint32_
 	ij.l = (int32_t)t.x, ij.i = (int32_t)t.y, ij.j = (int32_t)t.z, ij.m = (int32_t)t.w;
 	if (ival_empty(ij)) return esa_match<G>(E, q, qlen);
 	return esa_match_from<G>(E, q, qlen, ij.l, ij);
+}
+
+// 2-bit code of the first K (<= 16) characters of q, first character most
+// significant; false if one of them is not ACGT.  Reads 16 bytes.
+__device__ __forceinline__ bool kmer_code(g_u8p q, int K, uint32_t &code) {
+	uint4 w = ld_u128_unaligned(q);
+	auto pack4 = [](uint32_t v) {
+		uint32_t x = v & 0x06060606u;
+		x ^= x >> 1;
+		x = (x >> 1) & 0x03030303u;
+		return ((x & 0xffu) << 6) | (((x >> 8) & 0xffu) << 4) | (((x >> 16) & 0xffu) << 2) | (x >> 24);
+	};
+	auto need = [K](int d) { // bit-6 mask of the characters of dword d that belong to the K-mer
+		int c = K - 4 * d;
+		c = c < 0 ? 0 : (c > 4 ? 4 : c);
+		return c == 4 ? 0x40404040u : (0x40404040u & ((1u << (8 * c)) - 1u));
+	};
+	bool ok = ((w.x & need(0)) == need(0)) && ((w.y & need(1)) == need(1)) &&
+			  ((w.z & need(2)) == need(2)) && ((w.w & need(3)) == need(3));
+	uint32_t c32 = (pack4(w.x) << 24) | (pack4(w.y) << 16) | (pack4(w.z) << 8) | pack4(w.w);
+	code = c32 >> (32 - 2 * K);
+	return ok;
+}
+
+// What dist_anchor needs from get_match_cached (src/process.c:113-123): the
+// match length, whether the match is unique (inter.i == inter.j) and SA[inter.i].
+struct Probe {
+	uint32_t len;
+	uint32_t pos;
+	bool unique;
+};
+
+template <int G>
+__device__ __forceinline__ Probe esa_probe(const EsaG &E, g_u8p q, uint32_t qlen) {
+	Probe r;
+	const int K = E.deepK;
+	uint32_t code;
+	if (K > 0 && qlen > (uint32_t)K && kmer_code(q, K, code)) {
+		uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + code));
+		uint2 e = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
+		uint32_t kind = e.y & 3u;
+		if (kind == DEEP_FINAL) {
+			r.len = e.y >> 8, r.unique = (e.y >> 2) & 1u, r.pos = e.x;
+			return r;
+		}
+		if (kind == DEEP_SINGLE) {
+			r.pos = e.x, r.unique = true;
+			r.len = (uint32_t)K + common_prefix<G>(q + K, E.S + e.x + K, qlen - (uint32_t)K);
+			return r;
+		}
+		if (kind == DEEP_MULTI) {
+			uint4 t = ld_u128_unaligned((g_u8p)(E.side + e.x)); // {l,i,j,m}, l >= K
+			Ival ij;
+			ij.l = (int32_t)t.x, ij.i = (int32_t)t.y, ij.j = (int32_t)t.z, ij.m = (int32_t)t.w;
+			// all suffixes of the interval agree up to ij.l; only K characters are verified
+			uint32_t k = (uint32_t)K;
+			uint32_t lim = (uint32_t)ij.l < qlen ? (uint32_t)ij.l : qlen;
+			if (k < lim) k += common_prefix<G>(q + k, E.S + E.SA[ij.i] + k, lim - k);
+			if (k < lim || k >= qlen) {
+				r.len = k, r.unique = false, r.pos = 0;
+				return r;
+			}
+			Ival m = esa_match_from<G>(E, q, qlen, ij.l, ij);
+			r.len = m.l <= 0 ? 0u : (uint32_t)m.l;
+			r.unique = m.i == m.j;
+			r.pos = (uint32_t)E.SA[m.i];
+			return r;
+		}
+	}
+	Ival m = esa_match_cached<G>(E, q, qlen);
+	r.len = m.l <= 0 ? 0u : (uint32_t)m.l;
+	r.unique = m.i == m.j;
+	r.pos = (uint32_t)E.SA[m.i];
+	return r;
 }

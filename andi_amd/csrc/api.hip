@@ -54,6 +54,10 @@ struct andi_hip_esa {
 	int32_t *SA = nullptr, *LCP = nullptr, *CLD = nullptr;
 	uint8_t *FVC = nullptr;
 	int4 *tab = nullptr;
+	uint2 *deep = nullptr;
+	int4 *side = nullptr;
+	int32_t *flags = nullptr;
+	int32_t deepK = 0, side_cap = 0;
 	int32_t *min_scratch = nullptr;
 	int32_t n = 0;
 	int32_t thr = 0;
@@ -150,7 +154,8 @@ struct Timed {
 EsaDev esa_view(const andi_hip_esa *e) {
 	EsaDev v;
 	v.S = e->S, v.SA = e->SA, v.LCP = e->LCP, v.CLD = e->CLD, v.FVC = e->FVC, v.tab = e->tab;
-	v.n = e->n, v.thr = e->thr;
+	v.deep = e->deep, v.side = e->side, v.flags = e->flags;
+	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.side_cap = e->side_cap;
 	return v;
 }
 
@@ -275,7 +280,23 @@ int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, siz
 	chk(dmalloc(&e->FVC, n + ANDI_PAD));
 	chk(dmalloc(&e->tab, tab_entries));
 	chk(dmalloc(&e->min_scratch, mins));
-	e->bytes = (n + 1 + ANDI_PAD) + 4 * n + 8 * (n + 1) + n + ANDI_PAD + 16 * tab_entries + 4 * mins;
+	chk(dmalloc(&e->flags, 4));
+	// probe table depth: 4^K a few times the text length (override: ANDI_DEEP_K, 0 = off)
+	int K = 11;
+	while (K < 13 && ((size_t)1 << (2 * K)) < n) ++K;
+	if (const char *ev = getenv("ANDI_DEEP_K")) K = atoi(ev);
+	if (K != 0 && (K < 11 || K > 13)) K = 12;
+	if (n < 4096) K = 0; // tiny subjects: the reference walk is just as fast
+	e->deepK = K;
+	size_t deep_bytes = 0;
+	if (K) {
+		e->side_cap = (int32_t)std::min<size_t>(n / 2 + 16, (size_t)1 << (2 * K));
+		chk(dmalloc(&e->deep, (size_t)1 << (2 * K)));
+		chk(dmalloc(&e->side, (size_t)e->side_cap));
+		deep_bytes = ((size_t)8 << (2 * K)) + 16 * (size_t)e->side_cap;
+	}
+	e->bytes = (n + 1 + ANDI_PAD) + 4 * n + 8 * (n + 1) + n + ANDI_PAD + 16 * tab_entries + 4 * mins +
+			   deep_bytes;
 	if (err == hipSuccess) err = hipMemsetAsync(e->S + n, 0, 1 + ANDI_PAD, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(e->S, RS, n, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess)
@@ -296,6 +317,7 @@ int andi_hip_esa_build(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	EsaBuildArgs a;
 	a.S = e->S, a.SA = e->SA, a.LCP = e->LCP, a.CLD = e->CLD, a.FVC = e->FVC, a.tab = e->tab;
 	a.min_scratch = e->min_scratch;
+	a.deep = e->deep, a.side = e->side, a.flags = e->flags, a.deepK = e->deepK, a.side_cap = e->side_cap;
 	a.n = e->n;
 	Timed t(ctx, 0);
 	hipError_t err = andi_launch_esa_build(a, ctx->stream);
@@ -330,6 +352,9 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	(void)hipFree(e->CLD);
 	(void)hipFree(e->FVC);
 	(void)hipFree(e->tab);
+	(void)hipFree(e->deep);
+	(void)hipFree(e->side);
+	(void)hipFree(e->flags);
 	(void)hipFree(e->min_scratch);
 	delete e;
 }

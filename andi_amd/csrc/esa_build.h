@@ -19,6 +19,11 @@ struct EsaBuildArgs {
 	int32_t *CLD;       // n + 1   (out; doubles as PLCP scratch)
 	uint8_t *FVC;       // n       (out)
 	int4 *tab;          // 4^10    (out)
+	uint2 *deep;        // 4^deepK (out, may be null)
+	int4 *side;         // side_cap (out)
+	int32_t *flags;     // 4 ints  (out)
+	int32_t deepK;
+	int32_t side_cap;
 	int32_t *min_scratch; // andi_min_tree_entries(n) ints
 	int32_t n;
 };

@@ -13,6 +13,7 @@
 //   K2a min_tree      64-ary min pyramid over LCP
 //   K2b child_table   CLD from nearest-smaller-value searches  (src/esa.c:312-363)
 //   K4  kmer_table    4^10 interval table, one thread per 10-mer (src/esa.c:73-215)
+//   K4b probe_table   4^K outcome table for K = 11..13, one thread per K-mer
 #include "andi_dev.h"
 #include "esa_build.h"
 
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(256) void k_child_table(MinTree t, int32_t *__restr
 // singleton -> depth fixed to pos+1; interval deeper than one character but
 // shallower than 10 -> parent for every 10-mer except the single existing
 // elongation, which is followed (and cut at a separator).
-__global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict__ tab) {
+__global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict__ tab,
+													int32_t *__restrict__ flags) {
 	uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
 	if (code >= (1u << (2 * ANDI_CACHE_K))) return;
 	const EsaG E = esa_global(Ed);
@@ -230,6 +232,9 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 			if (!is_acgt(e)) { // separator inside the interval's label
 				out = ij;
 				decided = true;
+				// such an entry makes get_match_cached differ from the true
+				// longest match: remember it
+				atomicOr(&flags[0], 1);
 				break;
 			}
 			if (e != sym(k)) {
@@ -243,6 +248,75 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 		pos = ij.l;
 	}
 	tab[code] = make_int4(out.l, out.i, out.j, out.m);
+}
+
+// ---------------------------------------------------------------- K4b
+// Probe table.  For every ACGT K-mer w: how far does the longest-match search
+// (get_match, src/esa.c:531-624) get on w alone?
+//   w absent      -> FINAL: the match length l < K, uniqueness and SA[i] of the
+//                    matched prefix are the final answer for every query that
+//                    starts with w;
+//   w occurs once -> SINGLE: its position; the query is extended along it;
+//   w occurs more -> MULTI: the lcp-interval of w, the search resumes there.
+// Semantics are those of the true longest match; they coincide with the
+// reference's get_match_cached unless flags[0] is set, in which case the scan
+// ignores this table.  The walk starts from the 10-mer table entry.
+__global__ __launch_bounds__(256) void k_probe_table(EsaDev Ed, uint2 *__restrict__ deep,
+													 int4 *__restrict__ side,
+													 int32_t *__restrict__ flags) {
+	const int K = Ed.deepK;
+	uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
+	if (code >= (1u << (2 * K))) return;
+	if (flags[0]) return; // 10-mer table is not the true longest match here
+	const EsaG E = esa_global(Ed);
+	auto sym = [&](int pos) { return code_nt(code >> (2 * (K - 1 - pos))); };
+	auto emit = [&](uint32_t kind, uint32_t unique, uint32_t l, uint32_t x) {
+		deep[code] = make_uint2(x, kind | (unique << 2) | (l << 8));
+	};
+
+	uint4 t = ld_u128_unaligned((g_u8p)(E.tab + (code >> (2 * (K - ANDI_CACHE_K)))));
+	Ival in;
+	in.l = (int32_t)t.x, in.i = (int32_t)t.y, in.j = (int32_t)t.z, in.m = (int32_t)t.w;
+	int pos = in.l; // characters of w matched so far; == lcp of `in` unless singleton
+	for (;;) {
+		if (in.i == in.j) { // one suffix left: compare the rest of w against it
+			int32_t suf = E.SA[in.i];
+			while (pos < K && E.S[suf + pos] == sym(pos)) ++pos;
+			if (pos == K) {
+				emit(DEEP_SINGLE, 1, (uint32_t)K, (uint32_t)suf);
+			} else {
+				emit(DEEP_FINAL, 1, (uint32_t)pos, (uint32_t)suf);
+			}
+			return;
+		}
+		if (pos >= K) { // w is a proper prefix of (or equal to) the interval's label
+			uint32_t slot = (uint32_t)atomicAdd(&flags[1], 1);
+			if (slot < (uint32_t)Ed.side_cap) {
+				side[slot] = make_int4(in.l, in.i, in.j, in.m);
+				emit(DEEP_MULTI, 0, (uint32_t)K, slot);
+			} else {
+				emit(DEEP_FALLBACK, 0, 0, 0);
+			}
+			return;
+		}
+		// here pos == in.l: branch on the next character
+		Ival ij = esa_child(E, in, sym(pos));
+		if (ival_empty(ij)) {
+			emit(DEEP_FINAL, 0, (uint32_t)pos, (uint32_t)E.SA[in.i]);
+			return;
+		}
+		++pos;
+		if (ij.i < ij.j) { // verify the label up to the child's depth
+			int32_t suf = E.SA[ij.i];
+			int lim = ij.l < K ? ij.l : K;
+			while (pos < lim && E.S[suf + pos] == sym(pos)) ++pos;
+			if (pos < lim) {
+				emit(DEEP_FINAL, 0, (uint32_t)pos, (uint32_t)suf);
+				return;
+			}
+		}
+		in = ij;
+	}
 }
 
 // ---------------------------------------------------------------- host side
@@ -295,8 +369,17 @@ hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st) {
 	// K4: 10-mer interval table
 	EsaDev E;
 	E.S = a.S, E.SA = a.SA, E.LCP = a.LCP, E.CLD = a.CLD, E.FVC = a.FVC, E.tab = a.tab;
-	E.n = n, E.thr = 0;
-	k_kmer_table<<<blocks(1 << (2 * ANDI_CACHE_K)), B, 0, st>>>(E, a.tab);
+	E.deep = a.deep, E.side = a.side, E.flags = a.flags;
+	E.n = n, E.thr = 0, E.deepK = a.deepK, E.side_cap = a.side_cap;
+	e = hipMemsetAsync(a.flags, 0, 4 * sizeof(int32_t), st);
+	if (e != hipSuccess) return e;
+	k_kmer_table<<<blocks(1 << (2 * ANDI_CACHE_K)), B, 0, st>>>(E, a.tab, a.flags);
 	CHECK_LAUNCH();
+
+	// K4b: probe table
+	if (a.deep && a.deepK > 0) {
+		k_probe_table<<<blocks((int64_t)1 << (2 * a.deepK)), B, 0, st>>>(E, a.deep, a.side, a.flags);
+		CHECK_LAUNCH();
+	}
 	return hipSuccess;
 }

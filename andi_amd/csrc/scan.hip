@@ -112,10 +112,10 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 	}
 	// anchor, src/process.c:113-123
 	if (!found) {
-		Ival in = esa_match_cached<G>(c.E, c.Q + st.p, c.qlen - st.p);
-		curS = (uint32_t)c.E.SA[in.i];
-		curLen = in.l <= 0 ? 0u : (uint32_t)in.l;
-		found = in.i == in.j && curLen >= c.thr;
+		Probe pr = esa_probe<G>(c.E, c.Q + st.p, c.qlen - st.p);
+		curS = pr.pos;
+		curLen = pr.len;
+		found = pr.unique && curLen >= c.thr;
 	}
 
 	if (found) {

@@ -74,6 +74,44 @@ def test_join_mode_and_revcomp(ctx, orc):
     _check_set(ctx, orc, [a, b, c, rc], segments=(0, 2048))
 
 
+def _separator_spanning_subject(rng):
+    """3 contigs x 3 kbp whose junctions make a 10-mer table entry span a
+    separator: a 7-mer that occurs only right before
+    two '!T' junctions."""
+    while True:
+        c = [bytearray(rand_dna(rng, 3000)) for _ in range(3)]
+        w = b"GACCGGA"
+        c[0][-7:] = w
+        c[1][-7:] = w
+        c[1][0:2] = b"TA"
+        c[2][0:2] = b"TC"
+        seq = b"!".join(bytes(x) for x in c)
+        rc = seq[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+        if seq.count(w) == 2 and rc.count(w) == 0:
+            return seq
+
+
+def test_separator_spanning_table_entry(ctx, orc):
+    """The reference AS RUN uses the cached lookup (src/process.c:117), which on
+    such a subject is not the true longest match; the device must follow it
+    (the probe table is switched off by the build kernel's flag)."""
+    rng = np.random.default_rng(57)
+    subj = _separator_spanning_subject(rng)
+    O = orc.OracleEsa(subj)
+    q = b"GACCGGAATGCGTCAGATGA"
+    assert O.get_match(q, True) != O.get_match(q, False)  # the quirk is really triggered
+    queries = [rand_dna(rng, 2000) + q + rand_dna(rng, 3000) + b"GACCGGATTTT" + rand_dna(rng, 500),
+               subj.replace(b"!", b"")[:7000]]
+    import andi_amd
+    Q = andi_amd.Queries(ctx, queries)
+    E = andi_amd.Esa(ctx, subj)
+    got = andi_amd.scan_rows(ctx, [E], [-1], Q, andi_amd.M_JC, 512)
+    for k, qq in enumerate(queries):
+        assert (got[0, k] == O.dist_anchor(qq)).all(), k
+    E.close()
+    Q.close()
+
+
 def test_repeats_and_models(ctx, orc):
     rng = np.random.default_rng(41)
     unit = rand_dna(rng, 3000)
