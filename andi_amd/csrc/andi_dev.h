@@ -1,48 +1,56 @@
-// andi_dev.h — device-side view of one subject's enhanced suffix array and the
-// interval primitives shared by the index-build and scan kernels (gfx950).
+// andi_dev.h — device-side view of one subject's index and the primitives shared
+// by the index-build and scan kernels (gfx950).
 //
 // Layout in HBM per subject (all hipMalloc'ed, see api.hip):
 //   S    uint8[n+1+PAD]  RS, NUL at n, zero padding so wide loads never fault
 //   SA   int32[n]        suffix array (host-built, src/esa.c:294-304)
+// scan index (what the anchor scan uses; built by k_suffix_prefixes + k_probe_table):
+//   deep uint2[4^K]      probe table: for every ACGT K-mer the outcome of the
+//                        longest-match search as far as the K-mer alone decides
+//                        it, so most probes cost one random access
+//   rec  uint32[n]       scratch: K-mer code + valid length of every suffix
+//   flags int32[4]       [0] != 0: some 10-mer table entry may span a separator
+//                        (SURVEY.md appendix C.11): the reference's cached lookup
+//                        is then not the true longest match and the scan follows
+//                        the reference walk below instead of the probe table
+//                        [2] set by the 10-mer table kernel when it really
+//                        produced such an entry (diagnostic)
+// reference arrays (esa_s, src/esa.h:42-59; built on request or when flags[0]):
 //   LCP  int32[n+1]      LCP[0]=LCP[n]=-1          (K1, src/esa.c:373-426)
 //   CLD  int32[n+1]      child table                (K2, src/esa.c:312-363)
 //   FVC  uint8[n]        S[SA[i]+LCP[i]]            (K3, src/esa.c:229-245)
 //   tab  int4[4^10]      10-mer interval table {l,i,j,m} (K4, src/esa.c:73-215)
-//   deep uint2[4^K]      probe table (K4b): for every ACGT K-mer (K = 11..13) the
-//                        outcome of the longest-match search as far as the K-mer
-//                        alone decides it, so most probes cost one random access
-//   side int4[..]        intervals of K-mers that occur more than once
-//   flags int32[4]       [0] != 0: the 10-mer table has an entry spanning a
-//                        separator -> deep table unused
-//                        [1] number of side entries handed out
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define ANDI_CACHE_K 10
 #define ANDI_PAD 2048 /* bytes of zero padding behind every byte pool */
+#define ANDI_MAX_DEEP_K 13
 
 struct EsaDev {
 	const uint8_t *S;
 	const int32_t *SA;
-	const int32_t *LCP;
+	const int32_t *LCP; // reference arrays: null until built
 	const int32_t *CLD;
 	const uint8_t *FVC;
 	const int4 *tab; // x=l y=i z=j w=m
-	const uint2 *deep; // may be null
-	const int4 *side;
+	const uint2 *deep;
 	const int32_t *flags;
 	int32_t n;
 	int32_t thr;
-	int32_t deepK;    // 0 = no probe table
-	int32_t side_cap;
+	int32_t deepK;
+	int32_t mode; // ANDI_MODE_*
 };
 
+#define ANDI_MODE_PROBE 0     /* probe table + suffix-array search (true longest match) */
+#define ANDI_MODE_REFERENCE 1 /* 10-mer table + child-table walk, exactly as src/esa.c */
+
 // probe-table entry: x = payload, y = kind | unique << 2 | l << 8
-#define DEEP_FINAL 0u    /* K-mer absent: match length l < K, x = SA[i] of the matched prefix */
-#define DEEP_SINGLE 1u   /* K-mer occurs once: x = its position in RS */
-#define DEEP_MULTI 2u    /* K-mer occurs more than once: x = index into side[] */
-#define DEEP_FALLBACK 3u /* use the reference walk (side table full) */
+#define DEEP_FINAL 0u  /* K-mer absent: match length l < K; x = SA index of the one suffix if unique */
+#define DEEP_SINGLE 1u /* K-mer occurs once: x = its position in RS */
+#define DEEP_MULTI 2u  /* K-mer occurs more than once: x = first SA index, y >> 8 = run length - 1 */
+#define DEEP_SEARCH 3u /* (run too long to encode) search the whole suffix array */
 
 // Device code addresses the index through global-address-space pointers so
 // the compiler emits global_load (not flat_load) for them.
@@ -58,19 +66,15 @@ struct EsaG {
 	g_u8p FVC;
 	g_i4p tab;
 	g_u2p deep;
-	g_i4p side;
-	int32_t n, thr, deepK;
+	int32_t n, thr, deepK, mode;
 };
 
 __device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
 	EsaG g;
 	g.S = (g_u8p)e.S, g.SA = (g_i32p)e.SA, g.LCP = (g_i32p)e.LCP, g.CLD = (g_i32p)e.CLD;
 	g.FVC = (g_u8p)e.FVC, g.tab = (g_i4p)e.tab;
-	g.deep = (g_u2p)e.deep, g.side = (g_i4p)e.side;
-	g.n = e.n, g.thr = e.thr;
-	// the probe table is only valid when the 10-mer table has no entry spanning
-	// a separator: then get_match_cached == the true longest match everywhere
-	g.deepK = (e.deep && e.deepK > 0 && ((ANDI_GLOBAL const int32_t *)e.flags)[0] == 0) ? e.deepK : 0;
+	g.deep = (g_u2p)e.deep;
+	g.n = e.n, g.thr = e.thr, g.deepK = e.deepK, g.mode = e.mode;
 	return g;
 }
 
@@ -332,46 +336,91 @@ struct Probe {
 	bool unique;
 };
 
+// Longest match of q[0..qlen) given that exactly the suffixes SA[lo..hi] start
+// with q[0..k): the search of get_match_from (src/esa.c:531-601) without the
+// child table.  All suffixes of the range share c = lcp(first, last) characters;
+// q is compared against that label, then the range is narrowed by q[c] with two
+// binary searches (suffixes are sorted by their character at depth c).
+template <int G>
+__device__ __forceinline__ Probe sa_range_match(const EsaG &E, g_u8p q, uint32_t qlen, int32_t lo,
+												int32_t hi, uint32_t k) {
+	Probe r;
+	for (;;) {
+		int32_t pl = E.SA[lo];
+		if (lo == hi) { // one suffix left: extend along it
+			r.len = k < qlen ? k + common_prefix<G>(q + k, E.S + pl + k, qlen - k) : k;
+			r.pos = (uint32_t)pl, r.unique = true;
+			return r;
+		}
+		r.pos = (uint32_t)pl, r.unique = false;
+		if (k >= qlen) {
+			r.len = qlen;
+			return r;
+		}
+		int32_t ph = E.SA[hi];
+		// two distinct suffixes differ at or before the shorter one's NUL
+		uint32_t room = (uint32_t)E.n - (uint32_t)(pl > ph ? pl : ph);
+		uint32_t c = k < room ? k + common_prefix<G>(E.S + pl + k, E.S + ph + k, room - k) : k;
+		uint32_t lim = c < qlen ? c : qlen;
+		uint32_t m = k < lim ? k + common_prefix<G>(q + k, E.S + pl + k, lim - k) : k;
+		if (m < lim || m >= qlen) { // mismatch inside the shared label, or query exhausted
+			r.len = m;
+			return r;
+		}
+		// m == c < qlen: narrow by the next query character
+		const uint8_t ch = q[c];
+		int32_t a = lo, b = hi + 1; // first index with char >= ch
+		while (a < b) {
+			int32_t mid = a + ((b - a) >> 1);
+			if (E.S[E.SA[mid] + c] < ch) a = mid + 1; else b = mid;
+		}
+		int32_t first = a;
+		b = hi + 1; // first index with char > ch
+		while (a < b) {
+			int32_t mid = a + ((b - a) >> 1);
+			if (E.S[E.SA[mid] + c] <= ch) a = mid + 1; else b = mid;
+		}
+		if (first == a) { // no suffix continues with ch
+			r.len = c;
+			return r;
+		}
+		lo = first, hi = a - 1, k = c + 1;
+	}
+}
+
+// The probe of one chain step.  ANDI_MODE_PROBE: the K-mer at q decides most
+// outcomes with one table access; results are those of the true longest match,
+// which is what get_match_cached computes unless flags[0] is set.
+// ANDI_MODE_REFERENCE: the reference's own walk.
 template <int G>
 __device__ __forceinline__ Probe esa_probe(const EsaG &E, g_u8p q, uint32_t qlen) {
 	Probe r;
+	if (E.mode == ANDI_MODE_REFERENCE) {
+		Ival m = esa_match_cached<G>(E, q, qlen);
+		r.len = m.l <= 0 ? 0u : (uint32_t)m.l;
+		r.unique = m.i == m.j;
+		r.pos = (uint32_t)E.SA[m.i];
+		return r;
+	}
 	const int K = E.deepK;
 	uint32_t code;
-	if (K > 0 && qlen > (uint32_t)K && kmer_code(q, K, code)) {
+	if (qlen > (uint32_t)K && kmer_code(q, K, code)) {
 		uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + code));
-		uint2 e = make_uint2((uint32_t)raw, (uint32_t)(raw >> 32));
-		uint32_t kind = e.y & 3u;
+		uint32_t x = (uint32_t)raw, y = (uint32_t)(raw >> 32);
+		uint32_t kind = y & 3u;
 		if (kind == DEEP_FINAL) {
-			r.len = e.y >> 8, r.unique = (e.y >> 2) & 1u, r.pos = e.x;
+			r.len = y >> 8, r.unique = (y >> 2) & 1u;
+			r.pos = (r.unique && r.len >= (uint32_t)E.thr) ? (uint32_t)E.SA[x] : 0u;
 			return r;
 		}
 		if (kind == DEEP_SINGLE) {
-			r.pos = e.x, r.unique = true;
-			r.len = (uint32_t)K + common_prefix<G>(q + K, E.S + e.x + K, qlen - (uint32_t)K);
+			r.pos = x, r.unique = true;
+			r.len = (uint32_t)K + common_prefix<G>(q + K, E.S + x + K, qlen - (uint32_t)K);
 			return r;
 		}
-		if (kind == DEEP_MULTI) {
-			uint4 t = ld_u128_unaligned((g_u8p)(E.side + e.x)); // {l,i,j,m}, l >= K
-			Ival ij;
-			ij.l = (int32_t)t.x, ij.i = (int32_t)t.y, ij.j = (int32_t)t.z, ij.m = (int32_t)t.w;
-			// all suffixes of the interval agree up to ij.l; only K characters are verified
-			uint32_t k = (uint32_t)K;
-			uint32_t lim = (uint32_t)ij.l < qlen ? (uint32_t)ij.l : qlen;
-			if (k < lim) k += common_prefix<G>(q + k, E.S + E.SA[ij.i] + k, lim - k);
-			if (k < lim || k >= qlen) {
-				r.len = k, r.unique = false, r.pos = 0;
-				return r;
-			}
-			Ival m = esa_match_from<G>(E, q, qlen, ij.l, ij);
-			r.len = m.l <= 0 ? 0u : (uint32_t)m.l;
-			r.unique = m.i == m.j;
-			r.pos = (uint32_t)E.SA[m.i];
-			return r;
-		}
+		if (kind == DEEP_MULTI)
+			return sa_range_match<G>(E, q, qlen, (int32_t)x, (int32_t)(x + (y >> 8)), (uint32_t)K);
 	}
-	Ival m = esa_match_cached<G>(E, q, qlen);
-	r.len = m.l <= 0 ? 0u : (uint32_t)m.l;
-	r.unique = m.i == m.j;
-	r.pos = (uint32_t)E.SA[m.i];
-	return r;
+	// short remainder, separator within the first K characters, or DEEP_SEARCH
+	return sa_range_match<G>(E, q, qlen, 0, E.n - 1, 0);
 }

@@ -54,14 +54,16 @@ struct andi_hip_esa {
 	int32_t *SA = nullptr, *LCP = nullptr, *CLD = nullptr;
 	uint8_t *FVC = nullptr;
 	int4 *tab = nullptr;
-	uint2 *deep = nullptr;
-	int4 *side = nullptr;
-	int32_t *flags = nullptr;
-	int32_t deepK = 0, side_cap = 0;
 	int32_t *min_scratch = nullptr;
+	uint2 *deep = nullptr;
+	uint32_t *rec = nullptr;
+	int32_t *flags = nullptr;   // device, 4 ints
+	int32_t *h_flags = nullptr; // pinned host copy, refreshed after every index build
+	int32_t deepK = 0;
 	int32_t n = 0;
 	int32_t thr = 0;
-	bool built = false;
+	bool ref_built = false;   // LCP, CLD, FVC, tab valid
+	bool index_built = false; // deep, flags valid
 	size_t bytes = 0;
 };
 
@@ -151,12 +153,32 @@ struct Timed {
 	}
 };
 
-EsaDev esa_view(const andi_hip_esa *e) {
+EsaDev esa_view(const andi_hip_esa *e, int mode) {
 	EsaDev v;
 	v.S = e->S, v.SA = e->SA, v.LCP = e->LCP, v.CLD = e->CLD, v.FVC = e->FVC, v.tab = e->tab;
-	v.deep = e->deep, v.side = e->side, v.flags = e->flags;
-	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.side_cap = e->side_cap;
+	v.deep = e->deep, v.flags = e->flags;
+	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.mode = mode;
 	return v;
+}
+
+// probe table depth: smallest K with 4^K >= n, within [4, 13]
+int pick_deep_k(size_t n) {
+	int K = 4;
+	while (K < ANDI_MAX_DEEP_K && ((size_t)1 << (2 * K)) < n) ++K;
+	if (const char *ev = getenv("ANDI_DEEP_K")) {
+		int v = atoi(ev);
+		if (v >= 4 && v <= ANDI_MAX_DEEP_K) K = v;
+	}
+	return K;
+}
+
+EsaBuildArgs build_args(const andi_hip_esa *e) {
+	EsaBuildArgs a;
+	a.S = e->S, a.SA = e->SA, a.LCP = e->LCP, a.CLD = e->CLD, a.FVC = e->FVC, a.tab = e->tab;
+	a.deep = e->deep, a.rec = e->rec, a.flags = e->flags, a.deepK = e->deepK;
+	a.min_scratch = e->min_scratch;
+	a.n = e->n;
+	return a;
 }
 
 } // namespace
@@ -267,36 +289,20 @@ int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, siz
 	auto *e = new andi_hip_esa;
 	e->n = (int32_t)n;
 	e->thr = (int32_t)threshold;
-	const size_t tab_entries = (size_t)1 << (2 * ANDI_CACHE_K);
-	const size_t mins = andi_min_tree_entries(e->n);
 	hipError_t err = hipSuccess;
 	auto chk = [&](hipError_t x) {
 		if (err == hipSuccess) err = x;
 	};
+	e->deepK = pick_deep_k(n);
+	const size_t deep_entries = (size_t)1 << (2 * e->deepK);
 	chk(dmalloc(&e->S, n + 1 + ANDI_PAD));
 	chk(dmalloc(&e->SA, n));
-	chk(dmalloc(&e->LCP, n + 1));
-	chk(dmalloc(&e->CLD, n + 1));
-	chk(dmalloc(&e->FVC, n + ANDI_PAD));
-	chk(dmalloc(&e->tab, tab_entries));
-	chk(dmalloc(&e->min_scratch, mins));
+	chk(dmalloc(&e->deep, deep_entries));
+	chk(dmalloc(&e->rec, n));
 	chk(dmalloc(&e->flags, 4));
-	// probe table depth: 4^K a few times the text length (override: ANDI_DEEP_K, 0 = off)
-	int K = 11;
-	while (K < 13 && ((size_t)1 << (2 * K)) < n) ++K;
-	if (const char *ev = getenv("ANDI_DEEP_K")) K = atoi(ev);
-	if (K != 0 && (K < 11 || K > 13)) K = 12;
-	if (n < 4096) K = 0; // tiny subjects: the reference walk is just as fast
-	e->deepK = K;
-	size_t deep_bytes = 0;
-	if (K) {
-		e->side_cap = (int32_t)std::min<size_t>(n / 2 + 16, (size_t)1 << (2 * K));
-		chk(dmalloc(&e->deep, (size_t)1 << (2 * K)));
-		chk(dmalloc(&e->side, (size_t)e->side_cap));
-		deep_bytes = ((size_t)8 << (2 * K)) + 16 * (size_t)e->side_cap;
-	}
-	e->bytes = (n + 1 + ANDI_PAD) + 4 * n + 8 * (n + 1) + n + ANDI_PAD + 16 * tab_entries + 4 * mins +
-			   deep_bytes;
+	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault));
+	e->bytes = (n + 1 + ANDI_PAD) + 4 * n + 8 * deep_entries + 4 * n + 16;
+	if (err == hipSuccess) err = hipMemsetAsync(e->flags, 0, 4 * sizeof(int32_t), ctx->stream);
 	if (err == hipSuccess) err = hipMemsetAsync(e->S + n, 0, 1 + ANDI_PAD, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(e->S, RS, n, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess)
@@ -311,25 +317,64 @@ int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, siz
 	return 0;
 }
 
+static int ensure_reference_buffers(andi_hip_ctx *ctx, andi_hip_esa *e) {
+	if (e->LCP) return 0;
+	const size_t n = (size_t)e->n;
+	const size_t tab_entries = (size_t)1 << (2 * ANDI_CACHE_K);
+	const size_t mins = andi_min_tree_entries(e->n);
+	hipError_t err = hipSuccess;
+	auto chk = [&](hipError_t x) {
+		if (err == hipSuccess) err = x;
+	};
+	chk(dmalloc(&e->LCP, n + 1));
+	chk(dmalloc(&e->CLD, n + 1));
+	chk(dmalloc(&e->FVC, n + ANDI_PAD));
+	chk(dmalloc(&e->tab, tab_entries));
+	chk(dmalloc(&e->min_scratch, mins));
+	if (err != hipSuccess) return fail(ctx, "allocating the reference arrays", err);
+	e->bytes += 8 * (n + 1) + n + ANDI_PAD + 16 * tab_entries + 4 * mins;
+	return 0;
+}
+
 int andi_hip_esa_build(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!ctx || !e) return 1;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	EsaBuildArgs a;
-	a.S = e->S, a.SA = e->SA, a.LCP = e->LCP, a.CLD = e->CLD, a.FVC = e->FVC, a.tab = e->tab;
-	a.min_scratch = e->min_scratch;
-	a.deep = e->deep, a.side = e->side, a.flags = e->flags, a.deepK = e->deepK, a.side_cap = e->side_cap;
-	a.n = e->n;
+	if (ensure_reference_buffers(ctx, e)) return 1;
 	Timed t(ctx, 0);
-	hipError_t err = andi_launch_esa_build(a, ctx->stream);
+	hipError_t err = andi_launch_esa_build(build_args(e), ctx->stream);
 	t.stop();
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build", err);
-	e->built = true;
+	e->ref_built = true;
+	return 0;
+}
+
+int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
+	if (!ctx || !e) return 1;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	Timed t(ctx, 0);
+	hipError_t err = andi_launch_index_build(build_args(e), ctx->stream);
+	t.stop();
+	if (err == hipSuccess)
+		err = hipMemcpyAsync(e->h_flags, e->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index", err);
+	e->index_built = true;
+	return 0;
+}
+
+int andi_hip_esa_flags(andi_hip_ctx *ctx, const andi_hip_esa *e, int32_t *out4) {
+	if (!ctx || !e || !out4) return 1;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	HIP_TRY(ctx, hipMemcpy(out4, e->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
 	return 0;
 }
 
 int andi_hip_esa_download(andi_hip_ctx *ctx, const andi_hip_esa *e, int32_t *LCP, int32_t *CLD,
 						  uint8_t *FVC, andi_hip_interval *cache) {
 	if (!ctx || !e) return 1;
+	if (!e->ref_built) {
+		ctx->err = "andi_hip_esa_download: reference arrays not built (call andi_hip_esa_build)";
+		return 1;
+	}
 	const size_t n = (size_t)e->n;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	if (LCP) HIP_TRY(ctx, hipMemcpy(LCP, e->LCP, (n + 1) * 4, hipMemcpyDeviceToHost));
@@ -353,9 +398,10 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	(void)hipFree(e->FVC);
 	(void)hipFree(e->tab);
 	(void)hipFree(e->deep);
-	(void)hipFree(e->side);
+	(void)hipFree(e->rec);
 	(void)hipFree(e->flags);
 	(void)hipFree(e->min_scratch);
+	if (e->h_flags) (void)hipHostFree(e->h_flags);
 	delete e;
 }
 
@@ -458,8 +504,8 @@ static int ensure_segmentation(andi_hip_ctx *ctx, andi_hip_queries *q, uint32_t 
 int andi_hip_match_positions(andi_hip_ctx *ctx, const andi_hip_esa *esa, const andi_hip_queries *q,
 							 size_t qidx, size_t first, size_t count, int cached,
 							 andi_hip_interval *out_host) {
-	if (!ctx || !esa || !q || !out_host || qidx >= q->nq || !esa->built) {
-		if (ctx) ctx->err = "andi_hip_match_positions: bad arguments (index not built?)";
+	if (!ctx || !esa || !q || !out_host || qidx >= q->nq || !esa->ref_built) {
+		if (ctx) ctx->err = "andi_hip_match_positions: bad arguments (reference arrays not built?)";
 		return 1;
 	}
 	if (first + count > q->len[qidx]) {
@@ -470,7 +516,7 @@ int andi_hip_match_positions(andi_hip_ctx *ctx, const andi_hip_esa *esa, const a
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	andi_hip_interval *d_out = nullptr;
 	HIP_TRY(ctx, dmalloc(&d_out, count));
-	hipError_t e = andi_launch_match_positions(esa_view(esa), q->pool + q->off[qidx], q->len[qidx],
+	hipError_t e = andi_launch_match_positions(esa_view(esa, ANDI_MODE_REFERENCE), q->pool + q->off[qidx], q->len[qidx],
 											   (uint32_t)first, (uint32_t)count, cached, d_out,
 											   ctx->stream);
 	if (e == hipSuccess)
@@ -483,7 +529,7 @@ int andi_hip_match_positions(andi_hip_ctx *ctx, const andi_hip_esa *esa, const a
 }
 
 // ------------------------------------------------------------------ scan
-int andi_hip_scan_rows(andi_hip_ctx *ctx, const andi_hip_esa *const *subjects, const int64_t *self,
+int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const int64_t *self,
 					   size_t nsub, const andi_hip_queries *q_const, int model, uint32_t segment,
 					   andi_hip_model *M_dev) {
 	if (!ctx || !subjects || !q_const || !M_dev || nsub == 0 || nsub > 65535) {
@@ -518,12 +564,23 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, const andi_hip_esa *const *subjects, c
 	auto *h_esa = (EsaDev *)ctx->desc_host;
 	auto *h_self = (int64_t *)(h_esa + nsub);
 	uint64_t pairs = 0, nt = 0;
+	// the index builds must have finished: their flags decide which walk is exact
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	for (size_t s = 0; s < nsub; ++s) {
-		if (!subjects[s] || !subjects[s]->built) {
+		andi_hip_esa *e = subjects[s];
+		if (!e || (!e->index_built && !e->ref_built)) {
 			ctx->err = "andi_hip_scan_rows: subject index not built";
 			return 1;
 		}
-		h_esa[s] = esa_view(subjects[s]);
+		int mode = ANDI_MODE_PROBE;
+		if (!e->index_built || e->h_flags[0] != 0 || getenv("ANDI_FORCE_REFERENCE")) {
+			// a 10-mer table entry may span a separator: only the reference's
+			// own walk reproduces get_match_cached there
+			mode = ANDI_MODE_REFERENCE;
+			if (!e->ref_built && andi_hip_esa_build(ctx, e)) return 1;
+			ctx->acc.reference_subjects++;
+		}
+		h_esa[s] = esa_view(e, mode);
 		h_self[s] = self ? self[s] : -1;
 		bool has_self = h_self[s] >= 0 && (size_t)h_self[s] < q->nq;
 		pairs += q->nq - (has_self ? 1 : 0);
@@ -716,9 +773,9 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		}
 		andi_hip_esa *E = nullptr;
 		if (!rc && andi_hip_esa_stage(ctx, p->RS, p->SA.data(), p->n, p->thr, &E)) bail("staging subject");
-		if (!rc && andi_hip_esa_build(ctx, E)) bail("index build");
+		if (!rc && andi_hip_esa_build_index(ctx, E)) bail("index build");
 		int64_t self = (int64_t)i;
-		const andi_hip_esa *subj[1] = {E};
+		andi_hip_esa *subj[1] = {E};
 		if (!rc && andi_hip_scan_rows(ctx, subj, &self, 1, Q, o.model, o.segment, d_row)) bail("scan");
 		if (!rc && andi_hip_copy_to_host(ctx, M + i * n, d_row, n * sizeof(andi_hip_model))) bail("row copy");
 		if (E) andi_hip_esa_free(ctx, E);

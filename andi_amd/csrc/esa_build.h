@@ -19,14 +19,16 @@ struct EsaBuildArgs {
 	int32_t *CLD;       // n + 1   (out; doubles as PLCP scratch)
 	uint8_t *FVC;       // n       (out)
 	int4 *tab;          // 4^10    (out)
-	uint2 *deep;        // 4^deepK (out, may be null)
-	int4 *side;         // side_cap (out)
+	uint2 *deep;        // 4^deepK (out)
+	uint32_t *rec;      // n       (scratch)
 	int32_t *flags;     // 4 ints  (out)
 	int32_t deepK;
-	int32_t side_cap;
 	int32_t *min_scratch; // andi_min_tree_entries(n) ints
 	int32_t n;
 };
 
 size_t andi_min_tree_entries(int32_t n);
+// reference arrays LCP, CLD, FVC, tab (esa_init_LCP/_CLD/_FVC/_cache)
 hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st);
+// scan index: deep, side, flags from S and SA alone
+hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st);

@@ -13,9 +13,13 @@
 //   K2a min_tree      64-ary min pyramid over LCP
 //   K2b child_table   CLD from nearest-smaller-value searches  (src/esa.c:312-363)
 //   K4  kmer_table    4^10 interval table, one thread per 10-mer (src/esa.c:73-215)
-//   K4b probe_table   4^K outcome table for K = 11..13, one thread per K-mer
+// and the scan index (see "scan index" below):
+//   K5a suffix_prefixes  K-mer code and valid length of every suffix
+//   K5b probe_table      4^K outcome table, one thread per suffix-array gap
 #include "andi_dev.h"
 #include "esa_build.h"
+
+#include <cstring>
 
 #define CHECK_LAUNCH()                                                                             \
 	do {                                                                                           \
@@ -233,8 +237,8 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 				out = ij;
 				decided = true;
 				// such an entry makes get_match_cached differ from the true
-				// longest match: remember it
-				atomicOr(&flags[0], 1);
+				// longest match
+				atomicOr(&flags[2], 1);
 				break;
 			}
 			if (e != sym(k)) {
@@ -250,72 +254,154 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 	tab[code] = make_int4(out.l, out.i, out.j, out.m);
 }
 
-// ---------------------------------------------------------------- K4b
-// Probe table.  For every ACGT K-mer w: how far does the longest-match search
-// (get_match, src/esa.c:531-624) get on w alone?
-//   w absent      -> FINAL: the match length l < K, uniqueness and SA[i] of the
-//                    matched prefix are the final answer for every query that
-//                    starts with w;
-//   w occurs once -> SINGLE: its position; the query is extended along it;
-//   w occurs more -> MULTI: the lcp-interval of w, the search resumes there.
-// Semantics are those of the true longest match; they coincide with the
-// reference's get_match_cached unless flags[0] is set, in which case the scan
-// ignores this table.  The walk starts from the 10-mer table entry.
-__global__ __launch_bounds__(256) void k_probe_table(EsaDev Ed, uint2 *__restrict__ deep,
-													 int4 *__restrict__ side,
-													 int32_t *__restrict__ flags) {
-	const int K = Ed.deepK;
-	uint32_t code = blockIdx.x * blockDim.x + threadIdx.x;
-	if (code >= (1u << (2 * K))) return;
-	if (flags[0]) return; // 10-mer table is not the true longest match here
-	const EsaG E = esa_global(Ed);
-	auto sym = [&](int pos) { return code_nt(code >> (2 * (K - 1 - pos))); };
-	auto emit = [&](uint32_t kind, uint32_t unique, uint32_t l, uint32_t x) {
-		deep[code] = make_uint2(x, kind | (unique << 2) | (l << 8));
-	};
+// ================================================================ scan index
+// The anchor scan needs, per probe, only (match length, unique?, position).
+// The probe table answers that from the first K query characters.  It is built
+// bottom-up from the suffix array in two streaming passes; the only random
+// accesses are one 16-byte read of S per suffix.
+//
+// rec[r] describes suffix SA[r]: bits 31..6 the 2-bit code of its first K
+// characters (first character most significant, garbage past the valid part),
+// bits 5..4 what follows the valid part (0 ACGT/none, 1 '!', 2 ';', 3 other),
+// bits 3..0 v = number of leading ACGT characters, capped at K.
+#define REC_V(x) ((x)&15u)
+#define REC_SEP(x) (((x) >> 4) & 3u)
+#define REC_CODE(x) ((x) >> 6)
 
-	uint4 t = ld_u128_unaligned((g_u8p)(E.tab + (code >> (2 * (K - ANDI_CACHE_K)))));
-	Ival in;
-	in.l = (int32_t)t.x, in.i = (int32_t)t.y, in.j = (int32_t)t.z, in.m = (int32_t)t.w;
-	int pos = in.l; // characters of w matched so far; == lcp of `in` unless singleton
-	for (;;) {
-		if (in.i == in.j) { // one suffix left: compare the rest of w against it
-			int32_t suf = E.SA[in.i];
-			while (pos < K && E.S[suf + pos] == sym(pos)) ++pos;
-			if (pos == K) {
-				emit(DEEP_SINGLE, 1, (uint32_t)K, (uint32_t)suf);
-			} else {
-				emit(DEEP_FINAL, 1, (uint32_t)pos, (uint32_t)suf);
+__global__ __launch_bounds__(256) void k_suffix_prefixes(const uint8_t *__restrict__ Sd,
+														 const int32_t *__restrict__ SA,
+														 uint32_t *__restrict__ rec, int32_t n, int K) {
+	int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	g_u8p S = (g_u8p)Sd;
+	uint4 w = ld_u128_unaligned(S + SA[r]); // bytes past the text are NUL padding
+	// per byte: bit 6 set <=> ACGT
+	uint32_t valid = 0; // bit t set <=> byte t is ACGT
+	uint32_t words[4] = {w.x, w.y, w.z, w.w};
+	uint32_t code = 0;
+#pragma unroll
+	for (int d = 0; d < 4; ++d) {
+		uint32_t x = words[d] & 0x06060606u;
+		x ^= x >> 1;
+		x = (x >> 1) & 0x03030303u;
+		code = (code << 8) | ((x & 0xffu) << 6) | (((x >> 8) & 0xffu) << 4) | (((x >> 16) & 0xffu) << 2) | (x >> 24);
+		uint32_t m = words[d] & 0x40404040u;
+		valid |= (((m >> 6) & 1u) | ((m >> 13) & 2u) | ((m >> 20) & 4u) | ((m >> 27) & 8u)) << (4 * d);
+	}
+	uint32_t v = (uint32_t)__builtin_ctz(~valid); // leading ACGT characters, 0..16
+	uint32_t sep = 0;
+	if (v < (uint32_t)K) {
+		uint8_t c = (uint8_t)(words[v >> 2] >> (8 * (v & 3u)));
+		sep = c == '!' ? 1u : (c == ';' ? 2u : 3u);
+	} else {
+		v = (uint32_t)K;
+	}
+	rec[r] = ((code >> (32 - 2 * K)) << 6) | (sep << 4) | v;
+}
+
+// leading characters two suffixes share, counting ACGT only, capped at K
+__device__ __forceinline__ uint32_t rec_lcp(uint32_t a, uint32_t b, int K) {
+	uint32_t x = REC_CODE(a) ^ REC_CODE(b);
+	uint32_t same = x ? (uint32_t)(__builtin_clz(x) - (32 - 2 * K)) >> 1 : (uint32_t)K;
+	uint32_t va = REC_V(a), vb = REC_V(b);
+	uint32_t m = va < vb ? va : vb;
+	return same < m ? same : m;
+}
+
+// leading characters the K-mer `code` shares with a suffix
+__device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int K) {
+	uint32_t x = code ^ REC_CODE(a);
+	uint32_t same = x ? (uint32_t)(__builtin_clz(x) - (32 - 2 * K)) >> 1 : (uint32_t)K;
+	uint32_t va = REC_V(a);
+	return same < va ? same : va;
+}
+
+// One thread per gap r = 0..n of the suffix array (between suffix r-1 and r).
+//  (a) if suffix r starts a run of suffixes with the same valid K-mer, write that
+//      K-mer's entry: SINGLE (position) or MULTI (first SA index and run length);
+//  (b) every K-mer that sorts strictly inside the gap is absent from RS: its
+//      longest match is the longer of its common prefixes with the two
+//      neighbours; write FINAL(l, unique, SA index);
+//  (c) detect what can make the reference's 10-mer table differ from the true
+//      longest match: a prefix w (1..8 ACGT characters) whose every occurrence is
+//      followed by the same separator, at least twice (SURVEY.md appendix C.11;
+//      this test is a superset of the exact condition) -> flags[0].
+__global__ __launch_bounds__(256) void k_probe_table(const uint32_t *__restrict__ rec,
+													 const int32_t *__restrict__ SA,
+													 uint2 *__restrict__ deep,
+													 int32_t *__restrict__ flags, int32_t n, int K) {
+	int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid > n) return;
+	const int32_t r = (int32_t)gid;
+	const bool hasL = r > 0, hasR = r < n;
+	const uint32_t L = hasL ? rec[r - 1] : 0u, R = hasR ? rec[r] : 0u;
+	const uint32_t full = (uint32_t)K;
+	const uint32_t h = (hasL && hasR) ? rec_lcp(L, R, K) : 0u;
+
+	// (a) present K-mers
+	if (hasR && REC_V(R) == full && !(hasL && REC_V(L) == full && REC_CODE(L) == REC_CODE(R))) {
+		int32_t j = r;
+		while (j + 1 < n && rec[j + 1] == R) ++j;
+		uint32_t code = REC_CODE(R);
+		if (j == r) {
+			deep[code] = make_uint2((uint32_t)SA[r], DEEP_SINGLE | (1u << 2) | (full << 8));
+		} else if ((uint32_t)(j - r) < (1u << 24)) {
+			deep[code] = make_uint2((uint32_t)r, DEEP_MULTI | ((uint32_t)(j - r) << 8));
+		} else {
+			deep[code] = make_uint2(0, DEEP_SEARCH);
+		}
+	}
+
+	// (c) closed run of suffixes "w <sep>" with 1 <= |w| <= 8
+	if (hasR) {
+		uint32_t k = REC_V(R), sp = REC_SEP(R);
+		if (k >= 1 && k <= 8 && k < full && (sp == 1 || sp == 2) && (!hasL || h < k)) {
+			int32_t j = r;
+			while (j + 1 < n) {
+				uint32_t X = rec[j + 1];
+				if (REC_V(X) == k && REC_SEP(X) == sp && rec_lcp(R, X, K) == k) ++j; else break;
 			}
-			return;
+			if (j > r && (j + 1 == n || rec_lcp(R, rec[j + 1], K) < k)) atomicOr(&flags[0], 1);
 		}
-		if (pos >= K) { // w is a proper prefix of (or equal to) the interval's label
-			uint32_t slot = (uint32_t)atomicAdd(&flags[1], 1);
-			if (slot < (uint32_t)Ed.side_cap) {
-				side[slot] = make_int4(in.l, in.i, in.j, in.m);
-				emit(DEEP_MULTI, 0, (uint32_t)K, slot);
-			} else {
-				emit(DEEP_FALLBACK, 0, 0, 0);
-			}
-			return;
+	}
+
+	// (b) absent K-mers inside this gap
+	int64_t lo, hi;
+	if (!hasL) {
+		lo = 0;
+	} else if (REC_V(L) == full) {
+		lo = (int64_t)REC_CODE(L) + 1;
+	} else { // w <sep> sorts before every K-mer that starts with w
+		uint32_t sh = 2 * (full - REC_V(L));
+		lo = (int64_t)((REC_CODE(L) >> sh) << sh);
+	}
+	if (!hasR) {
+		hi = ((int64_t)1 << (2 * K)) - 1;
+	} else if (REC_V(R) == full) {
+		hi = (int64_t)REC_CODE(R) - 1;
+	} else {
+		uint32_t sh = 2 * (full - REC_V(R));
+		hi = (int64_t)((REC_CODE(R) >> sh) << sh) - 1;
+	}
+	if (lo > hi) return;
+	// is the left (right) neighbour the only suffix sharing a given prefix length with it?
+	const uint32_t hLL = (r >= 2) ? rec_lcp(rec[r - 2], L, K) : 0u;  // lcp(suffix r-2, suffix r-1)
+	const uint32_t hRR = (r + 1 < n) ? rec_lcp(R, rec[r + 1], K) : 0u; // lcp(suffix r, suffix r+1)
+	for (int64_t c = lo; c <= hi; ++c) {
+		uint32_t lL = hasL ? rec_lcp_code((uint32_t)c, L, K) : 0u;
+		uint32_t lR = hasR ? rec_lcp_code((uint32_t)c, R, K) : 0u;
+		uint32_t l, uniq, idx;
+		if (lL > lR) {
+			l = lL, idx = (uint32_t)(r - 1);
+			uniq = (r < 2 || hLL < l) ? 1u : 0u;
+		} else if (lR > lL) {
+			l = lR, idx = (uint32_t)r;
+			uniq = (r + 1 >= n || hRR < l) ? 1u : 0u;
+		} else { // both neighbours share l characters (or l == 0: every suffix does)
+			l = lL, idx = 0, uniq = (n == 1) ? 1u : 0u;
 		}
-		// here pos == in.l: branch on the next character
-		Ival ij = esa_child(E, in, sym(pos));
-		if (ival_empty(ij)) {
-			emit(DEEP_FINAL, 0, (uint32_t)pos, (uint32_t)E.SA[in.i]);
-			return;
-		}
-		++pos;
-		if (ij.i < ij.j) { // verify the label up to the child's depth
-			int32_t suf = E.SA[ij.i];
-			int lim = ij.l < K ? ij.l : K;
-			while (pos < lim && E.S[suf + pos] == sym(pos)) ++pos;
-			if (pos < lim) {
-				emit(DEEP_FINAL, 0, (uint32_t)pos, (uint32_t)suf);
-				return;
-			}
-		}
-		in = ij;
+		if (l == 0) uniq = (n == 1) ? 1u : 0u;
+		deep[c] = make_uint2(idx, DEEP_FINAL | (uniq << 2) | (l << 8));
 	}
 }
 
@@ -328,6 +414,19 @@ size_t andi_min_tree_entries(int32_t n) {
 		total += cnt;
 	}
 	return total ? total : 1;
+}
+
+hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
+	const int32_t n = a.n;
+	const int B = 256;
+	auto blocks = [&](int64_t items) { return (unsigned)((items + B - 1) / B); };
+	hipError_t e = hipMemsetAsync(a.flags, 0, 2 * sizeof(int32_t), st);
+	if (e != hipSuccess) return e;
+	k_suffix_prefixes<<<blocks(n), B, 0, st>>>(a.S, a.SA, a.rec, n, a.deepK);
+	CHECK_LAUNCH();
+	k_probe_table<<<blocks((int64_t)n + 1), B, 0, st>>>(a.rec, a.SA, a.deep, a.flags, n, a.deepK);
+	CHECK_LAUNCH();
+	return hipSuccess;
 }
 
 hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st) {
@@ -368,18 +467,13 @@ hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st) {
 
 	// K4: 10-mer interval table
 	EsaDev E;
+	memset(&E, 0, sizeof E);
 	E.S = a.S, E.SA = a.SA, E.LCP = a.LCP, E.CLD = a.CLD, E.FVC = a.FVC, E.tab = a.tab;
-	E.deep = a.deep, E.side = a.side, E.flags = a.flags;
-	E.n = n, E.thr = 0, E.deepK = a.deepK, E.side_cap = a.side_cap;
-	e = hipMemsetAsync(a.flags, 0, 4 * sizeof(int32_t), st);
+	E.flags = a.flags;
+	E.n = n, E.mode = ANDI_MODE_REFERENCE;
+	e = hipMemsetAsync(a.flags + 2, 0, sizeof(int32_t), st);
 	if (e != hipSuccess) return e;
 	k_kmer_table<<<blocks(1 << (2 * ANDI_CACHE_K)), B, 0, st>>>(E, a.tab, a.flags);
 	CHECK_LAUNCH();
-
-	// K4b: probe table
-	if (a.deep && a.deepK > 0) {
-		k_probe_table<<<blocks((int64_t)1 << (2 * a.deepK)), B, 0, st>>>(E, a.deep, a.side, a.flags);
-		CHECK_LAUNCH();
-	}
 	return hipSuccess;
 }

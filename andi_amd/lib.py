@@ -59,6 +59,7 @@ class Timings(C.Structure):
         ("scan_query_nt", C.c_uint64),
         ("scan_pairs", C.c_uint64),
         ("fixups", C.c_uint64),
+        ("reference_subjects", C.c_uint64),
     ]
 
 
@@ -87,6 +88,8 @@ SYMBOLS = {
     "andi_hip_sync": (C.c_int, [_P]),
     "andi_hip_esa_stage": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
     "andi_hip_esa_build": (C.c_int, [_P, _P]),
+    "andi_hip_esa_build_index": (C.c_int, [_P, _P]),
+    "andi_hip_esa_flags": (C.c_int, [_P, _P, _P]),
     "andi_hip_esa_download": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "andi_hip_esa_free": (None, [_P, _P]),
     "andi_hip_esa_bytes": (C.c_size_t, [_P]),
@@ -241,10 +244,11 @@ class Context:
 
 
 class Esa:
-    """esa_s (src/esa.h:42) resident in HBM: host prepares RS + SA, the device
-    builds LCP, CLD, FVC and the 10-mer table."""
+    """esa_s (src/esa.h:42) resident in HBM: host prepares RS + SA; the device
+    builds the scan index (build="index", default) and/or the reference's own
+    arrays LCP, CLD, FVC, 10-mer table (build="reference")."""
 
-    def __init__(self, ctx: Context, seq: bytes, p_value=0.025, sa=None, build=True):
+    def __init__(self, ctx: Context, seq: bytes, p_value=0.025, sa=None, build="index"):
         self.ctx = ctx
         self.RS, self.gc, self.threshold = subject_prepare(seq, p_value)
         self.n = len(self.RS)
@@ -253,13 +257,29 @@ class Esa:
         L = load()
         ctx._check(L.andi_hip_esa_stage(ctx._h, self.RS, self.SA.ctypes.data, self.n, self.threshold,
                                         C.byref(self._h)), "esa_stage")
-        if build:
+        self.reference_built = False
+        if build in ("index", "both", True):
             self.build()
+        if build in ("reference", "both"):
+            self.build_reference()
 
     def build(self):
+        """scan index (probe table)"""
+        self.ctx._check(load().andi_hip_esa_build_index(self.ctx._h, self._h), "esa_build_index")
+
+    def build_reference(self):
+        """LCP, CLD, FVC, 10-mer table"""
         self.ctx._check(load().andi_hip_esa_build(self.ctx._h, self._h), "esa_build")
+        self.reference_built = True
+
+    def flags(self):
+        out = np.zeros(4, np.int32)
+        self.ctx._check(load().andi_hip_esa_flags(self.ctx._h, self._h, out.ctypes.data), "esa_flags")
+        return out
 
     def download(self):
+        if not self.reference_built:
+            self.build_reference()
         n = self.n
         LCP = np.empty(n + 1, np.int32)
         CLD = np.empty(n + 1, np.int32)
@@ -311,6 +331,8 @@ class Queries:
 def match_positions(esa: Esa, queries: Queries, qidx, first, count, cached=True):
     """get_match(_cached) (src/esa.c:615-656) for consecutive suffixes.
     Returns int32 array (count, 4): l, i, j, SA[i]."""
+    if not esa.reference_built:
+        esa.build_reference()
     out = np.empty((count, 4), np.int32)
     esa.ctx._check(load().andi_hip_match_positions(esa.ctx._h, esa._h, queries._h, qidx, first, count,
                                                    int(cached), out.ctypes.data), "match_positions")

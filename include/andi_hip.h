@@ -118,8 +118,19 @@ int andi_hip_sync(andi_hip_ctx *ctx);
 int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, size_t n,
 					   size_t threshold, andi_hip_esa **out);
 /* esa_init_LCP, _CLD, _FVC, _cache (src/esa.c:373-426, 312-363, 229-245,
- * 73-215) as HIP kernels on the context's stream (asynchronous). */
+ * 73-215) as HIP kernels on the context's stream (asynchronous): the
+ * reference's own arrays, bit for bit. */
 int andi_hip_esa_build(andi_hip_ctx *ctx, andi_hip_esa *esa);
+/* The index the anchor scan uses in place of those arrays: a 4^K table holding,
+ * per K-mer, the outcome of get_match_cached (src/esa.c:636-656) as far as
+ * the K-mer decides it, built from RS and SA alone (asynchronous).  When the
+ * build finds that the reference's 10-mer table may contain an entry spanning
+ * a separator (flags[0], see andi_hip_esa_flags), andi_hip_scan_rows builds
+ * the reference arrays for that subject and follows the reference's walk. */
+int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *esa);
+/* flags[0]: see above; flags[2]: the 10-mer table kernel really produced such an
+ * entry (only after andi_hip_esa_build). */
+int andi_hip_esa_flags(andi_hip_ctx *ctx, const andi_hip_esa *esa, int32_t *flags4);
 /* Test hook: copy the built arrays back.  Any pointer may be NULL.
  * LCP/CLD have n+1 entries, FVC n, cache 4^10. */
 int andi_hip_esa_download(andi_hip_ctx *ctx, const andi_hip_esa *esa, int32_t *LCP,
@@ -139,11 +150,12 @@ int andi_hip_match_positions(andi_hip_ctx *ctx, const andi_hip_esa *esa,
 							 int cached, andi_hip_interval *out_host);
 
 /* dist_anchor (src/process.c:141-214) for every (subject, query) pair of
- * `nsub` staged+built subjects against all queries.  self[s] = index of the
+ * `nsub` staged subjects whose index is built (andi_hip_esa_build_index, or
+ * andi_hip_esa_build for the reference walk) against all queries.  self[s] = index of the
  * query that is subject s itself (gets the diagonal placeholder) or -1.
  * M_dev: device pointer, nsub * nq models, row s = subject s.  Asynchronous
  * on the context's stream. */
-int andi_hip_scan_rows(andi_hip_ctx *ctx, const andi_hip_esa *const *subjects,
+int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects,
 					   const int64_t *self, size_t nsub, const andi_hip_queries *q, int model,
 					   uint32_t segment, andi_hip_model *M_dev);
 
@@ -164,6 +176,7 @@ typedef struct {
 	uint64_t scan_query_nt; /* sum of query lengths over scanned pairs */
 	uint64_t scan_pairs;
 	uint64_t fixups;      /* segments whose speculative entry state was wrong */
+	uint64_t reference_subjects; /* subjects scanned with the reference walk */
 } andi_hip_timings;
 int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t);
 void andi_hip_timings_reset(andi_hip_ctx *ctx);

@@ -105,11 +105,36 @@ def test_separator_spanning_table_entry(ctx, orc):
     import andi_amd
     Q = andi_amd.Queries(ctx, queries)
     E = andi_amd.Esa(ctx, subj)
+    assert E.flags()[0] == 1  # the index build noticed the closed "w!" run
+    ctx.timings_reset()
     got = andi_amd.scan_rows(ctx, [E], [-1], Q, andi_amd.M_JC, 512)
+    assert ctx.timings()["reference_subjects"] == 1  # ... and the scan followed the reference walk
+    assert E.flags()[2] == 1  # the 10-mer table kernel really hit the separator branch
     for k, qq in enumerate(queries):
         assert (got[0, k] == O.dist_anchor(qq)).all(), k
     E.close()
     Q.close()
+
+
+def test_probe_table_depths_and_reference_walk_agree(ctx, orc, monkeypatch):
+    """Every probe-table depth K and the reference walk give the same counts."""
+    import andi_amd
+    from andi_amd import synth
+    rng = np.random.default_rng(91)
+    base = synth.base_codes(30000, 3)
+    seqs = [synth.to_bytes(base), synth.to_bytes(synth.mutate_codes(base, 0.06, 4)),
+            synth.join_contigs(synth.to_bytes(synth.mutate_codes(base, 0.02, 5)), 9, seed=4),
+            rand_dna(rng, 9000, b"AC"), rand_dna(rng, 500) * 30]
+    want = orc.dist_matrix(seqs, threads=4)
+    for K in ("4", "5", "7", "9", "11", "13"):
+        monkeypatch.setenv("ANDI_DEEP_K", K)
+        got, t = _gpu_rows(ctx, seqs, segment=700)
+        assert (got == want).all(), K
+    monkeypatch.delenv("ANDI_DEEP_K")
+    monkeypatch.setenv("ANDI_FORCE_REFERENCE", "1")
+    ctx.timings_reset()
+    got, t = _gpu_rows(ctx, seqs, segment=700)
+    assert (got == want).all() and t["reference_subjects"] == len(seqs)
 
 
 def test_repeats_and_models(ctx, orc):
