@@ -308,8 +308,7 @@ __device__ __forceinline__ Ival esa_match_cached(const EsaG &E, g_u8p q, uint32_
 
 // 2-bit code of the first K (<= 16) characters of q, first character most
 // significant; false if one of them is not ACGT.  Reads 16 bytes.
-__device__ __forceinline__ bool kmer_code(g_u8p q, int K, uint32_t &code) {
-	uint4 w = ld_u128_unaligned(q);
+__device__ __forceinline__ bool kmer_code_from(uint4 w, int K, uint32_t &code) {
 	auto pack4 = [](uint32_t v) {
 		uint32_t x = v & 0x06060606u;
 		x ^= x >> 1;
@@ -326,6 +325,10 @@ __device__ __forceinline__ bool kmer_code(g_u8p q, int K, uint32_t &code) {
 	uint32_t c32 = (pack4(w.x) << 24) | (pack4(w.y) << 16) | (pack4(w.z) << 8) | pack4(w.w);
 	code = c32 >> (32 - 2 * K);
 	return ok;
+}
+
+__device__ __forceinline__ bool kmer_code(g_u8p q, int K, uint32_t &code) {
+	return kmer_code_from(ld_u128_unaligned(q), K, code);
 }
 
 // What dist_anchor needs from get_match_cached (src/process.c:113-123): the

@@ -297,7 +297,7 @@ int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, siz
 	const size_t deep_entries = (size_t)1 << (2 * e->deepK);
 	chk(dmalloc(&e->S, n + 1 + ANDI_PAD));
 	chk(dmalloc(&e->SA, n));
-	chk(dmalloc(&e->deep, deep_entries));
+	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
 	chk(dmalloc(&e->rec, n));
 	chk(dmalloc(&e->flags, 4));
 	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault));
@@ -564,6 +564,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	auto *h_esa = (EsaDev *)ctx->desc_host;
 	auto *h_self = (int64_t *)(h_esa + nsub);
 	uint64_t pairs = 0, nt = 0;
+	int any_reference = 0;
 	// the index builds must have finished: their flags decide which walk is exact
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	for (size_t s = 0; s < nsub; ++s) {
@@ -579,6 +580,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			mode = ANDI_MODE_REFERENCE;
 			if (!e->ref_built && andi_hip_esa_build(ctx, e)) return 1;
 			ctx->acc.reference_subjects++;
+			any_reference = 1;
 		}
 		h_esa[s] = esa_view(e, mode);
 		h_self[s] = self ? self[s] : -1;
@@ -619,6 +621,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.owned = (uint32_t *)p;
 	a.M = M_dev;
 	a.fixups = ctx->d_fixups;
+	a.any_reference = any_reference;
+	a.force_blocking = getenv("ANDI_SCAN_BLOCKING") ? 1 : 0;
 
 	{
 		Timed t(ctx, 1);
