@@ -39,7 +39,7 @@ struct ScanArgs {
 	andi_hip_model *M;     // [nsub][nq]
 	unsigned long long *fixups;
 	int any_reference;  // some subject is in ANDI_MODE_REFERENCE
-	int force_blocking; // ANDI_SCAN_BLOCKING=1: run every subject through the blocking pass A
+	int use_lanes;      // ANDI_SCAN_LANES=1: lane-per-chain pass A for probe-table subjects
 };
 
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st);

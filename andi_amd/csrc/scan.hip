@@ -94,9 +94,88 @@ __device__ __forceinline__ void count_gap(uint32_t *hist, g_u8p s, g_u8p q,
 	}
 }
 
+// A chain spends most of its steps on one diagonal (query offset p against
+// subject offset p + d), advancing ~1/divergence bytes per step.  Window keeps
+// the 16*G bytes of both strings that the group fetched last, plus a bitmask of
+// the positions where they differ, in registers: the following lucky
+// comparisons and gap counts on that diagonal are answered from it without
+// touching memory, so each 16*G-byte line of Q and S is fetched once.
+template <int G>
+struct Window {
+	uint32_t q0, s0; // offsets of byte 0; q0 == ~0u: empty
+	uint4 qb, sb;    // this lane's bytes [16*sub, 16*sub + 16) of the window
+	uint32_t diff;   // bit t: this lane's byte t differs
+};
+
+__device__ __forceinline__ uint32_t diff_bits4(uint32_t x) { // one bit per non-zero byte
+	x |= x >> 4;
+	x |= x >> 2;
+	x |= x >> 1;
+	x &= 0x01010101u;
+	return (x * 0x08040201u) >> 24 & 0xfu;
+}
+
+template <int G>
+__device__ __forceinline__ void window_load(Window<G> &w, g_u8p Q, g_u8p S, uint32_t q0, uint32_t s0) {
+	const uint32_t sub = Group<G>::sub();
+	w.q0 = q0, w.s0 = s0;
+	w.qb = ld_u128_unaligned(Q + q0 + 16 * sub);
+	w.sb = ld_u128_unaligned(S + s0 + 16 * sub);
+	w.diff = diff_bits4(w.qb.x ^ w.sb.x) | (diff_bits4(w.qb.y ^ w.sb.y) << 4) |
+			 (diff_bits4(w.qb.z ^ w.sb.z) << 8) | (diff_bits4(w.qb.w ^ w.sb.w) << 12);
+}
+
+// lcp(Q + p, S + t, maxlen) (src/process.c:59-65) through the window
+template <int G>
+__device__ __forceinline__ uint32_t window_lcp(Window<G> &w, g_u8p Q, g_u8p S, uint32_t p, uint32_t t,
+											   uint32_t maxlen) {
+	const uint32_t sub = Group<G>::sub();
+	uint32_t len = 0;
+	for (;;) {
+		uint32_t o = p + len - w.q0; // offset into the window, if it applies
+		if (w.q0 == ~0u || t - p != w.s0 - w.q0 || p + len < w.q0 || o >= 16 * G) {
+			window_load(w, Q, S, p + len, t + len);
+			o = 0;
+		}
+		// first differing byte at or after o
+		int sh = (int)o - (int)(16 * sub);
+		uint32_t m = sh <= 0 ? w.diff : (sh >= 16 ? 0u : (w.diff >> sh) << sh);
+		uint64_t hit = Group<G>::slice(__ballot(m != 0));
+		if (hit) {
+			uint32_t first = (uint32_t)__builtin_ctzll(hit);
+			uint32_t bit = (uint32_t)__shfl((int)__builtin_ctz(m | 0x10000u), (int)(Group<G>::base() + first));
+			len += 16 * first + bit - o;
+			break;
+		}
+		len += 16 * G - o;
+		if (len >= maxlen) break;
+	}
+	return len < maxlen ? len : maxlen;
+}
+
+// model_count through the window when it covers Q[q..q+len) on its diagonal
+template <int G>
+__device__ __forceinline__ void window_count_gap(const Window<G> &w, uint32_t *hist, g_u8p Q, g_u8p S,
+												 uint32_t q, uint32_t s, uint32_t len) {
+	if (w.q0 != ~0u && s - q == w.s0 - w.q0 && q >= w.q0 && q + len <= w.q0 + 16 * G) {
+		const uint32_t lo = q - w.q0, hi = lo + len, mine = 16 * Group<G>::sub();
+		uint32_t a = lo > mine ? lo - mine : 0, b = hi > mine ? (hi - mine < 16 ? hi - mine : 16) : 0;
+		for (uint32_t t = a; t < b; ++t) {
+			uint32_t wq = t < 8 ? (t < 4 ? w.qb.x : w.qb.y) : (t < 12 ? w.qb.z : w.qb.w);
+			uint32_t ws = t < 8 ? (t < 4 ? w.sb.x : w.sb.y) : (t < 12 ? w.sb.z : w.sb.w);
+			int8_t cq = (int8_t)(wq >> (8 * (t & 3))), cs = (int8_t)(ws >> (8 * (t & 3)));
+			if (cs >= 'A' && cq >= 'A')
+				atomicAdd(&hist[(nt_code((uint8_t)cs) << 2) + nt_code((uint8_t)cq)], 1u);
+		}
+	} else {
+		count_gap<G>(hist, S + s, Q + q, len);
+	}
+}
+
 // One trip of the while loop, src/process.c:153-197.  Uniform within the group.
 template <int G>
-__device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st, uint32_t *hist) {
+__device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st, uint32_t *hist,
+												 Window<G> &w) {
 	const uint32_t n = (uint32_t)c.E.n;
 	uint32_t curS = 0, curLen = 0;
 	bool found = false;
@@ -107,7 +186,7 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 	uint32_t tryS = st.lastS + advance;
 	if (tryS < n && gap <= c.thr) {
 		curS = tryS;
-		curLen = common_prefix<G>(c.Q + st.p, c.E.S + tryS, c.qlen - st.p);
+		curLen = window_lcp<G>(w, c.Q, c.E.S, st.p, tryS, c.qlen - st.p);
 		found = curLen >= c.thr;
 	}
 	// anchor, src/process.c:113-123
@@ -124,7 +203,7 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 		if (curS > endS && st.p - endQ == curS - endS &&
 			(curS < c.border) == (st.lastS < c.border)) {
 			count_equal<G>(hist, st.lastLen);
-			count_gap<G>(hist, c.E.S + endS, c.Q + endQ, st.p - endQ);
+			window_count_gap<G>(w, hist, c.Q, c.E.S, endQ, endS, st.p - endQ);
 			st.lwra = 1;
 		} else {
 			if (st.lwra || st.lastLen >= 2 * c.thr) count_equal<G>(hist, st.lastLen);
@@ -184,9 +263,9 @@ __device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {
 // one starts.  Kept for the reference walk (flagged subjects) and as the
 // readable statement of what the round-based kernel below computes.
 template <int G>
-__global__ __launch_bounds__(BLOCK) void k_scan_cold_blocking(ScanArgs a) {
+__global__ __launch_bounds__(BLOCK, 8) void k_scan_cold_blocking(ScanArgs a) {
 	__shared__ uint32_t s_hist[BLOCK / G][16];
-	if (a.subjects[blockIdx.y].mode != ANDI_MODE_REFERENCE && !a.force_blocking) return;
+	if (a.subjects[blockIdx.y].mode != ANDI_MODE_REFERENCE && a.use_lanes) return; // k_scan_cold took it
 	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
 	uint32_t *hist = s_hist[threadIdx.x / G];
@@ -194,7 +273,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan_cold_blocking(ScanArgs a) {
 
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
 	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, (uint32_t)c.E.n);
-	while (st.p < it.end) st = chain_step<G>(c, st, hist);
+	Window<G> w;
+	w.q0 = ~0u;
+	while (st.p < it.end) st = chain_step<G>(c, st, hist, w);
 
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
 	uint32_t lane = Group<G>::sub();
@@ -431,6 +512,8 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 	hist_zero<G>(histT);
 	hist_zero<G>(histC);
 	ChainState C = cold_state(start, (uint32_t)c.E.n);
+	Window<G> w; // shared by both chains: they run next to each other
+	w.q0 = ~0u;
 	bool synced = false;
 	for (;;) {
 		if (same_state(T, C)) {
@@ -439,9 +522,9 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 		}
 		if (T.p >= end) break;
 		if (C.p >= end || T.p <= C.p) {
-			T = chain_step<G>(c, T, histT);
+			T = chain_step<G>(c, T, histT, w);
 		} else {
-			C = chain_step<G>(c, C, histC);
+			C = chain_step<G>(c, C, histC, w);
 		}
 	}
 	if (synced) {
@@ -575,12 +658,12 @@ template <int G>
 static hipError_t launch_cold(const ScanArgs &a, hipStream_t st) {
 	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	if (!a.force_blocking) {
+	if (a.use_lanes) { // experimental lane-per-chain form, probe-table subjects only
 		dim3 lane_grid((a.total_segs + BLOCK - 1) / BLOCK, a.nsub);
 		k_scan_cold<<<lane_grid, BLOCK, 0, st>>>(a);
 		CHECK_LAUNCH();
 	}
-	if (a.any_reference || a.force_blocking) { // subjects that need the reference's own walk
+	if (a.any_reference || !a.use_lanes) {
 		k_scan_cold_blocking<G><<<grid, BLOCK, 0, st>>>(a);
 		CHECK_LAUNCH();
 	}
