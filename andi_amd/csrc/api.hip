@@ -622,7 +622,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.M = M_dev;
 	a.fixups = ctx->d_fixups;
 	a.any_reference = any_reference;
-	a.use_lanes = getenv("ANDI_SCAN_LANES") ? 1 : 0;
+	a.use_lanes = getenv("ANDI_SCAN_BLOCKING") ? 0 : 1;
 
 	{
 		Timed t(ctx, 1);

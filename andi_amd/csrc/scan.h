@@ -39,7 +39,7 @@ struct ScanArgs {
 	andi_hip_model *M;     // [nsub][nq]
 	unsigned long long *fixups;
 	int any_reference;  // some subject is in ANDI_MODE_REFERENCE
-	int use_lanes;      // ANDI_SCAN_LANES=1: lane-per-chain pass A for probe-table subjects
+	int use_lanes;      // round-based pass A for probe-table subjects (ANDI_SCAN_BLOCKING=1 turns it off)
 };
 
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st);

@@ -112,7 +112,7 @@ __device__ __forceinline__ uint32_t diff_bits4(uint32_t x) { // one bit per non-
 	x |= x >> 2;
 	x |= x >> 1;
 	x &= 0x01010101u;
-	return (x * 0x08040201u) >> 24 & 0xfu;
+	return ((x * 0x01020408u) >> 24) & 0xfu;
 }
 
 template <int G>
@@ -283,57 +283,73 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold_blocking(ScanArgs a) {
 	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = hist[t];
 }
 
-// Round-based form, one lane per chain.  A chain step is a short sequence of
-// dependent memory accesses (16-byte compare windows, one probe-table entry,
-// the gap bytes) with little arithmetic in between.  Every lane runs its own
-// chain as a small state machine, and the wavefront executes "rounds": each lane
-// forms the two addresses its chain needs next, ONE pair of 16-byte loads
-// serves all 64 chains whatever point of the step they are at, then one pass
-// over the state machine consumes the data and moves every chain to its next
-// memory need.  Throughput is set by the number of chains in flight (64 per
-// wavefront) instead of by the latency of one chain's accesses.  Semantics are
-// exactly those of chain_step() in ANDI_MODE_PROBE.
+// ------------------------------------------------------------------ pass A, round-based
+// In the blocking form above the 64/G chains of a wavefront move in lock-step:
+// every step costs the latency of the slowest chain's dependent accesses (probe
+// table, then the occurrence(s) of the K-mer).  Here each chain is a small
+// state machine and the wavefront executes "rounds": every lane forms the two
+// addresses its chain needs next, ONE pair of 16-byte loads serves all chains
+// whatever point of their step they are at, the chains consume their data and
+// then run on -- typically through several steps, because lucky comparisons
+// and gap counts are answered from the chain's register window -- until each
+// needs memory again.  Semantics are exactly those of chain_step() in
+// ANDI_MODE_PROBE.
 enum : uint32_t {
 	PH_DONE = 0,
 	// phases that wait for the round's loads
-	PH_CMP,   // compare two byte streams, 16 bytes per round (kind: CK_*)
-	PH_KMER,  // fetch the K-mer at Q[p]
-	PH_TABLE, // fetch the probe-table entry
-	PH_MSA,   // K-mer occurs several times: fetch the next occurrence's position
-	PH_GAP,   // count substitutions between two anchors      (src/model.c:309-337)
-	// compute-only transitions, handled in this order within a round
+	PH_WIN,    // refill the register window at (w.q0, w.s0)
+	PH_TABLE,  // fetch the probe-table entry
+	PH_SINGLE, // extend along the one suffix that has the K-mer
+	PH_MSA,    // K-mer occurs several times: fetch their positions, one per lane
+	PH_MCMP,   // ... and extend along each of them, one per lane
+	PH_KMER,   // fetch Q[p..p+16) (K-mer not inside the window)
+	PH_GAP,    // count a gap the window does not cover         (src/model.c:309-337)
+	PH_LAST_MEM = PH_GAP,
+	// compute-only phases
 	PH_DECIDE,  // have (curS, curLen, unique)
 	PH_FOUND,   // src/process.c:158-193
 	PH_ADVANCE, // src/process.c:196
 	PH_STEP,    // top of the while loop                        (src/process.c:153)
+	PH_LUCKY,   // lucky comparison through the window          (src/process.c:93-97)
 	PH_PROBE    // lucky failed or was not tried                (src/process.c:113-123)
 };
-enum : uint32_t {
-	CK_LUCKY = 0, // Q[p..] against S[try..]                     (src/process.c:93-97)
-	CK_SINGLE,    // extension along the one suffix that has the K-mer
-	CK_MULTI      // extension along one of several suffixes that have it
-};
 
-// rare path (remainder shorter than K, separator in the K-mer): whole-array
+// rare path (remainder not longer than K, separator in the K-mer): whole-array
 // search, out of line so it does not inflate the kernel's register allocation
 __device__ __noinline__ Probe search_out_of_line(const EsaG &E, g_u8p q, uint32_t qlen) {
 	return sa_range_match<1>(E, q, qlen, 0, E.n - 1, 0);
 }
 
+// 2-bit codes (first byte in the top bits) and ACGT mask of 16 bytes
+__device__ __forceinline__ void codes16(uint4 v, uint32_t &code, uint32_t &valid) {
+	auto pack4 = [](uint32_t x) {
+		x &= 0x06060606u;
+		x ^= x >> 1;
+		x = (x >> 1) & 0x03030303u;
+		return ((x & 0xffu) << 6) | (((x >> 8) & 0xffu) << 4) | (((x >> 16) & 0xffu) << 2) | (x >> 24);
+	};
+	auto ok4 = [](uint32_t x) { // bit t set <=> byte t >= 'A' (bit 6)
+		x = (x >> 6) & 0x01010101u;
+		return ((x * 0x01020408u) >> 24) & 0xfu;
+	};
+	code = (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
+	valid = ok4(v.x) | (ok4(v.y) << 4) | (ok4(v.z) << 8) | (ok4(v.w) << 12);
+}
+
+template <int G>
 __global__ __launch_bounds__(BLOCK, 6) void k_scan_cold(ScanArgs a) {
-	// per-lane 4x4 substitution counters, counter-major so that the lanes of a
-	// wavefront always hit distinct banks
-	__shared__ uint32_t s_hist[16][BLOCK];
+	__shared__ uint32_t s_hist[BLOCK / G][16];
 	if (a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return; // see k_scan_cold_blocking
-	WorkItem it = decode_item<1>(a);
+	WorkItem it = decode_item<G>(a);
 	const bool work = it.valid && !it.is_self;
-	const uint32_t tid = threadIdx.x;
-#pragma unroll
-	for (int t = 0; t < 16; ++t) s_hist[t][tid] = 0;
+	uint32_t *hist = s_hist[threadIdx.x / G];
+	hist_zero<G>(hist);
 
 	// subject data is uniform for the block; query data is per chain
 	const EsaG E = esa_global(a.subjects[blockIdx.y]);
 	const uint32_t n = (uint32_t)E.n, thr = (uint32_t)E.thr, border = n / 2, K = (uint32_t)E.deepK;
+	const uint32_t sub = Group<G>::sub(), gbase = Group<G>::base();
+	constexpr uint32_t W = 16 * G; // window bytes
 	g_u8p Q = (g_u8p)a.qpool;
 	uint32_t qlen = 0;
 	if (work) {
@@ -343,65 +359,50 @@ __global__ __launch_bounds__(BLOCK, 6) void k_scan_cold(ScanArgs a) {
 
 	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, n);
 	uint32_t phase = (work && st.p < it.end) ? (uint32_t)PH_STEP : (uint32_t)PH_DONE;
-	uint32_t cmpKind = CK_LUCKY, cmpA = 0, cmpB = 0, cmpDone = 0, cmpMax = 0; // compare / gap cursor
+	// register window: this lane's 16 bytes of Q and S as 2-bit codes, ACGT masks, differing bytes
+	uint32_t wq0 = ~0u, ws0 = 0, wqc = 0, wsc = 0, wmask = 0; // wmask: diff | qvalid << 16; svalid in wsv
+	uint32_t wsv = 0;
+	uint32_t lkLen = 0, lkT = 0;                               // lucky comparison in progress
+	uint32_t cmpA = 0, cmpB = 0, cmpDone = 0, cmpMax = 0;      // PH_SINGLE / PH_GAP cursor
 	uint32_t curS = 0, curLen = 0, kcode = 0;
-	uint32_t mIdx = 0, mEnd = 0, bestLen = 0, bestCnt = 0, bestPos = 0; // several occurrences
-	uint32_t eqQuarter = 0, eqRest = 0; // model_count_equal, src/model.c:247-253
-	bool unique = false, khave = false, kvalid = false;
-	uint4 qhead = make_uint4(0, 0, 0, 0); // Q[p..p+16) when the lucky compare fetched it
+	uint32_t mlo = 0, mcnt = 0, moff = 0, bestLen = 0, bestCnt = 0, bestPos = 0; // several occurrences
+	uint32_t myPos = 0, myDone = 0, myLen = 0;                                    // ... this lane's candidate
+	bool unique = false, myFin = true;
 
 	while (__any(phase != PH_DONE)) {
-		// ---- one round of loads for every chain
+		// ---- one round of loads
 		g_u8p pa = Q, pb = E.S; // harmless addresses for chains that need nothing
-		if (phase == PH_CMP || phase == PH_GAP) {
-			pa = Q + cmpA + cmpDone;
-			pb = E.S + cmpB + cmpDone;
-		} else if (phase == PH_KMER) {
-			pa = Q + st.p;
+		if (phase == PH_WIN) {
+			pa = Q + wq0 + 16 * sub;
+			pb = E.S + ws0 + 16 * sub;
+		} else if (phase == PH_SINGLE || phase == PH_GAP) {
+			pa = Q + cmpA + cmpDone + 16 * sub;
+			pb = E.S + cmpB + cmpDone + 16 * sub;
 		} else if (phase == PH_TABLE) {
 			pa = (g_u8p)(E.deep + kcode);
 		} else if (phase == PH_MSA) {
-			pa = (g_u8p)(E.SA + mIdx);
+			if (moff + sub < mcnt) pa = (g_u8p)(E.SA + mlo + moff + sub);
+		} else if (phase == PH_MCMP) {
+			if (!myFin) {
+				pa = Q + st.p + K + myDone;
+				pb = E.S + myPos + K + myDone;
+			}
+		} else if (phase == PH_KMER) {
+			pa = Q + st.p;
 		}
 		const uint4 da = ld_u128_unaligned(pa);
 		const uint4 db = ld_u128_unaligned(pb);
 
-		// ---- one pass over the state machine
-		if (phase == PH_CMP) {
-			uint4 x = make_uint4(da.x ^ db.x, da.y ^ db.y, da.z ^ db.z, da.w ^ db.w);
-			uint32_t f = first_diff_byte(x);
-			if (cmpKind == CK_LUCKY && cmpDone == 0) qhead = da, khave = true, kvalid = false;
-			uint32_t len = cmpDone + f;
-			if (f < 16 || len >= cmpMax) {
-				if (len > cmpMax) len = cmpMax;
-				if (cmpKind == CK_LUCKY) {
-					curS = cmpB, curLen = len, unique = true;
-					phase = len >= thr ? (uint32_t)PH_FOUND : (uint32_t)PH_PROBE;
-				} else if (cmpKind == CK_SINGLE) {
-					curLen = K + len; // curS, unique set by PH_TABLE
-					phase = PH_DECIDE;
-				} else {
-					// The longest match is the best of the occurrences' own common
-					// prefixes with the query; it is unique iff exactly one attains it.
-					uint32_t l = K + len;
-					if (bestCnt == 0 || l > bestLen) {
-						bestLen = l, bestCnt = 1, bestPos = cmpB - K;
-					} else if (l == bestLen) {
-						++bestCnt;
-					}
-					if (++mIdx <= mEnd) {
-						phase = PH_MSA;
-					} else {
-						curLen = bestLen, curS = bestPos, unique = bestCnt == 1;
-						phase = PH_DECIDE;
-					}
-				}
-			} else {
-				cmpDone += 16;
-			}
-		} else if (phase == PH_KMER) {
-			qhead = da, khave = true;
-			phase = PH_PROBE;
+		// ---- consume
+		if (phase == PH_WIN) {
+			uint32_t qv, sv;
+			codes16(da, wqc, qv);
+			codes16(db, wsc, sv);
+			uint32_t diff = diff_bits4(da.x ^ db.x) | (diff_bits4(da.y ^ db.y) << 4) |
+							(diff_bits4(da.z ^ db.z) << 8) | (diff_bits4(da.w ^ db.w) << 12);
+			wmask = diff | (qv << 16);
+			wsv = sv;
+			phase = PH_LUCKY;
 		} else if (phase == PH_TABLE) {
 			uint32_t x = da.x, y = da.y, kind = y & 3u;
 			if (kind == DEEP_FINAL) {
@@ -410,10 +411,10 @@ __global__ __launch_bounds__(BLOCK, 6) void k_scan_cold(ScanArgs a) {
 				phase = PH_DECIDE;
 			} else if (kind == DEEP_SINGLE) {
 				curS = x, unique = true;
-				cmpKind = CK_SINGLE, cmpA = st.p + K, cmpB = x + K, cmpDone = 0, cmpMax = qlen - st.p - K;
-				phase = PH_CMP;
+				cmpA = st.p + K, cmpB = x + K, cmpDone = 0, cmpMax = qlen - st.p - K;
+				phase = PH_SINGLE;
 			} else if (kind == DEEP_MULTI) {
-				mIdx = x, mEnd = x + (y >> 8);
+				mlo = x, mcnt = (y >> 8) + 1, moff = 0;
 				bestLen = 0, bestCnt = 0, bestPos = 0;
 				phase = PH_MSA;
 			} else { // DEEP_SEARCH
@@ -421,20 +422,87 @@ __global__ __launch_bounds__(BLOCK, 6) void k_scan_cold(ScanArgs a) {
 				curS = pr.pos, curLen = pr.len, unique = pr.unique;
 				phase = PH_DECIDE;
 			}
-		} else if (phase == PH_MSA) { // da.x = SA[mIdx]
-			cmpKind = CK_MULTI, cmpA = st.p + K, cmpB = da.x + K, cmpDone = 0, cmpMax = qlen - st.p - K;
-			phase = PH_CMP;
+		} else if (phase == PH_SINGLE) {
+			uint4 x = make_uint4(da.x ^ db.x, da.y ^ db.y, da.z ^ db.z, da.w ^ db.w);
+			uint32_t f = first_diff_byte(x);
+			uint64_t hit = Group<G>::slice(__ballot(f < 16));
+			if (hit) {
+				uint32_t first = (uint32_t)__builtin_ctzll(hit);
+				uint32_t len = cmpDone + 16 * first + (uint32_t)__shfl((int)f, (int)(gbase + first));
+				curLen = K + (len < cmpMax ? len : cmpMax);
+				phase = PH_DECIDE;
+			} else {
+				cmpDone += W;
+				if (cmpDone >= cmpMax) {
+					curLen = K + cmpMax;
+					phase = PH_DECIDE;
+				}
+			}
+		} else if (phase == PH_MSA) { // da.x = SA[mlo + moff + sub] for the lanes that have a candidate
+			myFin = moff + sub >= mcnt;
+			myPos = da.x, myDone = 0, myLen = 0;
+			phase = PH_MCMP;
+		} else if (phase == PH_MCMP) {
+			// The longest match is the best of the candidates' own common prefixes
+			// with the query; it is unique iff exactly one attains it.
+			const uint32_t qrem = qlen - st.p;
+			if (!myFin) {
+				uint4 x = make_uint4(da.x ^ db.x, da.y ^ db.y, da.z ^ db.z, da.w ^ db.w);
+				uint32_t f = first_diff_byte(x);
+				uint32_t l = K + myDone + f;
+				if (f < 16 || l >= qrem) {
+					myLen = l < qrem ? l : qrem;
+					myFin = true;
+				} else {
+					myDone += 16;
+				}
+			}
+			if (Group<G>::slice(__ballot(!myFin)) == 0) {
+				bool mine = moff + sub < mcnt;
+				uint32_t best = mine ? myLen : 0u;
+				for (int o = G / 2; o; o >>= 1) {
+					uint32_t other = (uint32_t)__shfl_xor((int)best, o);
+					best = other > best ? other : best;
+				}
+				uint64_t who = Group<G>::slice(__ballot(mine && myLen == best));
+				uint32_t cnt = (uint32_t)__builtin_popcountll(who);
+				uint32_t pos = (uint32_t)__shfl((int)myPos, (int)(gbase + (uint32_t)__builtin_ctzll(who)));
+				if (best > bestLen || bestCnt == 0) {
+					bestLen = best, bestCnt = cnt, bestPos = pos;
+				} else if (best == bestLen) {
+					bestCnt += cnt;
+				}
+				moff += G;
+				if (moff < mcnt) {
+					phase = PH_MSA;
+				} else {
+					curLen = bestLen, curS = bestPos, unique = bestCnt == 1;
+					phase = PH_DECIDE;
+				}
+			}
+		} else if (phase == PH_KMER) {
+			uint32_t code, valid;
+			codes16(da, code, valid);
+			if ((valid & ((1u << K) - 1u)) == ((1u << K) - 1u)) {
+				kcode = code >> (32 - 2 * K);
+				phase = PH_TABLE;
+			} else {
+				Probe pr = search_out_of_line(E, Q + st.p, qlen - st.p);
+				curS = pr.pos, curLen = pr.len, unique = pr.unique;
+				phase = PH_DECIDE;
+			}
 		} else if (phase == PH_GAP) {
-			// this round holds gap bytes [cmpDone, cmpDone + 16) of both strings
-			uint32_t cnt = cmpMax - cmpDone < 16 ? cmpMax - cmpDone : 16;
+			uint32_t off = cmpDone + 16 * sub;
+			uint32_t cnt = off < cmpMax ? (cmpMax - off < 16 ? cmpMax - off : 16) : 0;
 			for (uint32_t t = 0; t < cnt; ++t) {
 				uint32_t wq = t < 8 ? (t < 4 ? da.x : da.y) : (t < 12 ? da.z : da.w);
 				uint32_t ws = t < 8 ? (t < 4 ? db.x : db.y) : (t < 12 ? db.z : db.w);
 				int8_t q = (int8_t)(wq >> (8 * (t & 3)));
 				int8_t s = (int8_t)(ws >> (8 * (t & 3)));
-				if (s >= 'A' && q >= 'A') s_hist[(nt_code((uint8_t)s) << 2) + nt_code((uint8_t)q)][tid] += 1;
+				if (s >= 'A' && q >= 'A')
+					atomicAdd(&hist[(nt_code((uint8_t)s) << 2) + nt_code((uint8_t)q)], 1u);
 			}
-			cmpDone += 16;
+			cmpDone += W;
 			if (cmpDone >= cmpMax) {
 				st.lwra = 1;
 				st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
@@ -442,49 +510,106 @@ __global__ __launch_bounds__(BLOCK, 6) void k_scan_cold(ScanArgs a) {
 			}
 		}
 
-		if (phase == PH_DECIDE) phase = (unique && curLen >= thr) ? (uint32_t)PH_FOUND : (uint32_t)PH_ADVANCE;
-		if (phase == PH_FOUND) {
-			uint32_t endS = st.lastS + st.lastLen;
-			uint32_t endQ = st.lastQ + st.lastLen;
-			if (curS > endS && st.p - endQ == curS - endS && (curS < border) == (st.lastS < border)) {
-				eqQuarter += st.lastLen >> 2, eqRest += st.lastLen & 3u;
-				cmpA = endQ, cmpB = endS, cmpDone = 0, cmpMax = st.p - endQ;
-				phase = PH_GAP;
-			} else {
-				if (st.lwra || st.lastLen >= 2 * thr) eqQuarter += st.lastLen >> 2, eqRest += st.lastLen & 3u;
-				st.lwra = 0;
-				st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
-				phase = PH_ADVANCE;
+		// ---- run on until every chain needs memory
+		while (__any(phase > PH_LAST_MEM)) {
+			if (phase == PH_DECIDE) phase = (unique && curLen >= thr) ? (uint32_t)PH_FOUND : (uint32_t)PH_ADVANCE;
+			if (phase == PH_FOUND) {
+				uint32_t endS = st.lastS + st.lastLen;
+				uint32_t endQ = st.lastQ + st.lastLen;
+				if (curS > endS && st.p - endQ == curS - endS && (curS < border) == (st.lastS < border)) {
+					count_equal<G>(hist, st.lastLen);
+					uint32_t glen = st.p - endQ;
+					if (wq0 != ~0u && endS - endQ == ws0 - wq0 && endQ >= wq0 && endQ + glen <= wq0 + W) {
+						// the window holds the gap: count from its 2-bit codes
+						uint32_t lo = endQ - wq0, hi = lo + glen, mine = 16 * sub;
+						uint32_t ta = lo > mine ? lo - mine : 0, tb = hi > mine ? (hi - mine < 16 ? hi - mine : 16) : 0;
+						uint32_t both = (wmask >> 16) & wsv;
+						for (uint32_t t = ta; t < tb; ++t)
+							if ((both >> t) & 1u)
+								atomicAdd(&hist[(((wsc >> (30 - 2 * t)) & 3u) << 2) | ((wqc >> (30 - 2 * t)) & 3u)], 1u);
+						st.lwra = 1;
+						st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
+						phase = PH_ADVANCE;
+					} else {
+						cmpA = endQ, cmpB = endS, cmpDone = 0, cmpMax = glen;
+						phase = PH_GAP;
+					}
+				} else {
+					if (st.lwra || st.lastLen >= 2 * thr) count_equal<G>(hist, st.lastLen);
+					st.lwra = 0;
+					st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
+					phase = PH_ADVANCE;
+				}
 			}
-		}
-		if (phase == PH_ADVANCE) {
-			st.p += curLen + 1;
-			phase = st.p < it.end ? (uint32_t)PH_STEP : (uint32_t)PH_DONE;
-		}
-		if (phase == PH_STEP) {
-			uint32_t advance = st.p - st.lastQ;
-			uint32_t gap = advance - st.lastLen;
-			uint32_t tryS = st.lastS + advance;
-			khave = false;
-			if (tryS < n && gap <= thr) {
-				cmpKind = CK_LUCKY, cmpA = st.p, cmpB = tryS, cmpDone = 0, cmpMax = qlen - st.p;
-				phase = PH_CMP;
-			} else {
-				phase = PH_PROBE;
+			if (phase == PH_ADVANCE) {
+				st.p += curLen + 1;
+				phase = st.p < it.end ? (uint32_t)PH_STEP : (uint32_t)PH_DONE;
 			}
-		}
-		if (phase == PH_PROBE) {
-			uint32_t qrem = qlen - st.p;
-			if (qrem > K && !khave) {
-				phase = PH_KMER;
-			} else {
-				if (qrem > K) kvalid = kmer_code_from(qhead, (int)K, kcode);
-				if (qrem > K && kvalid) {
-					phase = PH_TABLE;
-				} else { // rare: resolved now, consumed by PH_DECIDE in the next round
-					Probe pr = search_out_of_line(E, Q + st.p, qrem);
+			if (phase == PH_STEP) {
+				uint32_t advance = st.p - st.lastQ;
+				uint32_t gap = advance - st.lastLen;
+				uint32_t tryS = st.lastS + advance;
+				if (tryS < n && gap <= thr) {
+					lkLen = 0, lkT = tryS;
+					phase = PH_LUCKY;
+				} else {
+					phase = PH_PROBE;
+				}
+			}
+			if (phase == PH_LUCKY) {
+				const uint32_t maxlen = qlen - st.p;
+				uint32_t pos = st.p + lkLen, o = pos - wq0;
+				if (wq0 == ~0u || lkT - st.p != ws0 - wq0 || pos < wq0 || o >= W) {
+					wq0 = pos, ws0 = lkT + lkLen;
+					phase = PH_WIN;
+				} else {
+					int sh = (int)o - (int)(16 * sub);
+					uint32_t d = wmask & 0xffffu;
+					uint32_t m = sh <= 0 ? d : (sh >= 16 ? 0u : (d >> sh) << sh);
+					uint64_t hit = Group<G>::slice(__ballot(m != 0));
+					bool finished = true;
+					if (hit) {
+						uint32_t first = (uint32_t)__builtin_ctzll(hit);
+						uint32_t bit = (uint32_t)__shfl((int)__builtin_ctz(m | 0x10000u), (int)(gbase + first));
+						lkLen += 16 * first + bit - o;
+					} else {
+						lkLen += W - o;
+						finished = lkLen >= maxlen;
+						if (!finished) { // ran off the window: fetch the next one
+							wq0 = st.p + lkLen, ws0 = lkT + lkLen;
+							phase = PH_WIN;
+						}
+					}
+					if (finished) {
+						curS = lkT, curLen = lkLen < maxlen ? lkLen : maxlen, unique = true;
+						phase = curLen >= thr ? (uint32_t)PH_FOUND : (uint32_t)PH_PROBE;
+					}
+				}
+			}
+			if (phase == PH_PROBE) {
+				uint32_t qrem = qlen - st.p;
+				uint32_t o = st.p - wq0;
+				if (qrem <= K) {
+					Probe pr = search_out_of_line(E, Q + st.p, qrem); // rare
 					curS = pr.pos, curLen = pr.len, unique = pr.unique;
 					phase = PH_DECIDE;
+				} else if (wq0 != ~0u && st.p >= wq0 && o + 16 <= W) {
+					// the K-mer's 16 bytes sit in the window, across lanes o/16 and o/16 + 1
+					uint32_t l0 = gbase + (o >> 4), r = o & 15u;
+					uint32_t c0 = (uint32_t)__shfl((int)wqc, (int)l0), c1 = (uint32_t)__shfl((int)wqc, (int)(l0 + 1));
+					uint32_t v0 = (uint32_t)__shfl((int)wmask, (int)l0) >> 16, v1 = (uint32_t)__shfl((int)wmask, (int)(l0 + 1)) >> 16;
+					uint32_t code = r ? ((c0 << (2 * r)) | (c1 >> (32 - 2 * r))) : c0;
+					uint32_t valid = r ? ((v0 >> r) | (v1 << (16 - r))) : v0;
+					if ((valid & ((1u << K) - 1u)) == ((1u << K) - 1u)) {
+						kcode = code >> (32 - 2 * K);
+						phase = PH_TABLE;
+					} else {
+						Probe pr = search_out_of_line(E, Q + st.p, qrem); // separator in the K-mer
+						curS = pr.pos, curLen = pr.len, unique = pr.unique;
+						phase = PH_DECIDE;
+					}
+				} else {
+					phase = PH_KMER;
 				}
 			}
 		}
@@ -492,12 +617,8 @@ __global__ __launch_bounds__(BLOCK, 6) void k_scan_cold(ScanArgs a) {
 
 	if (work) {
 		size_t slot = (size_t)it.sub * a.total_segs + it.w;
-		a.cold_exit[slot] = st;
-		// model_count_equal (src/model.c:247-253): len/4 to each diagonal cell, the rest to T->T
-		s_hist[0][tid] += eqQuarter, s_hist[5][tid] += eqQuarter, s_hist[10][tid] += eqQuarter;
-		s_hist[15][tid] += eqQuarter + eqRest;
-#pragma unroll
-		for (int t = 0; t < 16; ++t) a.cold_counts[slot * 16 + t] = s_hist[t][tid];
+		if (sub == 0) a.cold_exit[slot] = st;
+		for (uint32_t t = sub; t < 16; t += G) a.cold_counts[slot * 16 + t] = hist[t];
 	}
 }
 
@@ -658,9 +779,8 @@ template <int G>
 static hipError_t launch_cold(const ScanArgs &a, hipStream_t st) {
 	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	if (a.use_lanes) { // experimental lane-per-chain form, probe-table subjects only
-		dim3 lane_grid((a.total_segs + BLOCK - 1) / BLOCK, a.nsub);
-		k_scan_cold<<<lane_grid, BLOCK, 0, st>>>(a);
+	if (a.use_lanes) { // round-based form, probe-table subjects only
+		k_scan_cold<G><<<grid, BLOCK, 0, st>>>(a);
 		CHECK_LAUNCH();
 	}
 	if (a.any_reference || !a.use_lanes) {
