@@ -38,8 +38,6 @@ struct ScanArgs {
 	uint32_t *owned;       // [..][16] counts the true chain adds inside the segment
 	andi_hip_model *M;     // [nsub][nq]
 	unsigned long long *fixups;
-	int any_reference;  // some subject is in ANDI_MODE_REFERENCE
-	int use_lanes;      // round-based pass A for probe-table subjects (ANDI_SCAN_BLOCKING=1 turns it off)
 };
 
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st);

@@ -96,15 +96,17 @@ __device__ __forceinline__ void count_gap(uint32_t *hist, g_u8p s, g_u8p q,
 
 // A chain spends most of its steps on one diagonal (query offset p against
 // subject offset p + d), advancing ~1/divergence bytes per step.  Window keeps
-// the 16*G bytes of both strings that the group fetched last, plus a bitmask of
-// the positions where they differ, in registers: the following lucky
-// comparisons and gap counts on that diagonal are answered from it without
-// touching memory, so each 16*G-byte line of Q and S is fetched once.
+// what the group fetched last -- 16*G bytes of both strings, as 2-bit codes plus
+// ACGT masks, and a bitmask of the positions where the bytes differ -- in
+// registers: the following lucky comparisons, gap counts and K-mer codes on
+// that diagonal are answered from it without touching memory, so each
+// 16*G-byte line of Q and S is fetched once.
 template <int G>
 struct Window {
 	uint32_t q0, s0; // offsets of byte 0; q0 == ~0u: empty
-	uint4 qb, sb;    // this lane's bytes [16*sub, 16*sub + 16) of the window
-	uint32_t diff;   // bit t: this lane's byte t differs
+	uint32_t qc, sc; // 2-bit codes of this lane's 16 bytes, first byte in the top bits
+	uint32_t mask;   // bits 0..15: byte differs; bits 16..31: Q byte is ACGT
+	uint32_t sv;     // bits 0..15: S byte is ACGT
 };
 
 __device__ __forceinline__ uint32_t diff_bits4(uint32_t x) { // one bit per non-zero byte
@@ -115,14 +117,33 @@ __device__ __forceinline__ uint32_t diff_bits4(uint32_t x) { // one bit per non-
 	return ((x * 0x01020408u) >> 24) & 0xfu;
 }
 
+// 2-bit codes (first byte in the top bits) and ACGT mask of 16 bytes
+__device__ __forceinline__ void codes16(uint4 v, uint32_t &code, uint32_t &valid) {
+	auto pack4 = [](uint32_t x) {
+		x &= 0x06060606u;
+		x ^= x >> 1;
+		x = (x >> 1) & 0x03030303u;
+		return ((x & 0xffu) << 6) | (((x >> 8) & 0xffu) << 4) | (((x >> 16) & 0xffu) << 2) | (x >> 24);
+	};
+	auto ok4 = [](uint32_t x) { // bit t set <=> byte t has bit 6 (ACGT; separators and NUL have not)
+		x = (x >> 6) & 0x01010101u;
+		return ((x * 0x01020408u) >> 24) & 0xfu;
+	};
+	code = (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
+	valid = ok4(v.x) | (ok4(v.y) << 4) | (ok4(v.z) << 8) | (ok4(v.w) << 12);
+}
+
 template <int G>
 __device__ __forceinline__ void window_load(Window<G> &w, g_u8p Q, g_u8p S, uint32_t q0, uint32_t s0) {
 	const uint32_t sub = Group<G>::sub();
 	w.q0 = q0, w.s0 = s0;
-	w.qb = ld_u128_unaligned(Q + q0 + 16 * sub);
-	w.sb = ld_u128_unaligned(S + s0 + 16 * sub);
-	w.diff = diff_bits4(w.qb.x ^ w.sb.x) | (diff_bits4(w.qb.y ^ w.sb.y) << 4) |
-			 (diff_bits4(w.qb.z ^ w.sb.z) << 8) | (diff_bits4(w.qb.w ^ w.sb.w) << 12);
+	uint4 qb = ld_u128_unaligned(Q + q0 + 16 * sub);
+	uint4 sb = ld_u128_unaligned(S + s0 + 16 * sub);
+	uint32_t qv;
+	codes16(qb, w.qc, qv);
+	codes16(sb, w.sc, w.sv);
+	w.mask = diff_bits4(qb.x ^ sb.x) | (diff_bits4(qb.y ^ sb.y) << 4) | (diff_bits4(qb.z ^ sb.z) << 8) |
+			 (diff_bits4(qb.w ^ sb.w) << 12) | (qv << 16);
 }
 
 // lcp(Q + p, S + t, maxlen) (src/process.c:59-65) through the window
@@ -139,7 +160,8 @@ __device__ __forceinline__ uint32_t window_lcp(Window<G> &w, g_u8p Q, g_u8p S, u
 		}
 		// first differing byte at or after o
 		int sh = (int)o - (int)(16 * sub);
-		uint32_t m = sh <= 0 ? w.diff : (sh >= 16 ? 0u : (w.diff >> sh) << sh);
+		uint32_t d = w.mask & 0xffffu;
+		uint32_t m = sh <= 0 ? d : (sh >= 16 ? 0u : (d >> sh) << sh);
 		uint64_t hit = Group<G>::slice(__ballot(m != 0));
 		if (hit) {
 			uint32_t first = (uint32_t)__builtin_ctzll(hit);
@@ -160,16 +182,85 @@ __device__ __forceinline__ void window_count_gap(const Window<G> &w, uint32_t *h
 	if (w.q0 != ~0u && s - q == w.s0 - w.q0 && q >= w.q0 && q + len <= w.q0 + 16 * G) {
 		const uint32_t lo = q - w.q0, hi = lo + len, mine = 16 * Group<G>::sub();
 		uint32_t a = lo > mine ? lo - mine : 0, b = hi > mine ? (hi - mine < 16 ? hi - mine : 16) : 0;
-		for (uint32_t t = a; t < b; ++t) {
-			uint32_t wq = t < 8 ? (t < 4 ? w.qb.x : w.qb.y) : (t < 12 ? w.qb.z : w.qb.w);
-			uint32_t ws = t < 8 ? (t < 4 ? w.sb.x : w.sb.y) : (t < 12 ? w.sb.z : w.sb.w);
-			int8_t cq = (int8_t)(wq >> (8 * (t & 3))), cs = (int8_t)(ws >> (8 * (t & 3)));
-			if (cs >= 'A' && cq >= 'A')
-				atomicAdd(&hist[(nt_code((uint8_t)cs) << 2) + nt_code((uint8_t)cq)], 1u);
-		}
+		const uint32_t both = (w.mask >> 16) & w.sv; // neither byte is a separator
+		for (uint32_t t = a; t < b; ++t)
+			if ((both >> t) & 1u)
+				atomicAdd(&hist[(((w.sc >> (30 - 2 * t)) & 3u) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)], 1u);
 	} else {
 		count_gap<G>(hist, S + s, Q + q, len);
 	}
+}
+
+// The probe of one chain step (anchor(), src/process.c:113-123) in
+// ANDI_MODE_PROBE: the K-mer at Q[p] selects a probe-table entry that either is
+// the answer, or names the one suffix to extend along, or names a few suffixes
+// that the lanes of the group extend along in parallel.
+template <int G>
+__device__ __forceinline__ Probe probe_step(const PairCtx &c, uint32_t p, const Window<G> &w) {
+	const EsaG &E = c.E;
+	const uint32_t qrem = c.qlen - p, K = (uint32_t)E.deepK;
+	g_u8p q = c.Q + p;
+	if (E.mode == ANDI_MODE_REFERENCE) return esa_probe<G>(E, q, qrem);
+	if (qrem <= K) return sa_range_match<G>(E, q, qrem, 0, E.n - 1, 0);
+
+	uint32_t code, valid;
+	const uint32_t o = p - w.q0;
+	if (w.q0 != ~0u && p >= w.q0 && o + 16 <= 16 * G) {
+		// the K-mer's 16 bytes sit in the window, across lanes o/16 and o/16 + 1
+		uint32_t l0 = Group<G>::base() + (o >> 4), r = o & 15u;
+		uint32_t c0 = (uint32_t)__shfl((int)w.qc, (int)l0), c1 = (uint32_t)__shfl((int)w.qc, (int)(l0 + 1));
+		uint32_t v0 = (uint32_t)__shfl((int)w.mask, (int)l0) >> 16, v1 = (uint32_t)__shfl((int)w.mask, (int)(l0 + 1)) >> 16;
+		code = r ? ((c0 << (2 * r)) | (c1 >> (32 - 2 * r))) : c0;
+		valid = r ? ((v0 >> r) | (v1 << (16 - r))) : v0;
+	} else {
+		codes16(ld_u128_unaligned(q), code, valid);
+	}
+	if ((valid & ((1u << K) - 1u)) != ((1u << K) - 1u)) // separator inside the K-mer
+		return sa_range_match<G>(E, q, qrem, 0, E.n - 1, 0);
+
+	uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + (code >> (32 - 2 * K))));
+	const uint32_t x = (uint32_t)raw, y = (uint32_t)(raw >> 32), kind = y & 3u;
+	Probe r;
+	if (kind == DEEP_FINAL) {
+		r.len = y >> 8, r.unique = (y >> 2) & 1u;
+		r.pos = (r.unique && r.len >= (uint32_t)E.thr) ? (uint32_t)E.SA[x] : 0u;
+		return r;
+	}
+	if (kind == DEEP_SINGLE) {
+		r.pos = x, r.unique = true;
+		r.len = K + common_prefix<G>(q + K, E.S + x + K, qrem - K);
+		return r;
+	}
+	if (kind != DEEP_MULTI) return sa_range_match<G>(E, q, qrem, 0, E.n - 1, 0);
+
+	// Several occurrences: the longest match is the best of their own common
+	// prefixes with the query and it is unique iff exactly one attains it.  One
+	// occurrence per lane, G at a time.
+	const uint32_t sub = Group<G>::sub(), cnt = (y >> 8) + 1;
+	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
+	for (uint32_t off = 0; off < cnt; off += G) {
+		const bool mine = off + sub < cnt;
+		uint32_t pos = 0, len = 0;
+		if (mine) {
+			pos = (uint32_t)E.SA[x + off + sub];
+			len = K + common_prefix<1>(q + K, E.S + pos + K, qrem - K);
+		}
+		uint32_t best = len;
+		for (int d = G / 2; d; d >>= 1) {
+			uint32_t other = (uint32_t)__shfl_xor((int)best, d);
+			best = other > best ? other : best;
+		}
+		uint64_t who = Group<G>::slice(__ballot(mine && len == best));
+		uint32_t n = (uint32_t)__builtin_popcountll(who);
+		uint32_t bp = (uint32_t)__shfl((int)pos, (int)(Group<G>::base() + (uint32_t)__builtin_ctzll(who)));
+		if (bestCnt == 0 || best > bestLen) {
+			bestLen = best, bestCnt = n, bestPos = bp;
+		} else if (best == bestLen) {
+			bestCnt += n;
+		}
+	}
+	r.len = bestLen, r.unique = bestCnt == 1, r.pos = bestPos;
+	return r;
 }
 
 // One trip of the while loop, src/process.c:153-197.  Uniform within the group.
@@ -191,7 +282,7 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 	}
 	// anchor, src/process.c:113-123
 	if (!found) {
-		Probe pr = esa_probe<G>(c.E, c.Q + st.p, c.qlen - st.p);
+		Probe pr = probe_step<G>(c, st.p, w);
 		curS = pr.pos;
 		curLen = pr.len;
 		found = pr.unique && curLen >= c.thr;
@@ -259,13 +350,9 @@ __device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {
 }
 
 // ------------------------------------------------------------------ pass A
-// Blocking form: every group runs chain_step() to completion before the next
-// one starts.  Kept for the reference walk (flagged subjects) and as the
-// readable statement of what the round-based kernel below computes.
 template <int G>
-__global__ __launch_bounds__(BLOCK, 8) void k_scan_cold_blocking(ScanArgs a) {
+__global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 	__shared__ uint32_t s_hist[BLOCK / G][16];
-	if (a.subjects[blockIdx.y].mode != ANDI_MODE_REFERENCE && a.use_lanes) return; // k_scan_cold took it
 	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
 	uint32_t *hist = s_hist[threadIdx.x / G];
@@ -281,345 +368,6 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold_blocking(ScanArgs a) {
 	uint32_t lane = Group<G>::sub();
 	if (lane == 0) a.cold_exit[slot] = st;
 	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = hist[t];
-}
-
-// ------------------------------------------------------------------ pass A, round-based
-// In the blocking form above the 64/G chains of a wavefront move in lock-step:
-// every step costs the latency of the slowest chain's dependent accesses (probe
-// table, then the occurrence(s) of the K-mer).  Here each chain is a small
-// state machine and the wavefront executes "rounds": every lane forms the two
-// addresses its chain needs next, ONE pair of 16-byte loads serves all chains
-// whatever point of their step they are at, the chains consume their data and
-// then run on -- typically through several steps, because lucky comparisons
-// and gap counts are answered from the chain's register window -- until each
-// needs memory again.  Semantics are exactly those of chain_step() in
-// ANDI_MODE_PROBE.
-enum : uint32_t {
-	PH_DONE = 0,
-	// phases that wait for the round's loads
-	PH_WIN,    // refill the register window at (w.q0, w.s0)
-	PH_TABLE,  // fetch the probe-table entry
-	PH_SINGLE, // extend along the one suffix that has the K-mer
-	PH_MSA,    // K-mer occurs several times: fetch their positions, one per lane
-	PH_MCMP,   // ... and extend along each of them, one per lane
-	PH_KMER,   // fetch Q[p..p+16) (K-mer not inside the window)
-	PH_GAP,    // count a gap the window does not cover         (src/model.c:309-337)
-	PH_LAST_MEM = PH_GAP,
-	// compute-only phases
-	PH_DECIDE,  // have (curS, curLen, unique)
-	PH_FOUND,   // src/process.c:158-193
-	PH_ADVANCE, // src/process.c:196
-	PH_STEP,    // top of the while loop                        (src/process.c:153)
-	PH_LUCKY,   // lucky comparison through the window          (src/process.c:93-97)
-	PH_PROBE    // lucky failed or was not tried                (src/process.c:113-123)
-};
-
-// rare path (remainder not longer than K, separator in the K-mer): whole-array
-// search, out of line so it does not inflate the kernel's register allocation
-__device__ __noinline__ Probe search_out_of_line(const EsaG &E, g_u8p q, uint32_t qlen) {
-	return sa_range_match<1>(E, q, qlen, 0, E.n - 1, 0);
-}
-
-// 2-bit codes (first byte in the top bits) and ACGT mask of 16 bytes
-__device__ __forceinline__ void codes16(uint4 v, uint32_t &code, uint32_t &valid) {
-	auto pack4 = [](uint32_t x) {
-		x &= 0x06060606u;
-		x ^= x >> 1;
-		x = (x >> 1) & 0x03030303u;
-		return ((x & 0xffu) << 6) | (((x >> 8) & 0xffu) << 4) | (((x >> 16) & 0xffu) << 2) | (x >> 24);
-	};
-	auto ok4 = [](uint32_t x) { // bit t set <=> byte t >= 'A' (bit 6)
-		x = (x >> 6) & 0x01010101u;
-		return ((x * 0x01020408u) >> 24) & 0xfu;
-	};
-	code = (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
-	valid = ok4(v.x) | (ok4(v.y) << 4) | (ok4(v.z) << 8) | (ok4(v.w) << 12);
-}
-
-template <int G>
-__global__ __launch_bounds__(BLOCK, 6) void k_scan_cold(ScanArgs a) {
-	__shared__ uint32_t s_hist[BLOCK / G][16];
-	if (a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return; // see k_scan_cold_blocking
-	WorkItem it = decode_item<G>(a);
-	const bool work = it.valid && !it.is_self;
-	uint32_t *hist = s_hist[threadIdx.x / G];
-	hist_zero<G>(hist);
-
-	// subject data is uniform for the block; query data is per chain
-	const EsaG E = esa_global(a.subjects[blockIdx.y]);
-	const uint32_t n = (uint32_t)E.n, thr = (uint32_t)E.thr, border = n / 2, K = (uint32_t)E.deepK;
-	const uint32_t sub = Group<G>::sub(), gbase = Group<G>::base();
-	constexpr uint32_t W = 16 * G; // window bytes
-	g_u8p Q = (g_u8p)a.qpool;
-	uint32_t qlen = 0;
-	if (work) {
-		Q += a.qoff[it.qidx];
-		qlen = a.qlen[it.qidx];
-	}
-
-	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, n);
-	uint32_t phase = (work && st.p < it.end) ? (uint32_t)PH_STEP : (uint32_t)PH_DONE;
-	// register window: this lane's 16 bytes of Q and S as 2-bit codes, ACGT masks, differing bytes
-	uint32_t wq0 = ~0u, ws0 = 0, wqc = 0, wsc = 0, wmask = 0; // wmask: diff | qvalid << 16; svalid in wsv
-	uint32_t wsv = 0;
-	uint32_t lkLen = 0, lkT = 0;                               // lucky comparison in progress
-	uint32_t cmpA = 0, cmpB = 0, cmpDone = 0, cmpMax = 0;      // PH_SINGLE / PH_GAP cursor
-	uint32_t curS = 0, curLen = 0, kcode = 0;
-	uint32_t mlo = 0, mcnt = 0, moff = 0, bestLen = 0, bestCnt = 0, bestPos = 0; // several occurrences
-	uint32_t myPos = 0, myDone = 0, myLen = 0;                                    // ... this lane's candidate
-	bool unique = false, myFin = true;
-
-	while (__any(phase != PH_DONE)) {
-		// ---- one round of loads
-		g_u8p pa = Q, pb = E.S; // harmless addresses for chains that need nothing
-		if (phase == PH_WIN) {
-			pa = Q + wq0 + 16 * sub;
-			pb = E.S + ws0 + 16 * sub;
-		} else if (phase == PH_SINGLE || phase == PH_GAP) {
-			pa = Q + cmpA + cmpDone + 16 * sub;
-			pb = E.S + cmpB + cmpDone + 16 * sub;
-		} else if (phase == PH_TABLE) {
-			pa = (g_u8p)(E.deep + kcode);
-		} else if (phase == PH_MSA) {
-			if (moff + sub < mcnt) pa = (g_u8p)(E.SA + mlo + moff + sub);
-		} else if (phase == PH_MCMP) {
-			if (!myFin) {
-				pa = Q + st.p + K + myDone;
-				pb = E.S + myPos + K + myDone;
-			}
-		} else if (phase == PH_KMER) {
-			pa = Q + st.p;
-		}
-		const uint4 da = ld_u128_unaligned(pa);
-		const uint4 db = ld_u128_unaligned(pb);
-
-		// ---- consume
-		if (phase == PH_WIN) {
-			uint32_t qv, sv;
-			codes16(da, wqc, qv);
-			codes16(db, wsc, sv);
-			uint32_t diff = diff_bits4(da.x ^ db.x) | (diff_bits4(da.y ^ db.y) << 4) |
-							(diff_bits4(da.z ^ db.z) << 8) | (diff_bits4(da.w ^ db.w) << 12);
-			wmask = diff | (qv << 16);
-			wsv = sv;
-			phase = PH_LUCKY;
-		} else if (phase == PH_TABLE) {
-			uint32_t x = da.x, y = da.y, kind = y & 3u;
-			if (kind == DEEP_FINAL) {
-				curLen = y >> 8, unique = (y >> 2) & 1u;
-				curS = (unique && curLen >= thr) ? (uint32_t)E.SA[x] : 0u;
-				phase = PH_DECIDE;
-			} else if (kind == DEEP_SINGLE) {
-				curS = x, unique = true;
-				cmpA = st.p + K, cmpB = x + K, cmpDone = 0, cmpMax = qlen - st.p - K;
-				phase = PH_SINGLE;
-			} else if (kind == DEEP_MULTI) {
-				mlo = x, mcnt = (y >> 8) + 1, moff = 0;
-				bestLen = 0, bestCnt = 0, bestPos = 0;
-				phase = PH_MSA;
-			} else { // DEEP_SEARCH
-				Probe pr = search_out_of_line(E, Q + st.p, qlen - st.p);
-				curS = pr.pos, curLen = pr.len, unique = pr.unique;
-				phase = PH_DECIDE;
-			}
-		} else if (phase == PH_SINGLE) {
-			uint4 x = make_uint4(da.x ^ db.x, da.y ^ db.y, da.z ^ db.z, da.w ^ db.w);
-			uint32_t f = first_diff_byte(x);
-			uint64_t hit = Group<G>::slice(__ballot(f < 16));
-			if (hit) {
-				uint32_t first = (uint32_t)__builtin_ctzll(hit);
-				uint32_t len = cmpDone + 16 * first + (uint32_t)__shfl((int)f, (int)(gbase + first));
-				curLen = K + (len < cmpMax ? len : cmpMax);
-				phase = PH_DECIDE;
-			} else {
-				cmpDone += W;
-				if (cmpDone >= cmpMax) {
-					curLen = K + cmpMax;
-					phase = PH_DECIDE;
-				}
-			}
-		} else if (phase == PH_MSA) { // da.x = SA[mlo + moff + sub] for the lanes that have a candidate
-			myFin = moff + sub >= mcnt;
-			myPos = da.x, myDone = 0, myLen = 0;
-			phase = PH_MCMP;
-		} else if (phase == PH_MCMP) {
-			// The longest match is the best of the candidates' own common prefixes
-			// with the query; it is unique iff exactly one attains it.
-			const uint32_t qrem = qlen - st.p;
-			if (!myFin) {
-				uint4 x = make_uint4(da.x ^ db.x, da.y ^ db.y, da.z ^ db.z, da.w ^ db.w);
-				uint32_t f = first_diff_byte(x);
-				uint32_t l = K + myDone + f;
-				if (f < 16 || l >= qrem) {
-					myLen = l < qrem ? l : qrem;
-					myFin = true;
-				} else {
-					myDone += 16;
-				}
-			}
-			if (Group<G>::slice(__ballot(!myFin)) == 0) {
-				bool mine = moff + sub < mcnt;
-				uint32_t best = mine ? myLen : 0u;
-				for (int o = G / 2; o; o >>= 1) {
-					uint32_t other = (uint32_t)__shfl_xor((int)best, o);
-					best = other > best ? other : best;
-				}
-				uint64_t who = Group<G>::slice(__ballot(mine && myLen == best));
-				uint32_t cnt = (uint32_t)__builtin_popcountll(who);
-				uint32_t pos = (uint32_t)__shfl((int)myPos, (int)(gbase + (uint32_t)__builtin_ctzll(who)));
-				if (best > bestLen || bestCnt == 0) {
-					bestLen = best, bestCnt = cnt, bestPos = pos;
-				} else if (best == bestLen) {
-					bestCnt += cnt;
-				}
-				moff += G;
-				if (moff < mcnt) {
-					phase = PH_MSA;
-				} else {
-					curLen = bestLen, curS = bestPos, unique = bestCnt == 1;
-					phase = PH_DECIDE;
-				}
-			}
-		} else if (phase == PH_KMER) {
-			uint32_t code, valid;
-			codes16(da, code, valid);
-			if ((valid & ((1u << K) - 1u)) == ((1u << K) - 1u)) {
-				kcode = code >> (32 - 2 * K);
-				phase = PH_TABLE;
-			} else {
-				Probe pr = search_out_of_line(E, Q + st.p, qlen - st.p);
-				curS = pr.pos, curLen = pr.len, unique = pr.unique;
-				phase = PH_DECIDE;
-			}
-		} else if (phase == PH_GAP) {
-			uint32_t off = cmpDone + 16 * sub;
-			uint32_t cnt = off < cmpMax ? (cmpMax - off < 16 ? cmpMax - off : 16) : 0;
-			for (uint32_t t = 0; t < cnt; ++t) {
-				uint32_t wq = t < 8 ? (t < 4 ? da.x : da.y) : (t < 12 ? da.z : da.w);
-				uint32_t ws = t < 8 ? (t < 4 ? db.x : db.y) : (t < 12 ? db.z : db.w);
-				int8_t q = (int8_t)(wq >> (8 * (t & 3)));
-				int8_t s = (int8_t)(ws >> (8 * (t & 3)));
-				if (s >= 'A' && q >= 'A')
-					atomicAdd(&hist[(nt_code((uint8_t)s) << 2) + nt_code((uint8_t)q)], 1u);
-			}
-			cmpDone += W;
-			if (cmpDone >= cmpMax) {
-				st.lwra = 1;
-				st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
-				phase = PH_ADVANCE;
-			}
-		}
-
-		// ---- run on until every chain needs memory
-		while (__any(phase > PH_LAST_MEM)) {
-			if (phase == PH_DECIDE) phase = (unique && curLen >= thr) ? (uint32_t)PH_FOUND : (uint32_t)PH_ADVANCE;
-			if (phase == PH_FOUND) {
-				uint32_t endS = st.lastS + st.lastLen;
-				uint32_t endQ = st.lastQ + st.lastLen;
-				if (curS > endS && st.p - endQ == curS - endS && (curS < border) == (st.lastS < border)) {
-					count_equal<G>(hist, st.lastLen);
-					uint32_t glen = st.p - endQ;
-					if (wq0 != ~0u && endS - endQ == ws0 - wq0 && endQ >= wq0 && endQ + glen <= wq0 + W) {
-						// the window holds the gap: count from its 2-bit codes
-						uint32_t lo = endQ - wq0, hi = lo + glen, mine = 16 * sub;
-						uint32_t ta = lo > mine ? lo - mine : 0, tb = hi > mine ? (hi - mine < 16 ? hi - mine : 16) : 0;
-						uint32_t both = (wmask >> 16) & wsv;
-						for (uint32_t t = ta; t < tb; ++t)
-							if ((both >> t) & 1u)
-								atomicAdd(&hist[(((wsc >> (30 - 2 * t)) & 3u) << 2) | ((wqc >> (30 - 2 * t)) & 3u)], 1u);
-						st.lwra = 1;
-						st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
-						phase = PH_ADVANCE;
-					} else {
-						cmpA = endQ, cmpB = endS, cmpDone = 0, cmpMax = glen;
-						phase = PH_GAP;
-					}
-				} else {
-					if (st.lwra || st.lastLen >= 2 * thr) count_equal<G>(hist, st.lastLen);
-					st.lwra = 0;
-					st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
-					phase = PH_ADVANCE;
-				}
-			}
-			if (phase == PH_ADVANCE) {
-				st.p += curLen + 1;
-				phase = st.p < it.end ? (uint32_t)PH_STEP : (uint32_t)PH_DONE;
-			}
-			if (phase == PH_STEP) {
-				uint32_t advance = st.p - st.lastQ;
-				uint32_t gap = advance - st.lastLen;
-				uint32_t tryS = st.lastS + advance;
-				if (tryS < n && gap <= thr) {
-					lkLen = 0, lkT = tryS;
-					phase = PH_LUCKY;
-				} else {
-					phase = PH_PROBE;
-				}
-			}
-			if (phase == PH_LUCKY) {
-				const uint32_t maxlen = qlen - st.p;
-				uint32_t pos = st.p + lkLen, o = pos - wq0;
-				if (wq0 == ~0u || lkT - st.p != ws0 - wq0 || pos < wq0 || o >= W) {
-					wq0 = pos, ws0 = lkT + lkLen;
-					phase = PH_WIN;
-				} else {
-					int sh = (int)o - (int)(16 * sub);
-					uint32_t d = wmask & 0xffffu;
-					uint32_t m = sh <= 0 ? d : (sh >= 16 ? 0u : (d >> sh) << sh);
-					uint64_t hit = Group<G>::slice(__ballot(m != 0));
-					bool finished = true;
-					if (hit) {
-						uint32_t first = (uint32_t)__builtin_ctzll(hit);
-						uint32_t bit = (uint32_t)__shfl((int)__builtin_ctz(m | 0x10000u), (int)(gbase + first));
-						lkLen += 16 * first + bit - o;
-					} else {
-						lkLen += W - o;
-						finished = lkLen >= maxlen;
-						if (!finished) { // ran off the window: fetch the next one
-							wq0 = st.p + lkLen, ws0 = lkT + lkLen;
-							phase = PH_WIN;
-						}
-					}
-					if (finished) {
-						curS = lkT, curLen = lkLen < maxlen ? lkLen : maxlen, unique = true;
-						phase = curLen >= thr ? (uint32_t)PH_FOUND : (uint32_t)PH_PROBE;
-					}
-				}
-			}
-			if (phase == PH_PROBE) {
-				uint32_t qrem = qlen - st.p;
-				uint32_t o = st.p - wq0;
-				if (qrem <= K) {
-					Probe pr = search_out_of_line(E, Q + st.p, qrem); // rare
-					curS = pr.pos, curLen = pr.len, unique = pr.unique;
-					phase = PH_DECIDE;
-				} else if (wq0 != ~0u && st.p >= wq0 && o + 16 <= W) {
-					// the K-mer's 16 bytes sit in the window, across lanes o/16 and o/16 + 1
-					uint32_t l0 = gbase + (o >> 4), r = o & 15u;
-					uint32_t c0 = (uint32_t)__shfl((int)wqc, (int)l0), c1 = (uint32_t)__shfl((int)wqc, (int)(l0 + 1));
-					uint32_t v0 = (uint32_t)__shfl((int)wmask, (int)l0) >> 16, v1 = (uint32_t)__shfl((int)wmask, (int)(l0 + 1)) >> 16;
-					uint32_t code = r ? ((c0 << (2 * r)) | (c1 >> (32 - 2 * r))) : c0;
-					uint32_t valid = r ? ((v0 >> r) | (v1 << (16 - r))) : v0;
-					if ((valid & ((1u << K) - 1u)) == ((1u << K) - 1u)) {
-						kcode = code >> (32 - 2 * K);
-						phase = PH_TABLE;
-					} else {
-						Probe pr = search_out_of_line(E, Q + st.p, qrem); // separator in the K-mer
-						curS = pr.pos, curLen = pr.len, unique = pr.unique;
-						phase = PH_DECIDE;
-					}
-				} else {
-					phase = PH_KMER;
-				}
-			}
-		}
-	}
-
-	if (work) {
-		size_t slot = (size_t)it.sub * a.total_segs + it.w;
-		if (sub == 0) a.cold_exit[slot] = st;
-		for (uint32_t t = sub; t < 16; t += G) a.cold_counts[slot * 16 + t] = hist[t];
-	}
 }
 
 // Replays the true chain (entering in state T) through [start, end) next to the
@@ -657,7 +405,7 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 
 // ------------------------------------------------------------------ pass B
 template <int G>
-__global__ __launch_bounds__(BLOCK, 8) void k_scan_stitch(ScanArgs a) {
+__global__ __launch_bounds__(BLOCK, 6) void k_scan_stitch(ScanArgs a) {
 	__shared__ uint32_t s_hist[BLOCK / G][2][16];
 	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
@@ -779,14 +527,8 @@ template <int G>
 static hipError_t launch_cold(const ScanArgs &a, hipStream_t st) {
 	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	if (a.use_lanes) { // round-based form, probe-table subjects only
-		k_scan_cold<G><<<grid, BLOCK, 0, st>>>(a);
-		CHECK_LAUNCH();
-	}
-	if (a.any_reference || !a.use_lanes) {
-		k_scan_cold_blocking<G><<<grid, BLOCK, 0, st>>>(a);
-		CHECK_LAUNCH();
-	}
+	k_scan_cold<G><<<grid, BLOCK, 0, st>>>(a);
+	CHECK_LAUNCH();
 	return hipSuccess;
 }
 
