@@ -191,6 +191,18 @@ __device__ __forceinline__ void window_count_gap(const Window<G> &w, uint32_t *h
 	}
 }
 
+// Rare paths of the probe, kept out of line: inlined into every chain step they
+// multiply the kernel's code size (and its instruction-cache footprint).
+template <int G>
+__device__ __noinline__ Probe reference_probe(const EsaG &E, g_u8p q, uint32_t qrem) {
+	return esa_probe<G>(E, q, qrem); // the reference's own walk, ANDI_MODE_REFERENCE
+}
+
+template <int G>
+__device__ __noinline__ Probe root_search(const EsaG &E, g_u8p q, uint32_t qrem) {
+	return sa_range_match<G>(E, q, qrem, 0, E.n - 1, 0);
+}
+
 // The probe of one chain step (anchor(), src/process.c:113-123) in
 // ANDI_MODE_PROBE: the K-mer at Q[p] selects a probe-table entry that either is
 // the answer, or names the one suffix to extend along, or names a few suffixes
@@ -200,8 +212,8 @@ __device__ __forceinline__ Probe probe_step(const PairCtx &c, uint32_t p, const 
 	const EsaG &E = c.E;
 	const uint32_t qrem = c.qlen - p, K = (uint32_t)E.deepK;
 	g_u8p q = c.Q + p;
-	if (E.mode == ANDI_MODE_REFERENCE) return esa_probe<G>(E, q, qrem);
-	if (qrem <= K) return sa_range_match<G>(E, q, qrem, 0, E.n - 1, 0);
+	if (E.mode == ANDI_MODE_REFERENCE) return reference_probe<G>(E, q, qrem);
+	if (qrem <= K) return root_search<G>(E, q, qrem);
 
 	uint32_t code, valid;
 	const uint32_t o = p - w.q0;
@@ -216,7 +228,7 @@ __device__ __forceinline__ Probe probe_step(const PairCtx &c, uint32_t p, const 
 		codes16(ld_u128_unaligned(q), code, valid);
 	}
 	if ((valid & ((1u << K) - 1u)) != ((1u << K) - 1u)) // separator inside the K-mer
-		return sa_range_match<G>(E, q, qrem, 0, E.n - 1, 0);
+		return root_search<G>(E, q, qrem);
 
 	uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + (code >> (32 - 2 * K))));
 	const uint32_t x = (uint32_t)raw, y = (uint32_t)(raw >> 32), kind = y & 3u;
@@ -231,7 +243,7 @@ __device__ __forceinline__ Probe probe_step(const PairCtx &c, uint32_t p, const 
 		r.len = K + common_prefix<G>(q + K, E.S + x + K, qrem - K);
 		return r;
 	}
-	if (kind != DEEP_MULTI) return sa_range_match<G>(E, q, qrem, 0, E.n - 1, 0);
+	if (kind != DEEP_MULTI) return root_search<G>(E, q, qrem);
 
 	// Several occurrences: the longest match is the best of their own common
 	// prefixes with the query and it is unique iff exactly one attains it.  One
@@ -390,10 +402,12 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 			break;
 		}
 		if (T.p >= end) break;
-		if (C.p >= end || T.p <= C.p) {
-			T = chain_step<G>(c, T, histT, w);
+		const bool stepT = C.p >= end || T.p <= C.p; // one call site keeps the code small
+		ChainState nx = chain_step<G>(c, stepT ? T : C, stepT ? histT : histC, w);
+		if (stepT) {
+			T = nx;
 		} else {
-			C = chain_step<G>(c, C, histC, w);
+			C = nx;
 		}
 	}
 	if (synced) {
