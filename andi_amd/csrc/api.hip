@@ -21,7 +21,11 @@
 #include "esa_build.h"
 #include "scan.h"
 
-#define ANDI_DEFAULT_SEGMENT 16384u
+// segment length when the caller passes 0: short enough that one scan launch has
+// several hundred thousand chains, long enough that stitching stays a few per cent
+#define ANDI_MIN_SEGMENT 4096u
+#define ANDI_MAX_SEGMENT 65536u
+#define ANDI_TARGET_CHAINS (1u << 20)
 
 static_assert(sizeof(andi_hip_model) == 68, "struct model must be 17 x u32 (src/model.h:52-57)");
 static_assert(sizeof(andi_hip_interval) == 16, "lcp_inter_t is 4 x int32 (src/esa.h:25-34)");
@@ -544,7 +548,11 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	auto *q = const_cast<andi_hip_queries *>(q_const);
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (segment == 0) segment = ANDI_DEFAULT_SEGMENT;
+	if (segment == 0) {
+		uint64_t nt = q->total_nt * (uint64_t)nsub;
+		segment = ANDI_MIN_SEGMENT;
+		while (segment < ANDI_MAX_SEGMENT && nt / segment > ANDI_TARGET_CHAINS) segment *= 2;
+	}
 	if (ensure_segmentation(ctx, q, segment)) return 1;
 
 	// descriptors: [EsaDev x nsub][int64 x nsub]

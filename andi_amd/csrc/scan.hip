@@ -36,7 +36,7 @@
 
 #define WAVES_PER_BLOCK 4
 #define BLOCK (64 * WAVES_PER_BLOCK)
-#define SCAN_G 8 /* lanes per chain in passes A and B */
+#define SCAN_G 4 /* lanes per chain in passes A and B (measured best of 4/8/16 on MI355X) */
 
 #define CHECK_LAUNCH()                                                                             \
 	do {                                                                                           \
@@ -191,15 +191,15 @@ __device__ __forceinline__ void window_count_gap(const Window<G> &w, uint32_t *h
 	}
 }
 
-// Rare paths of the probe, kept out of line: inlined into every chain step they
-// multiply the kernel's code size (and its instruction-cache footprint).
+// Rare paths of the probe.  (Keeping them out of line shrinks the kernel 50x but
+// measured ~10 % slower: the calls constrain register allocation on the hot path.)
 template <int G>
-__device__ __noinline__ Probe reference_probe(const EsaG &E, g_u8p q, uint32_t qrem) {
+__device__ __forceinline__ Probe reference_probe(const EsaG &E, g_u8p q, uint32_t qrem) {
 	return esa_probe<G>(E, q, qrem); // the reference's own walk, ANDI_MODE_REFERENCE
 }
 
 template <int G>
-__device__ __noinline__ Probe root_search(const EsaG &E, g_u8p q, uint32_t qrem) {
+__device__ __forceinline__ Probe root_search(const EsaG &E, g_u8p q, uint32_t qrem) {
 	return sa_range_match<G>(E, q, qrem, 0, E.n - 1, 0);
 }
 

@@ -23,7 +23,6 @@ one gather at the end.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -48,20 +47,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1729)
     return ap.parse_args()
-
-
-def set_size(n_gpus):
-    table = {1: 29, 2: 42, 4: 60, 8: 80}
-    if n_gpus in table:
-        return table[n_gpus]
-    return n_gpus * max(1, round(29 / math.sqrt(n_gpus)))
-
-
-def row_block(total, world, rank):
-    """Contiguous block of subject rows owned by `rank` (sizes differ by <= 1)."""
-    base, extra = divmod(total, world)
-    start = rank * base + min(rank, extra)
-    return start, start + base + (1 if rank < extra else 0)
 
 
 def cpu_baseline(seqs, p_value, model):
@@ -98,7 +83,7 @@ def main():
     import torch
 
     import andi_amd
-    from andi_amd import lib, synth
+    from andi_amd import lib, shard, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the anchor-distance engine has no CPU path")
@@ -109,14 +94,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    G = args.genomes or set_size(world)
+    G = args.genomes or shard.weak_scaling_set_size(world)
     model = andi_amd.M_JC
     p_value = 0.025
     t_gen = time.time()
     seqs, ds = synth.genome_set(G, args.length, args.dlo, args.dhi, seed=args.seed)
     t_gen = time.time() - t_gen
 
-    r0, r1 = row_block(G, world, rank)
+    r0, r1 = shard.row_block(G, world, rank)
     ctx = andi_amd.Context(local_rank)
     # ---- untimed staging: queries, and for the owned rows RS + host suffix array
     t_stage = time.time()
@@ -125,11 +110,8 @@ def main():
     ctx.sync()
     t_stage = time.time() - t_stage
     nsub = r1 - r0
-    rows_max = max(row_block(G, world, r)[1] - row_block(G, world, r)[0] for r in range(world))
-    block = torch.zeros((rows_max, G, 17), dtype=torch.int32, device="cuda")
-    gathered = None
-    if world > 1:
-        gathered = torch.zeros((world, rows_max, G, 17), dtype=torch.int32, device="cuda")
+    block = torch.zeros((shard.max_rows(G, world), G, 17), dtype=torch.int32, device="cuda")
+    gathered = [None]
     selfs = list(range(r0, r1))
     dptr = andi_amd.lib._P(block.data_ptr())
 
@@ -138,8 +120,8 @@ def main():
             e.build()  # K1-K4
         lib.scan_rows_dev(ctx, esas, selfs, Q, model, args.segment, dptr)  # K5-K7
         ctx.sync()  # the engine's stream is not torch's: finish before the collective
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, block)  # RCCL over xGMI; rank 0 keeps the matrix
+        if world > 1:  # RCCL over xGMI: the one exchange of the job, 68 B per ordered pair
+            gathered[0] = shard.gather_matrix(block, G, dist, world, rank)
 
     def fence():
         if world > 1:
@@ -177,19 +159,13 @@ def main():
         try:
             rec = json.load(open(prof))
             key = "G%d_L%d_seg%d" % (G, args.length, args.segment)
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")  # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE
         except Exception:
             traffic = None
 
     out = None
     if rank == 0:
-        full = block[:nsub].cpu().numpy().view(np.uint32) if world == 1 else None
-        if world > 1:
-            parts = []
-            for r in range(world):
-                a, b = row_block(G, world, r)
-                parts.append(gathered[r, : b - a].cpu().numpy().view(np.uint32))
-            full = np.concatenate(parts, axis=0)
+        full = shard.gather_matrix(block, G) if world == 1 else gathered[0]
         dmat = [andi_amd.estimate(full[0, j].astype(np.uint64) + full[j, 0], model) for j in range(1, min(G, 4))]
         out = {
             "metric": "genome-pairs/sec (ordered pairs, n^2-n) over the N x N anchor-distance loop",
@@ -200,7 +176,7 @@ def main():
                                    "seed %d; rows block-partitioned over %d GPU(s)"
                                    % (G, args.length, args.dlo, args.dhi, args.seed, world),
                        "genomes": G, "length": args.length, "model": "JC", "pairs": pairs_total,
-                       "segment": args.segment or 16384},
+                       "segment": args.segment or "auto (4096 for this set)"},
             "roofline": {"bound": "hbm", "kernel": "k_scan_cold", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_ms,
