@@ -9,10 +9,10 @@ against the 8 TB/s roofline.
 Workload at --gpus 1: BASELINE.json configs[1] as synthetic data ("C2-synth",
 SURVEY.md §8d): 29 genomes of 4.9 Mbp, each diverged from a common base by
 d_k ~ U[0.0004, 0.03], JC model.  One step = one pass of the device path over
-the whole set: per subject the index build (LCP, child table, FVC, 10-mer
-table; K1-K4) from the resident RS + suffix array, then the anchor scan of every
-query against every subject (K5-K7), then (N > 1) the RCCL gather of the row
-blocks on rank 0.  Suffix arrays are built on the host and uploaded before the
+the whole set: per subject the device index build (the scan index: K-mer probe
+table, from the resident RS + suffix array), then the anchor scan of every query
+against every subject (passes A/B/C of scan.hip), then (N > 1) the RCCL gather of
+the row blocks.  Suffix arrays are built on the host and uploaded before the
 timed region (north_star: "SA ... on host"); their cost is reported under
 "end_to_end", never in "value".
 
@@ -117,8 +117,8 @@ def main():
 
     def step():
         for e in esas:
-            e.build()  # K1-K4
-        lib.scan_rows_dev(ctx, esas, selfs, Q, model, args.segment, dptr)  # K5-K7
+            e.build()  # device index build
+        lib.scan_rows_dev(ctx, esas, selfs, Q, model, args.segment, dptr)  # anchor scan
         ctx.sync()  # the engine's stream is not torch's: finish before the collective
         if world > 1:  # RCCL over xGMI: the one exchange of the job, 68 B per ordered pair
             gathered[0] = shard.gather_matrix(block, G, dist, world, rank)
@@ -181,7 +181,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_ms,
                          "launches": int(tm["scan_launches"])},
-            "breakdown_ms_per_step": {"index_build_K1_K4": tm["build_ms"] / args.steps,
+            "breakdown_ms_per_step": {"index_build": tm["build_ms"] / args.steps,
                                       "scan_cold_pass": tm["scan_ms"] / args.steps,
                                       "scan_stitch_reduce": tm["stitch_ms"] / args.steps,
                                       "fixups": int(tm["fixups"])},
