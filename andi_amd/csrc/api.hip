@@ -18,6 +18,7 @@
 
 #include "andi_dev.h"
 #include "andi_hip.h"
+#include "bootstrap.h"
 #include "esa_build.h"
 #include "scan.h"
 
@@ -643,6 +644,30 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	ctx->acc.scan_pairs += pairs;
 	ctx->acc.scan_query_nt += nt;
+	return 0;
+}
+
+// ------------------------------------------------------------------ bootstrap
+int andi_hip_bootstrap(andi_hip_ctx *ctx, const andi_hip_model *M, size_t n, uint64_t seed,
+					   size_t replicates, andi_hip_model *B) {
+	if (!ctx || !M || !B || n == 0 || n > 65535) {
+		if (ctx) ctx->err = "andi_hip_bootstrap: bad arguments";
+		return 1;
+	}
+	if (replicates == 0) return 0;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const size_t one = n * n * sizeof(andi_hip_model);
+	andi_hip_model *dM = nullptr, *dB = nullptr;
+	hipError_t e = hipMalloc((void **)&dM, one);
+	if (e == hipSuccess) e = hipMalloc((void **)&dB, one * replicates);
+	if (e == hipSuccess) e = hipMemcpyAsync(dM, M, one, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess)
+		e = andi_launch_bootstrap(dM, dB, (uint32_t)n, (uint32_t)replicates, seed, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(B, dB, one * replicates, hipMemcpyDeviceToHost, ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(dM);
+	(void)hipFree(dB);
+	if (e != hipSuccess) return fail(ctx, "andi_hip_bootstrap", e);
 	return 0;
 }
 

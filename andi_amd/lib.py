@@ -98,6 +98,7 @@ SYMBOLS = {
     "andi_hip_match_positions": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _P]),
     "andi_hip_scan_rows": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64), C.c_size_t, _P, C.c_int,
                                      C.c_uint32, _P]),
+    "andi_hip_bootstrap": (C.c_int, [_P, _P, C.c_size_t, C.c_uint64, C.c_size_t, _P]),
     "andi_hip_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "andi_hip_dev_free": (None, [_P, _P]),
     "andi_hip_copy_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -358,6 +359,16 @@ def scan_rows(ctx: Context, esas, selfs, queries: Queries, model=M_JC, segment=0
     finally:
         ctx.free(d)
     return out
+
+
+def bootstrap(ctx: Context, M, replicates, seed=0):
+    """calculate_bootstrap (src/process.c:289): (replicates, n, n, 17) uint32."""
+    M = np.ascontiguousarray(M, dtype=np.uint32)
+    n = M.shape[0]
+    assert M.shape == (n, n, 17)
+    B = np.empty((replicates, n, n, 17), np.uint32)
+    ctx._check(load().andi_hip_bootstrap(ctx._h, M.ctypes.data, n, seed, replicates, B.ctypes.data), "bootstrap")
+    return B
 
 
 def dist_matrix(seqs, p_value=0.025, model=M_JC, device=0, host_threads=0, segment=0):

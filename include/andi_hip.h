@@ -159,6 +159,15 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects,
 					   const int64_t *self, size_t nsub, const andi_hip_queries *q, int model,
 					   uint32_t segment, andi_hip_model *M_dev);
 
+/* calculate_bootstrap (src/process.c:289-321): `replicates` resampled matrices
+ * from M (host, n*n) into B (host, replicates*n*n).  For every pair i < j the
+ * summed counts model_average(M(i,j), M(j,i)) are redrawn from a multinomial
+ * (model_bootstrap, src/model.c:222-232), mirrored, diagonal {counts[0]=1,
+ * seq_len=1}.  Deterministic in (seed, replicate, i, j).  The reference seeds
+ * GSL from the clock, so only the distribution can be compared, not the draws. */
+int andi_hip_bootstrap(andi_hip_ctx *ctx, const andi_hip_model *M, size_t n, uint64_t seed,
+					   size_t replicates, andi_hip_model *B);
+
 /* plain device memory helpers so callers need no HIP headers */
 int andi_hip_dev_alloc(andi_hip_ctx *ctx, size_t bytes, void **dptr);
 void andi_hip_dev_free(andi_hip_ctx *ctx, void *dptr);
