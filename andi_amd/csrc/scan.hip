@@ -146,16 +146,19 @@ __device__ __forceinline__ void window_load(Window<G> &w, g_u8p Q, g_u8p S, uint
 			 (diff_bits4(qb.w ^ sb.w) << 12) | (qv << 16);
 }
 
-// lcp(Q + p, S + t, maxlen) (src/process.c:59-65) through the window
+// lcp(Q + p, S + t, maxlen) (src/process.c:59-65) through the window.  A match that
+// runs past the window it started in is followed BULK windows at a time (2*BULK
+// independent loads in flight) instead of one dependent window after the other.
 template <int G>
 __device__ __forceinline__ uint32_t window_lcp(Window<G> &w, g_u8p Q, g_u8p S, uint32_t p, uint32_t t,
 											   uint32_t maxlen) {
+	constexpr uint32_t W = 16 * G;
 	const uint32_t sub = Group<G>::sub();
 	uint32_t len = 0;
-	for (;;) {
-		uint32_t o = p + len - w.q0; // offset into the window, if it applies
-		if (w.q0 == ~0u || t - p != w.s0 - w.q0 || p + len < w.q0 || o >= 16 * G) {
-			window_load(w, Q, S, p + len, t + len);
+	{
+		uint32_t o = p - w.q0; // offset into the window, if it applies
+		if (w.q0 == ~0u || t - p != w.s0 - w.q0 || p < w.q0 || o >= W) {
+			window_load(w, Q, S, p, t);
 			o = 0;
 		}
 		// first differing byte at or after o
@@ -166,11 +169,33 @@ __device__ __forceinline__ uint32_t window_lcp(Window<G> &w, g_u8p Q, g_u8p S, u
 		if (hit) {
 			uint32_t first = (uint32_t)__builtin_ctzll(hit);
 			uint32_t bit = (uint32_t)__shfl((int)__builtin_ctz(m | 0x10000u), (int)(Group<G>::base() + first));
-			len += 16 * first + bit - o;
+			len = 16 * first + bit - o;
+			return len < maxlen ? len : maxlen;
+		}
+		len = W - o;
+	}
+	while (len < maxlen) {
+		g_u8p a = Q + p + len + 16 * sub, b = S + t + len + 16 * sub;
+		constexpr int BULK = 2;
+		uint4 qa[BULK], sa[BULK];
+#pragma unroll
+		for (int u = 0; u < BULK; ++u) qa[u] = ld_u128_unaligned(a + u * W), sa[u] = ld_u128_unaligned(b + u * W);
+		uint32_t key = ~0u; // offset of this lane's first differing byte within the BULK windows
+#pragma unroll
+		for (int u = BULK - 1; u >= 0; --u) {
+			uint32_t f = first_diff_byte(make_uint4(qa[u].x ^ sa[u].x, qa[u].y ^ sa[u].y, qa[u].z ^ sa[u].z,
+													 qa[u].w ^ sa[u].w));
+			if (f < 16) key = u * W + 16 * sub + f;
+		}
+		for (int dlt = G / 2; dlt; dlt >>= 1) {
+			uint32_t other = (uint32_t)__shfl_xor((int)key, dlt);
+			key = other < key ? other : key;
+		}
+		if (key != ~0u) {
+			len += key;
 			break;
 		}
-		len += 16 * G - o;
-		if (len >= maxlen) break;
+		len += BULK * W;
 	}
 	return len < maxlen ? len : maxlen;
 }
