@@ -573,6 +573,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	auto *h_esa = (EsaDev *)ctx->desc_host;
 	auto *h_self = (int64_t *)(h_esa + nsub);
 	uint64_t pairs = 0, nt = 0;
+	int any_reference = 0;
 	// the index builds must have finished: their flags decide which walk is exact
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	for (size_t s = 0; s < nsub; ++s) {
@@ -588,6 +589,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			mode = ANDI_MODE_REFERENCE;
 			if (!e->ref_built && andi_hip_esa_build(ctx, e)) return 1;
 			ctx->acc.reference_subjects++;
+			any_reference = 1;
 		}
 		h_esa[s] = esa_view(e, mode);
 		h_self[s] = self ? self[s] : -1;
@@ -628,6 +630,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.owned = (uint32_t *)p;
 	a.M = M_dev;
 	a.fixups = ctx->d_fixups;
+	a.any_reference = any_reference;
 
 	{
 		Timed t(ctx, 1);

@@ -38,6 +38,7 @@ struct ScanArgs {
 	uint32_t *owned;       // [..][16] counts the true chain adds inside the segment
 	andi_hip_model *M;     // [nsub][nq]
 	unsigned long long *fixups;
+	int any_reference; // some subject is in ANDI_MODE_REFERENCE: launch the reference-walk kernels too
 };
 
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st);

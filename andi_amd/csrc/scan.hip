@@ -232,12 +232,12 @@ __device__ __forceinline__ Probe root_search(const EsaG &E, g_u8p q, uint32_t qr
 // ANDI_MODE_PROBE: the K-mer at Q[p] selects a probe-table entry that either is
 // the answer, or names the one suffix to extend along, or names a few suffixes
 // that the lanes of the group extend along in parallel.
-template <int G>
+template <int G, int MODE>
 __device__ __forceinline__ Probe probe_step(const PairCtx &c, uint32_t p, const Window<G> &w) {
 	const EsaG &E = c.E;
 	const uint32_t qrem = c.qlen - p, K = (uint32_t)E.deepK;
 	g_u8p q = c.Q + p;
-	if (E.mode == ANDI_MODE_REFERENCE) return reference_probe<G>(E, q, qrem);
+	if constexpr (MODE == ANDI_MODE_REFERENCE) return reference_probe<G>(E, q, qrem);
 	if (qrem <= K) return root_search<G>(E, q, qrem);
 
 	uint32_t code, valid;
@@ -301,7 +301,7 @@ __device__ __forceinline__ Probe probe_step(const PairCtx &c, uint32_t p, const 
 }
 
 // One trip of the while loop, src/process.c:153-197.  Uniform within the group.
-template <int G>
+template <int G, int MODE>
 __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st, uint32_t *hist,
 												 Window<G> &w) {
 	const uint32_t n = (uint32_t)c.E.n;
@@ -319,7 +319,7 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 	}
 	// anchor, src/process.c:113-123
 	if (!found) {
-		Probe pr = probe_step<G>(c, st.p, w);
+		Probe pr = probe_step<G, MODE>(c, st.p, w);
 		curS = pr.pos;
 		curLen = pr.len;
 		found = pr.unique && curLen >= c.thr;
@@ -387,9 +387,12 @@ __device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {
 }
 
 // ------------------------------------------------------------------ pass A
-template <int G>
+// MODE is a template parameter so that the kernel for probe-table subjects does
+// not carry the reference walk's code; blocks of the other mode's subjects exit.
+template <int G, int MODE>
 __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 	__shared__ uint32_t s_hist[BLOCK / G][16];
+	if (a.subjects[blockIdx.y].mode != MODE) return;
 	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
 	uint32_t *hist = s_hist[threadIdx.x / G];
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, (uint32_t)c.E.n);
 	Window<G> w;
 	w.q0 = ~0u;
-	while (st.p < it.end) st = chain_step<G>(c, st, hist, w);
+	while (st.p < it.end) st = chain_step<G, MODE>(c, st, hist, w);
 
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
 	uint32_t lane = Group<G>::sub();
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 // Replays the true chain (entering in state T) through [start, end) next to the
 // segment's cold chain.  On return T is the true chain's state on leaving the
 // segment and histT[0..16) the counts it added inside the segment.
-template <int G>
+template <int G, int MODE>
 __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, uint32_t start,
 											   uint32_t end, const ChainState &coldExit,
 											   const uint32_t *coldCounts, uint32_t *histT,
@@ -428,7 +431,7 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 		}
 		if (T.p >= end) break;
 		const bool stepT = C.p >= end || T.p <= C.p; // one call site keeps the code small
-		ChainState nx = chain_step<G>(c, stepT ? T : C, stepT ? histT : histC, w);
+		ChainState nx = chain_step<G, MODE>(c, stepT ? T : C, stepT ? histT : histC, w);
 		if (stepT) {
 			T = nx;
 		} else {
@@ -443,9 +446,10 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 }
 
 // ------------------------------------------------------------------ pass B
-template <int G>
+template <int G, int MODE>
 __global__ __launch_bounds__(BLOCK, 6) void k_scan_stitch(ScanArgs a) {
 	__shared__ uint32_t s_hist[BLOCK / G][2][16];
+	if (a.subjects[blockIdx.y].mode != MODE) return;
 	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_scan_stitch(ScanArgs a) {
 	uint32_t *histT = s_hist[threadIdx.x / G][0], *histC = s_hist[threadIdx.x / G][1];
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
 	ChainState T = a.cold_exit[slot - 1]; // assumed entry; verified in pass C
-	stitch_segment<G>(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
+	stitch_segment<G, MODE>(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
 					  histC);
 	if (lane == 0) a.true_exit[slot] = T;
 	for (uint32_t t = lane; t < 16; t += G) a.owned[slot * 16 + t] = histT[t];
@@ -514,8 +518,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 				uint32_t start = k * a.seg;
 				uint32_t e = start + a.seg;
 				uint32_t end = e < c.qlen ? e : c.qlen;
-				stitch_segment<64>(c, st, start, end, a.cold_exit[row + k],
-								   a.cold_counts + (row + k) * 16, histT, histC);
+				if (c.E.mode == ANDI_MODE_REFERENCE) {
+					stitch_segment<64, ANDI_MODE_REFERENCE>(c, st, start, end, a.cold_exit[row + k],
+															 a.cold_counts + (row + k) * 16, histT, histC);
+				} else {
+					stitch_segment<64, ANDI_MODE_PROBE>(c, st, start, end, a.cold_exit[row + k],
+														 a.cold_counts + (row + k) * 16, histT, histC);
+				}
 				if (lane < 16) total[lane] += histT[lane];
 			}
 		}
@@ -566,8 +575,12 @@ template <int G>
 static hipError_t launch_cold(const ScanArgs &a, hipStream_t st) {
 	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	k_scan_cold<G><<<grid, BLOCK, 0, st>>>(a);
+	k_scan_cold<G, ANDI_MODE_PROBE><<<grid, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
+	if (a.any_reference) {
+		k_scan_cold<G, ANDI_MODE_REFERENCE><<<grid, BLOCK, 0, st>>>(a);
+		CHECK_LAUNCH();
+	}
 	return hipSuccess;
 }
 
@@ -575,8 +588,12 @@ template <int G>
 static hipError_t launch_stitch(const ScanArgs &a, hipStream_t st) {
 	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	k_scan_stitch<G><<<grid, BLOCK, 0, st>>>(a);
+	k_scan_stitch<G, ANDI_MODE_PROBE><<<grid, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
+	if (a.any_reference) {
+		k_scan_stitch<G, ANDI_MODE_REFERENCE><<<grid, BLOCK, 0, st>>>(a);
+		CHECK_LAUNCH();
+	}
 	return hipSuccess;
 }
 
