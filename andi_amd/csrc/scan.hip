@@ -75,23 +75,32 @@ __device__ __forceinline__ ChainState cold_state(uint32_t start, uint32_t n) {
 	return s;
 }
 
-// model_count_equal for RAW/JC/Kimura, src/model.c:247-253
-template <int G>
-__device__ __forceinline__ void count_equal(uint32_t *hist, uint32_t len) {
-	static_assert(G >= 4, "needs four lanes");
-	uint32_t lane = Group<G>::sub();
-	if (lane < 4) atomicAdd(&hist[5 * lane], len / 4 + (lane == 3 ? (len & 3u) : 0u));
+// What a chain adds to the 4x4 matrix.  Substitutions between anchors go to a
+// per-group histogram in LDS; the equal runs of model_count_equal (RAW/JC/Kimura:
+// len/4 to A->A, C->C, G->G and len/4 + len%4 to T->T, src/model.c:247-253) are
+// two running sums in registers, folded into the histogram at the end.
+struct Tally {
+	uint32_t *hist; // LDS, 16 cells
+	uint32_t quarter, rest;
+};
+
+__device__ __forceinline__ void count_equal(Tally &t, uint32_t len) {
+	t.quarter += len >> 2;
+	t.rest += len & 3u;
 }
 
-// model_count, src/model.c:309-337
 template <int G>
-__device__ __forceinline__ void count_gap(uint32_t *hist, g_u8p s, g_u8p q,
-										  uint32_t len) {
-	for (uint32_t off = Group<G>::sub(); off < len; off += G) {
-		int8_t a = (int8_t)s[off], b = (int8_t)q[off];
-		if (a >= 'A' && b >= 'A')
-			atomicAdd(&hist[(nt_code((uint8_t)a) << 2) + nt_code((uint8_t)b)], 1u);
-	}
+__device__ __forceinline__ void tally_begin(Tally &t, uint32_t *hist) {
+	t.hist = hist, t.quarter = 0, t.rest = 0;
+	for (uint32_t c = Group<G>::sub(); c < 16; c += G) hist[c] = 0;
+}
+
+// value of cell c including the equal runs (call after the chain is done)
+__device__ __forceinline__ uint32_t tally_cell(const Tally &t, uint32_t c) {
+	uint32_t v = t.hist[c];
+	if (c == 0 || c == 5 || c == 10) v += t.quarter;
+	if (c == 15) v += t.quarter + t.rest;
+	return v;
 }
 
 // A chain spends most of its steps on one diagonal (query offset p against
@@ -149,17 +158,21 @@ __device__ __forceinline__ void window_load(Window<G> &w, g_u8p Q, g_u8p S, uint
 // lcp(Q + p, S + t, maxlen) (src/process.c:59-65) through the window.  A match that
 // runs past the window it started in is followed BULK windows at a time (2*BULK
 // independent loads in flight) instead of one dependent window after the other.
+// A window that has to be fetched starts `back` (<= 16) bytes before p, where the
+// gap since the last anchor begins: if this comparison yields a right anchor, the
+// gap's substitutions are then counted from the window too.
 template <int G>
 __device__ __forceinline__ uint32_t window_lcp(Window<G> &w, g_u8p Q, g_u8p S, uint32_t p, uint32_t t,
-											   uint32_t maxlen) {
+											   uint32_t maxlen, uint32_t back) {
 	constexpr uint32_t W = 16 * G;
 	const uint32_t sub = Group<G>::sub();
 	uint32_t len = 0;
 	{
 		uint32_t o = p - w.q0; // offset into the window, if it applies
 		if (w.q0 == ~0u || t - p != w.s0 - w.q0 || p < w.q0 || o >= W) {
-			window_load(w, Q, S, p, t);
-			o = 0;
+			if (back > 16) back = 16;
+			window_load(w, Q, S, p - back, t - back);
+			o = back;
 		}
 		// first differing byte at or after o
 		int sh = (int)o - (int)(16 * sub);
@@ -200,19 +213,24 @@ __device__ __forceinline__ uint32_t window_lcp(Window<G> &w, g_u8p Q, g_u8p S, u
 	return len < maxlen ? len : maxlen;
 }
 
-// model_count through the window when it covers Q[q..q+len) on its diagonal
+// model_count (src/model.c:309-337) of Q[q..q+len) against S[s..s+len), through the
+// window: the part it covers is counted from its 2-bit codes, for the rest the
+// window is moved along the gap.
 template <int G>
-__device__ __forceinline__ void window_count_gap(const Window<G> &w, uint32_t *hist, g_u8p Q, g_u8p S,
-												 uint32_t q, uint32_t s, uint32_t len) {
-	if (w.q0 != ~0u && s - q == w.s0 - w.q0 && q >= w.q0 && q + len <= w.q0 + 16 * G) {
-		const uint32_t lo = q - w.q0, hi = lo + len, mine = 16 * Group<G>::sub();
+__device__ __forceinline__ void window_count_gap(Window<G> &w, uint32_t *hist, g_u8p Q, g_u8p S, uint32_t q,
+												 uint32_t s, uint32_t len) {
+	constexpr uint32_t W = 16 * G;
+	const uint32_t mine = 16 * Group<G>::sub();
+	while (len) {
+		if (w.q0 == ~0u || s - q != w.s0 - w.q0 || q < w.q0 || q >= w.q0 + W) window_load(w, Q, S, q, s);
+		const uint32_t lo = q - w.q0, hi = lo + len < W ? lo + len : W;
 		uint32_t a = lo > mine ? lo - mine : 0, b = hi > mine ? (hi - mine < 16 ? hi - mine : 16) : 0;
 		const uint32_t both = (w.mask >> 16) & w.sv; // neither byte is a separator
 		for (uint32_t t = a; t < b; ++t)
 			if ((both >> t) & 1u)
 				atomicAdd(&hist[(((w.sc >> (30 - 2 * t)) & 3u) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)], 1u);
-	} else {
-		count_gap<G>(hist, S + s, Q + q, len);
+		const uint32_t done = hi - lo;
+		q += done, s += done, len -= done;
 	}
 }
 
@@ -302,7 +320,7 @@ __device__ __forceinline__ Probe probe_step(const PairCtx &c, uint32_t p, const 
 
 // One trip of the while loop, src/process.c:153-197.  Uniform within the group.
 template <int G, int MODE>
-__device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st, uint32_t *hist,
+__device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st, Tally &tally,
 												 Window<G> &w) {
 	const uint32_t n = (uint32_t)c.E.n;
 	uint32_t curS = 0, curLen = 0;
@@ -314,7 +332,7 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 	uint32_t tryS = st.lastS + advance;
 	if (tryS < n && gap <= c.thr) {
 		curS = tryS;
-		curLen = window_lcp<G>(w, c.Q, c.E.S, st.p, tryS, c.qlen - st.p);
+		curLen = window_lcp<G>(w, c.Q, c.E.S, st.p, tryS, c.qlen - st.p, gap);
 		found = curLen >= c.thr;
 	}
 	// anchor, src/process.c:113-123
@@ -330,11 +348,11 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 		uint32_t endQ = st.lastQ + st.lastLen;
 		if (curS > endS && st.p - endQ == curS - endS &&
 			(curS < c.border) == (st.lastS < c.border)) {
-			count_equal<G>(hist, st.lastLen);
-			window_count_gap<G>(w, hist, c.Q, c.E.S, endQ, endS, st.p - endQ);
+			count_equal(tally, st.lastLen);
+			window_count_gap<G>(w, tally.hist, c.Q, c.E.S, endQ, endS, st.p - endQ);
 			st.lwra = 1;
 		} else {
-			if (st.lwra || st.lastLen >= 2 * c.thr) count_equal<G>(hist, st.lastLen);
+			if (st.lwra || st.lastLen >= 2 * c.thr) count_equal(tally, st.lastLen);
 			st.lwra = 0;
 		}
 		st.lastS = curS;
@@ -343,11 +361,6 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 	}
 	st.p += curLen + 1;
 	return st;
-}
-
-template <int G>
-__device__ __forceinline__ void hist_zero(uint32_t *hist) {
-	for (uint32_t t = Group<G>::sub(); t < 16; t += G) hist[t] = 0;
 }
 
 struct WorkItem {
@@ -395,19 +408,19 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 	if (a.subjects[blockIdx.y].mode != MODE) return;
 	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
-	uint32_t *hist = s_hist[threadIdx.x / G];
-	hist_zero<G>(hist);
+	Tally tally;
+	tally_begin<G>(tally, s_hist[threadIdx.x / G]);
 
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
 	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, (uint32_t)c.E.n);
 	Window<G> w;
 	w.q0 = ~0u;
-	while (st.p < it.end) st = chain_step<G, MODE>(c, st, hist, w);
+	while (st.p < it.end) st = chain_step<G, MODE>(c, st, tally, w);
 
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
 	uint32_t lane = Group<G>::sub();
 	if (lane == 0) a.cold_exit[slot] = st;
-	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = hist[t];
+	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = tally_cell(tally, t);
 }
 
 // Replays the true chain (entering in state T) through [start, end) next to the
@@ -418,8 +431,9 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 											   uint32_t end, const ChainState &coldExit,
 											   const uint32_t *coldCounts, uint32_t *histT,
 											   uint32_t *histC) {
-	hist_zero<G>(histT);
-	hist_zero<G>(histC);
+	Tally tT, tC;
+	tally_begin<G>(tT, histT);
+	tally_begin<G>(tC, histC);
 	ChainState C = cold_state(start, (uint32_t)c.E.n);
 	Window<G> w; // shared by both chains: they run next to each other
 	w.q0 = ~0u;
@@ -431,18 +445,22 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 		}
 		if (T.p >= end) break;
 		const bool stepT = C.p >= end || T.p <= C.p; // one call site keeps the code small
-		ChainState nx = chain_step<G, MODE>(c, stepT ? T : C, stepT ? histT : histC, w);
+		Tally tx = stepT ? tT : tC;
+		ChainState nx = chain_step<G, MODE>(c, stepT ? T : C, tx, w);
 		if (stepT) {
-			T = nx;
+			T = nx, tT = tx;
 		} else {
-			C = nx;
+			C = nx, tC = tx;
 		}
 	}
-	if (synced) {
-		// from the meeting point on, the cold chain's trajectory is the true one
-		for (uint32_t t = Group<G>::sub(); t < 16; t += G) histT[t] += coldCounts[t] - histC[t];
-		T = coldExit;
+	// fold the equal runs in; from the meeting point on, the cold chain's
+	// trajectory is the true one
+	for (uint32_t t = Group<G>::sub(); t < 16; t += G) {
+		uint32_t v = tally_cell(tT, t);
+		if (synced) v += coldCounts[t] - tally_cell(tC, t);
+		histT[t] = v;
 	}
+	if (synced) T = coldExit;
 }
 
 // ------------------------------------------------------------------ pass B
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 
 	uint32_t *total = s_hist[threadIdx.x >> 6][0];
 	uint32_t *histT = s_hist[threadIdx.x >> 6][1], *histC = s_hist[threadIdx.x >> 6][2];
-	hist_zero<64>(total);
+	if (lane < 16) total[lane] = 0;
 
 	const uint32_t base = a.qseg_start[qidx];
 	const uint32_t nseg = a.qseg_start[qidx + 1] - base;
@@ -532,12 +550,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	}
 
 	// src/process.c:199-211
+	Tally last;
+	last.hist = total, last.quarter = 0, last.rest = 0;
 	if (fin.lastLen >= c.qlen) {
-		count_equal<64>(total, c.qlen);
+		count_equal(last, c.qlen);
 	} else if (fin.lwra || fin.lastLen >= 2 * c.thr) {
-		count_equal<64>(total, fin.lastLen);
+		count_equal(last, fin.lastLen);
 	}
-	if (lane < 16) out->counts[lane] = total[lane];
+	if (lane < 16) out->counts[lane] = tally_cell(last, lane);
 	if (lane == 0) out->seq_len = c.qlen;
 }
 
@@ -566,7 +586,7 @@ static int scan_group() {
 	static int g = [] {
 		const char *e = getenv("ANDI_SCAN_G");
 		int v = e ? atoi(e) : SCAN_G;
-		return (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : SCAN_G;
+		return (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : SCAN_G;
 	}();
 	return g;
 }
@@ -599,21 +619,25 @@ static hipError_t launch_stitch(const ScanArgs &a, hipStream_t st) {
 
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
 	switch (scan_group()) {
+		case 2: return launch_cold<2>(a, st);
 		case 4: return launch_cold<4>(a, st);
+		case 8: return launch_cold<8>(a, st);
 		case 16: return launch_cold<16>(a, st);
 		case 32: return launch_cold<32>(a, st);
 		case 64: return launch_cold<64>(a, st);
-		default: return launch_cold<8>(a, st);
+		default: return launch_cold<SCAN_G>(a, st);
 	}
 }
 
 hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
 	switch (scan_group()) {
+		case 2: return launch_stitch<2>(a, st);
 		case 4: return launch_stitch<4>(a, st);
+		case 8: return launch_stitch<8>(a, st);
 		case 16: return launch_stitch<16>(a, st);
 		case 32: return launch_stitch<32>(a, st);
 		case 64: return launch_stitch<64>(a, st);
-		default: return launch_stitch<8>(a, st);
+		default: return launch_stitch<SCAN_G>(a, st);
 	}
 }
 
