@@ -80,8 +80,9 @@ __device__ __forceinline__ ChainState cold_state(uint32_t start, uint32_t n) {
 // len/4 to A->A, C->C, G->G and len/4 + len%4 to T->T, src/model.c:247-253) are
 // two running sums in registers, folded into the histogram at the end.
 struct Tally {
-	uint32_t *hist; // LDS, 16 cells
-	uint32_t quarter, rest;
+	uint32_t *hist;        // LDS, 16 cells: substitutions found in gaps
+	uint32_t quarter, rest; // equal runs (uniform within the group)
+	uint32_t same[4];      // A->A, C->C, G->G, T->T pairs this lane saw in gaps
 };
 
 __device__ __forceinline__ void count_equal(Tally &t, uint32_t len) {
@@ -92,15 +93,25 @@ __device__ __forceinline__ void count_equal(Tally &t, uint32_t len) {
 template <int G>
 __device__ __forceinline__ void tally_begin(Tally &t, uint32_t *hist) {
 	t.hist = hist, t.quarter = 0, t.rest = 0;
+	t.same[0] = t.same[1] = t.same[2] = t.same[3] = 0;
 	for (uint32_t c = Group<G>::sub(); c < 16; c += G) hist[c] = 0;
 }
 
-// value of cell c including the equal runs (call after the chain is done)
-__device__ __forceinline__ uint32_t tally_cell(const Tally &t, uint32_t c) {
-	uint32_t v = t.hist[c];
-	if (c == 0 || c == 5 || c == 10) v += t.quarter;
-	if (c == 15) v += t.quarter + t.rest;
-	return v;
+// Fold the register-held parts into the LDS histogram (once, when the chain is done).
+template <int G>
+__device__ __forceinline__ void tally_finish(Tally &t) {
+#pragma unroll
+	for (int x = 0; x < 4; ++x) {
+		uint32_t v = t.same[x];
+		for (int d = G / 2; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+		t.same[x] = v;
+	}
+	if (Group<G>::sub() == 0) {
+		t.hist[0] += t.quarter + t.same[0];
+		t.hist[5] += t.quarter + t.same[1];
+		t.hist[10] += t.quarter + t.same[2];
+		t.hist[15] += t.quarter + t.rest + t.same[3];
+	}
 }
 
 // A chain spends most of its steps on one diagonal (query offset p against
@@ -217,7 +228,7 @@ __device__ __forceinline__ uint32_t window_lcp(Window<G> &w, g_u8p Q, g_u8p S, u
 // window: the part it covers is counted from its 2-bit codes, for the rest the
 // window is moved along the gap.
 template <int G>
-__device__ __forceinline__ void window_count_gap(Window<G> &w, uint32_t *hist, g_u8p Q, g_u8p S, uint32_t q,
+__device__ __forceinline__ void window_count_gap(Window<G> &w, Tally &tally, g_u8p Q, g_u8p S, uint32_t q,
 												 uint32_t s, uint32_t len) {
 	constexpr uint32_t W = 16 * G;
 	const uint32_t mine = 16 * Group<G>::sub();
@@ -225,10 +236,27 @@ __device__ __forceinline__ void window_count_gap(Window<G> &w, uint32_t *hist, g
 		if (w.q0 == ~0u || s - q != w.s0 - w.q0 || q < w.q0 || q >= w.q0 + W) window_load(w, Q, S, q, s);
 		const uint32_t lo = q - w.q0, hi = lo + len < W ? lo + len : W;
 		uint32_t a = lo > mine ? lo - mine : 0, b = hi > mine ? (hi - mine < 16 ? hi - mine : 16) : 0;
-		const uint32_t both = (w.mask >> 16) & w.sv; // neither byte is a separator
-		for (uint32_t t = a; t < b; ++t)
-			if ((both >> t) & 1u)
-				atomicAdd(&hist[(((w.sc >> (30 - 2 * t)) & 3u) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)], 1u);
+		// this lane's gap bytes where neither string has a separator (model.c:318-320)
+		uint32_t range = b > a ? ((0xffffu >> (16 - (b - a))) << a) : 0u;
+		uint32_t both = (w.mask >> 16) & w.sv & range;
+		// equal pairs (the bulk of a gap): per nucleotide by population count.  Byte t
+		// of the lane sits at bits 31-2t..30-2t of the code words.
+		uint32_t eq = both & ~w.mask & 0xffffu;
+		uint32_t m = __brev(eq) >> 16; // byte t -> bit 15-t
+		m = (m | (m << 8)) & 0x00ff00ffu;
+		m = (m | (m << 4)) & 0x0f0f0f0fu;
+		m = (m | (m << 2)) & 0x33333333u;
+		m = (m | (m << 1)) & 0x55555555u; // byte t -> bit 30-2t
+		uint32_t c0 = w.qc & m, c1 = (w.qc >> 1) & m; // low / high code bit of the selected bytes
+		tally.same[0] += (uint32_t)__builtin_popcount(m & ~(c0 | c1));
+		tally.same[1] += (uint32_t)__builtin_popcount(c0 & ~c1);
+		tally.same[2] += (uint32_t)__builtin_popcount(c1 & ~c0);
+		tally.same[3] += (uint32_t)__builtin_popcount(c0 & c1);
+		// substitutions: one LDS add each
+		for (uint32_t d = both & w.mask & 0xffffu; d; d &= d - 1) {
+			uint32_t t = (uint32_t)__builtin_ctz(d);
+			atomicAdd(&tally.hist[(((w.sc >> (30 - 2 * t)) & 3u) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)], 1u);
+		}
 		const uint32_t done = hi - lo;
 		q += done, s += done, len -= done;
 	}
@@ -349,7 +377,7 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 		if (curS > endS && st.p - endQ == curS - endS &&
 			(curS < c.border) == (st.lastS < c.border)) {
 			count_equal(tally, st.lastLen);
-			window_count_gap<G>(w, tally.hist, c.Q, c.E.S, endQ, endS, st.p - endQ);
+			window_count_gap<G>(w, tally, c.Q, c.E.S, endQ, endS, st.p - endQ);
 			st.lwra = 1;
 		} else {
 			if (st.lwra || st.lastLen >= 2 * c.thr) count_equal(tally, st.lastLen);
@@ -420,7 +448,8 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
 	uint32_t lane = Group<G>::sub();
 	if (lane == 0) a.cold_exit[slot] = st;
-	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = tally_cell(tally, t);
+	tally_finish<G>(tally);
+	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = tally.hist[t];
 }
 
 // Replays the true chain (entering in state T) through [start, end) next to the
@@ -453,14 +482,12 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 			C = nx, tC = tx;
 		}
 	}
-	// fold the equal runs in; from the meeting point on, the cold chain's
-	// trajectory is the true one
-	for (uint32_t t = Group<G>::sub(); t < 16; t += G) {
-		uint32_t v = tally_cell(tT, t);
-		if (synced) v += coldCounts[t] - tally_cell(tC, t);
-		histT[t] = v;
+	tally_finish<G>(tT);
+	tally_finish<G>(tC);
+	if (synced) { // from the meeting point on, the cold chain's trajectory is the true one
+		for (uint32_t t = Group<G>::sub(); t < 16; t += G) histT[t] += coldCounts[t] - histC[t];
+		T = coldExit;
 	}
-	if (synced) T = coldExit;
 }
 
 // ------------------------------------------------------------------ pass B
@@ -552,12 +579,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	// src/process.c:199-211
 	Tally last;
 	last.hist = total, last.quarter = 0, last.rest = 0;
+	last.same[0] = last.same[1] = last.same[2] = last.same[3] = 0;
 	if (fin.lastLen >= c.qlen) {
 		count_equal(last, c.qlen);
 	} else if (fin.lwra || fin.lastLen >= 2 * c.thr) {
 		count_equal(last, fin.lastLen);
 	}
-	if (lane < 16) out->counts[lane] = tally_cell(last, lane);
+	tally_finish<64>(last);
+	if (lane < 16) out->counts[lane] = total[lane];
 	if (lane == 0) out->seq_len = c.qlen;
 }
 
