@@ -62,6 +62,7 @@ struct andi_hip_esa {
 	int32_t *min_scratch = nullptr;
 	uint2 *deep = nullptr;
 	uint32_t *rec = nullptr;
+	uint32_t *P2 = nullptr, *V = nullptr; // packed text for the index build
 	int32_t *flags = nullptr;   // device, 4 ints
 	int32_t *h_flags = nullptr; // pinned host copy, refreshed after every index build
 	int32_t deepK = 0;
@@ -180,7 +181,7 @@ int pick_deep_k(size_t n) {
 EsaBuildArgs build_args(const andi_hip_esa *e) {
 	EsaBuildArgs a;
 	a.S = e->S, a.SA = e->SA, a.LCP = e->LCP, a.CLD = e->CLD, a.FVC = e->FVC, a.tab = e->tab;
-	a.deep = e->deep, a.rec = e->rec, a.flags = e->flags, a.deepK = e->deepK;
+	a.deep = e->deep, a.rec = e->rec, a.P2 = e->P2, a.V = e->V, a.flags = e->flags, a.deepK = e->deepK;
 	a.min_scratch = e->min_scratch;
 	a.n = e->n;
 	return a;
@@ -304,6 +305,8 @@ int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, siz
 	chk(dmalloc(&e->SA, n));
 	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
 	chk(dmalloc(&e->rec, n));
+	chk(dmalloc(&e->P2, (n + 1) / 16 + 8));
+	chk(dmalloc(&e->V, (n + 1) / 32 + 8));
 	chk(dmalloc(&e->flags, 4));
 	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault));
 	e->bytes = (n + 1 + ANDI_PAD) + 4 * n + 8 * deep_entries + 4 * n + 16;
@@ -404,6 +407,8 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	(void)hipFree(e->tab);
 	(void)hipFree(e->deep);
 	(void)hipFree(e->rec);
+	(void)hipFree(e->P2);
+	(void)hipFree(e->V);
 	(void)hipFree(e->flags);
 	(void)hipFree(e->min_scratch);
 	if (e->h_flags) (void)hipHostFree(e->h_flags);

@@ -14,6 +14,7 @@
 //   K2b child_table   CLD from nearest-smaller-value searches  (src/esa.c:312-363)
 //   K4  kmer_table    4^10 interval table, one thread per 10-mer (src/esa.c:73-215)
 // and the scan index (see "scan index" below):
+//   K5p pack_text        2-bit codes + ACGT bitmap of the text (L2-sized)
 //   K5a suffix_prefixes  K-mer code and valid length of every suffix
 //   K5b probe_table      4^K outcome table, one thread per suffix-array gap
 #include "andi_dev.h"
@@ -268,30 +269,54 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 #define REC_SEP(x) (((x) >> 4) & 3u)
 #define REC_CODE(x) ((x) >> 6)
 
+// K5p: 2-bit codes (16 per word, first character in the top bits) and an ACGT
+// bitmap (32 per word, first character in the top bit) of the text.  Together
+// 3 bits per character = 3.7 MB for a 9.8 M-character RS: the per-suffix random
+// reads of k_suffix_prefixes then mostly stay inside one XCD's L2.
+__global__ __launch_bounds__(256) void k_pack_text(const uint8_t *__restrict__ Sd, uint32_t *__restrict__ P2,
+												   uint32_t *__restrict__ V, int64_t words32) {
+	int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // 32 characters per thread
+	if (j >= words32) return;
+	g_u8p S = (g_u8p)Sd + 32 * j; // padding behind the text reads as NUL = not ACGT
+	uint32_t code[2], ok = 0;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		uint4 w = ld_u128_unaligned(S + 16 * h);
+		uint32_t words[4] = {w.x, w.y, w.z, w.w};
+		uint32_t c = 0;
+#pragma unroll
+		for (int d = 0; d < 4; ++d) {
+			uint32_t x = words[d] & 0x06060606u;
+			x ^= x >> 1;
+			x = (x >> 1) & 0x03030303u;
+			c = (c << 8) | ((x & 0xffu) << 6) | (((x >> 8) & 0xffu) << 4) | (((x >> 16) & 0xffu) << 2) | (x >> 24);
+			uint32_t m = words[d] & 0x40404040u; // bit 6: ACGT
+			ok = (ok << 4) | (((m >> 6) & 1u) << 3) | (((m >> 14) & 1u) << 2) | (((m >> 22) & 1u) << 1) | ((m >> 30) & 1u);
+		}
+		code[h] = c;
+	}
+	P2[2 * j] = code[0], P2[2 * j + 1] = code[1];
+	V[j] = ok;
+}
+
 __global__ __launch_bounds__(256) void k_suffix_prefixes(const uint8_t *__restrict__ Sd,
+														 const uint32_t *__restrict__ P2,
+														 const uint32_t *__restrict__ V,
 														 const int32_t *__restrict__ SA,
 														 uint32_t *__restrict__ rec, int32_t n, int K) {
 	int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n) return;
-	g_u8p S = (g_u8p)Sd;
-	uint4 w = ld_u128_unaligned(S + SA[r]); // bytes past the text are NUL padding
-	// per byte: bit 6 set <=> ACGT
-	uint32_t valid = 0; // bit t set <=> byte t is ACGT
-	uint32_t words[4] = {w.x, w.y, w.z, w.w};
-	uint32_t code = 0;
-#pragma unroll
-	for (int d = 0; d < 4; ++d) {
-		uint32_t x = words[d] & 0x06060606u;
-		x ^= x >> 1;
-		x = (x >> 1) & 0x03030303u;
-		code = (code << 8) | ((x & 0xffu) << 6) | (((x >> 8) & 0xffu) << 4) | (((x >> 16) & 0xffu) << 2) | (x >> 24);
-		uint32_t m = words[d] & 0x40404040u;
-		valid |= (((m >> 6) & 1u) | ((m >> 13) & 2u) | ((m >> 20) & 4u) | ((m >> 27) & 8u)) << (4 * d);
-	}
-	uint32_t v = (uint32_t)__builtin_ctz(~valid); // leading ACGT characters, 0..16
+	const uint32_t p = (uint32_t)SA[r];
+	// 16 codes starting at p
+	uint64_t cw = ((uint64_t)P2[p >> 4] << 32) | P2[(p >> 4) + 1];
+	uint32_t code = (uint32_t)((cw << (2 * (p & 15u))) >> 32);
+	// ACGT flags of the 32 characters starting at p, first character in the top bit
+	uint64_t vw = ((uint64_t)V[p >> 5] << 32) | V[(p >> 5) + 1];
+	uint32_t valid = (uint32_t)((vw << (p & 31u)) >> 32);
+	uint32_t v = (uint32_t)__builtin_clz(~valid | 1u); // leading ACGT characters
 	uint32_t sep = 0;
 	if (v < (uint32_t)K) {
-		uint8_t c = (uint8_t)(words[v >> 2] >> (8 * (v & 3u)));
+		uint8_t c = ((g_u8p)Sd)[p + v]; // rare: suffix within K characters of a separator
 		sep = c == '!' ? 1u : (c == ';' ? 2u : 3u);
 	} else {
 		v = (uint32_t)K;
@@ -422,7 +447,10 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
 	auto blocks = [&](int64_t items) { return (unsigned)((items + B - 1) / B); };
 	hipError_t e = hipMemsetAsync(a.flags, 0, 2 * sizeof(int32_t), st);
 	if (e != hipSuccess) return e;
-	k_suffix_prefixes<<<blocks(n), B, 0, st>>>(a.S, a.SA, a.rec, n, a.deepK);
+	const int64_t words32 = ((int64_t)n + 1 + 31) / 32 + 1; // one spare word: two-word reads at the end
+	k_pack_text<<<blocks(words32), B, 0, st>>>(a.S, a.P2, a.V, words32);
+	CHECK_LAUNCH();
+	k_suffix_prefixes<<<blocks(n), B, 0, st>>>(a.S, a.P2, a.V, a.SA, a.rec, n, a.deepK);
 	CHECK_LAUNCH();
 	k_probe_table<<<blocks((int64_t)n + 1), B, 0, st>>>(a.rec, a.SA, a.deep, a.flags, n, a.deepK);
 	CHECK_LAUNCH();

@@ -249,9 +249,12 @@ class Esa:
     builds the scan index (build="index", default) and/or the reference's own
     arrays LCP, CLD, FVC, 10-mer table (build="reference")."""
 
-    def __init__(self, ctx: Context, seq: bytes, p_value=0.025, sa=None, build="index"):
+    def __init__(self, ctx: Context, seq: bytes, p_value=0.025, sa=None, build="index", prepared=None):
         self.ctx = ctx
-        self.RS, self.gc, self.threshold = subject_prepare(seq, p_value)
+        if prepared is not None:  # (RS, gc, threshold, SA) from prepare_host(), e.g. made in a thread pool
+            self.RS, self.gc, self.threshold, sa = prepared
+        else:
+            self.RS, self.gc, self.threshold = subject_prepare(seq, p_value)
         self.n = len(self.RS)
         self.SA = suffix_array(self.RS) if sa is None else np.ascontiguousarray(sa, dtype=np.int32)
         self._h = _P()
@@ -303,6 +306,14 @@ class Esa:
             self.close()
         except Exception:
             pass
+
+
+def prepare_host(seq: bytes, p_value=0.025):
+    """The host part of esa_init for one subject: RS, gc, threshold and the suffix
+    array.  ctypes releases the GIL, so a ThreadPool runs these in parallel (the
+    role of the OpenMP subject loop, src/dist_hack.h:46-52)."""
+    RS, gc, thr = subject_prepare(seq, p_value)
+    return RS, gc, thr, suffix_array(RS)
 
 
 class Queries:
