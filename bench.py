@@ -89,7 +89,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the anchor-distance engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run also with one rank
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -125,11 +126,11 @@ def main():
             e.build()  # device index build
         lib.scan_rows_dev(ctx, esas, selfs, Q, model, args.segment, dptr)  # anchor scan
         ctx.sync()  # the engine's stream is not torch's: finish before the collective
-        if world > 1:  # RCCL over xGMI: the one exchange of the job, 68 B per ordered pair
-            gathered[0] = shard.gather_matrix(block, G, dist, world, rank)
+        if use_dist:  # RCCL over xGMI: the one exchange of the job, 68 B per ordered pair
+            gathered[0] = shard.gather_matrix(block, G, dist, world, rank, force=True)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +144,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     tm = ctx.timings()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -170,7 +171,7 @@ def main():
 
     out = None
     if rank == 0:
-        full = shard.gather_matrix(block, G) if world == 1 else gathered[0]
+        full = gathered[0] if use_dist else shard.gather_matrix(block, G)
         dmat = [andi_amd.estimate(full[0, j].astype(np.uint64) + full[j, 0], model) for j in range(1, min(G, 4))]
         out = {
             "metric": "genome-pairs/sec (ordered pairs, n^2-n) over the N x N anchor-distance loop",
@@ -206,7 +207,7 @@ def main():
         e.close()
     Q.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
