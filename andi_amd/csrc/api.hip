@@ -546,10 +546,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		if (ctx) ctx->err = "andi_hip_scan_rows: bad arguments";
 		return 1;
 	}
-	if (model != ANDI_M_RAW && model != ANDI_M_JC && model != ANDI_M_KIMURA) {
-		// LogDet/ANI count anchor bytes individually (src/model.c:256-278);
-		// that variant of the equal-run attribution is not on the device yet.
-		ctx->err = "andi_hip_scan_rows: only the RAW, JC and Kimura models are supported";
+	if (model < ANDI_M_RAW || model > ANDI_M_ANI) {
+		ctx->err = "andi_hip_scan_rows: unknown model";
 		return 1;
 	}
 	auto *q = const_cast<andi_hip_queries *>(q_const);
@@ -636,6 +634,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.M = M_dev;
 	a.fixups = ctx->d_fixups;
 	a.any_reference = any_reference;
+	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 
 	{
 		Timed t(ctx, 1);

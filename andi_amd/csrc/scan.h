@@ -38,6 +38,7 @@ struct ScanArgs {
 	uint32_t *owned;       // [..][16] counts the true chain adds inside the segment
 	andi_hip_model *M;     // [nsub][nq]
 	unsigned long long *fixups;
+	int exact_equal;   // LogDet/ANI: count the nucleotides of every anchor (src/model.c:256-278)
 	int any_reference; // some subject is in ANDI_MODE_REFERENCE: launch the reference-walk kernels too
 };
 

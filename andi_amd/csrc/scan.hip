@@ -50,6 +50,7 @@ struct PairCtx {
 	uint32_t qlen;
 	uint32_t thr;
 	uint32_t border; // n / 2, src/process.c:149
+	bool exact;      // LogDet/ANI: equal runs are counted per nucleotide (src/model.c:256-278)
 };
 
 __device__ __forceinline__ bool same_state(const ChainState &a, const ChainState &b) {
@@ -153,6 +154,39 @@ __device__ __forceinline__ void codes16(uint4 v, uint32_t &code, uint32_t &valid
 	valid = ok4(v.x) | (ok4(v.y) << 4) | (ok4(v.z) << 8) | (ok4(v.w) << 12);
 }
 
+// same[x] += number of selected bytes (bit t of sel16 = byte t) whose 2-bit code is x;
+// byte t of a 16-byte chunk sits at bits 31-2t..30-2t of `code`
+__device__ __forceinline__ void add_composition(uint32_t code, uint32_t sel16, uint32_t *same) {
+	uint32_t m = __brev(sel16) >> 16; // byte t -> bit 15-t
+	m = (m | (m << 8)) & 0x00ff00ffu;
+	m = (m | (m << 4)) & 0x0f0f0f0fu;
+	m = (m | (m << 2)) & 0x33333333u;
+	m = (m | (m << 1)) & 0x55555555u; // byte t -> bit 30-2t
+	uint32_t c0 = code & m, c1 = (code >> 1) & m; // low / high code bit of the selected bytes
+	same[0] += (uint32_t)__builtin_popcount(m & ~(c0 | c1));
+	same[1] += (uint32_t)__builtin_popcount(c0 & ~c1);
+	same[2] += (uint32_t)__builtin_popcount(c1 & ~c0);
+	same[3] += (uint32_t)__builtin_popcount(c0 & c1);
+}
+
+// model_count_equal (src/model.c:246-279) for the anchor Q[qpos..qpos+len).  RAW, JC and
+// Kimura split the length evenly; LogDet and ANI count the anchor's nucleotides, which
+// streams the anchor once more (16 bytes per lane and step).
+template <int G>
+__device__ __forceinline__ void count_anchor(const PairCtx &c, Tally &t, uint32_t qpos, uint32_t len) {
+	if (!c.exact) {
+		count_equal(t, len);
+		return;
+	}
+	for (uint32_t off = 16 * Group<G>::sub(); off < len; off += 16 * G) {
+		uint32_t code, valid;
+		codes16(ld_u128_unaligned(c.Q + qpos + off), code, valid);
+		uint32_t left = len - off;
+		if (left < 16) valid &= (1u << left) - 1u;
+		add_composition(code, valid, t.same);
+	}
+}
+
 template <int G>
 __device__ __forceinline__ void window_load(Window<G> &w, g_u8p Q, g_u8p S, uint32_t q0, uint32_t s0) {
 	const uint32_t sub = Group<G>::sub();
@@ -241,17 +275,7 @@ __device__ __forceinline__ void window_count_gap(Window<G> &w, Tally &tally, g_u
 		uint32_t both = (w.mask >> 16) & w.sv & range;
 		// equal pairs (the bulk of a gap): per nucleotide by population count.  Byte t
 		// of the lane sits at bits 31-2t..30-2t of the code words.
-		uint32_t eq = both & ~w.mask & 0xffffu;
-		uint32_t m = __brev(eq) >> 16; // byte t -> bit 15-t
-		m = (m | (m << 8)) & 0x00ff00ffu;
-		m = (m | (m << 4)) & 0x0f0f0f0fu;
-		m = (m | (m << 2)) & 0x33333333u;
-		m = (m | (m << 1)) & 0x55555555u; // byte t -> bit 30-2t
-		uint32_t c0 = w.qc & m, c1 = (w.qc >> 1) & m; // low / high code bit of the selected bytes
-		tally.same[0] += (uint32_t)__builtin_popcount(m & ~(c0 | c1));
-		tally.same[1] += (uint32_t)__builtin_popcount(c0 & ~c1);
-		tally.same[2] += (uint32_t)__builtin_popcount(c1 & ~c0);
-		tally.same[3] += (uint32_t)__builtin_popcount(c0 & c1);
+		add_composition(w.qc, both & ~w.mask & 0xffffu, tally.same);
 		// substitutions: one LDS add each
 		for (uint32_t d = both & w.mask & 0xffffu; d; d &= d - 1) {
 			uint32_t t = (uint32_t)__builtin_ctz(d);
@@ -376,11 +400,11 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 		uint32_t endQ = st.lastQ + st.lastLen;
 		if (curS > endS && st.p - endQ == curS - endS &&
 			(curS < c.border) == (st.lastS < c.border)) {
-			count_equal(tally, st.lastLen);
+			count_anchor<G>(c, tally, st.lastQ, st.lastLen);
 			window_count_gap<G>(w, tally, c.Q, c.E.S, endQ, endS, st.p - endQ);
 			st.lwra = 1;
 		} else {
-			if (st.lwra || st.lastLen >= 2 * c.thr) count_equal(tally, st.lastLen);
+			if (st.lwra || st.lastLen >= 2 * c.thr) count_anchor<G>(c, tally, st.lastQ, st.lastLen);
 			st.lwra = 0;
 		}
 		st.lastS = curS;
@@ -403,6 +427,7 @@ __device__ __forceinline__ PairCtx make_ctx(const ScanArgs &a, uint32_t sub, uin
 	c.qlen = a.qlen[qidx];
 	c.thr = (uint32_t)c.E.thr;
 	c.border = (uint32_t)c.E.n / 2;
+	c.exact = a.exact_equal != 0;
 	return c;
 }
 
@@ -581,9 +606,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	last.hist = total, last.quarter = 0, last.rest = 0;
 	last.same[0] = last.same[1] = last.same[2] = last.same[3] = 0;
 	if (fin.lastLen >= c.qlen) {
-		count_equal(last, c.qlen);
+		count_anchor<64>(c, last, 0, c.qlen);
 	} else if (fin.lwra || fin.lastLen >= 2 * c.thr) {
-		count_equal(last, fin.lastLen);
+		count_anchor<64>(c, last, fin.lastQ, fin.lastLen);
 	}
 	tally_finish<64>(last);
 	if (lane < 16) out->counts[lane] = total[lane];

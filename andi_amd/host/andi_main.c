@@ -403,9 +403,6 @@ int main(int argc, char *argv[]) {
 	if (any_short)
 		soft_warnx("One of the given input sequences is shorter than a thousand nucleotides. This may result "
 				   "in inaccurate distances. Try an alignment instead.");
-	if (opts.model == ANDI_M_LOGDET || opts.model == ANDI_M_ANI)
-		errx(1, "The %s model is not available on the GPU path yet (it counts anchor characters one by one); "
-				"use Raw, JC or Kimura.", opts.model == ANDI_M_LOGDET ? "LogDet" : "ANI");
 
 	if (progress == P_AUTO) progress = isatty(STDERR_FILENO) ? P_ALWAYS : P_NEVER;
 	if (progress == P_ALWAYS) {

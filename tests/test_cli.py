@@ -43,8 +43,6 @@ def test_cli_usage_and_validation(tmp_path):
     rc, out, err = run([empty])
     assert rc == 1 and "The sequence B is empty." in err and "other than acgtACGT" in err  # src/andi.c:302-304,282
     two = fasta(tmp_path / "two.fa", [("A", b"ACGTACGTAC"), ("B", b"ACGTACGTAA")])
-    rc, out, err = run(["-m", "LogDet", two])
-    assert rc == 1 and "LogDet" in err
     rc, out, err = run(["-p", "7", "-m", "nope", "-b", "x", "--version"])
     assert "between 0 and 1, exclusive" in err and "Ignoring argument for --model" in err
     assert "Expected a positive number for -b" in err
@@ -83,6 +81,9 @@ def test_cli_matrix_equals_oracle_and_options_agree(tmp_path, orc):
     # models, -v coverage block, -vv asymmetry
     rc, raw, _ = run(["-m", "Raw", f])
     assert raw.splitlines()[1].split()[2] == "%1.4f" % orc.estimate(M[0, 1].astype(np.uint64) + M[1, 0], orc.M_RAW)
+    rc, ani, _ = run(["-m", "ANI", f])
+    assert ani.splitlines()[1].split()[2] == "%1.4f" % orc.estimate(
+        orc.dist_matrix(seqs, model=orc.M_ANI, threads=4)[[0, 1], [1, 0]].astype(np.uint64).sum(axis=0), orc.M_ANI)
     rc, v, _ = run(["-v", f])
     assert v.startswith(out) and "\nCoverage:\n" in v
     assert v.split("Coverage:\n")[1].splitlines()[0].split()[1] == "%1.4e" % orc.coverage(M[0, 1])

@@ -144,7 +144,7 @@ def test_repeats_and_models(ctx, orc):
     g = rand_dna(rng, 30000) + unit + rand_dna(rng, 20000) + unit + rand_dna(rng, 10000) + unit
     codes = np.frombuffer(g.translate(bytes.maketrans(b"ACGT", bytes(range(4)))), np.uint8)
     h = synth.to_bytes(synth.mutate_codes(codes, 0.02, 4))
-    for model in (0, 1, 2):
+    for model in (0, 1, 2, 3, 4):  # Raw, JC, Kimura; LogDet and ANI count anchors per nucleotide
         _check_set(ctx, orc, [g, h], segments=(0, 512), model=model)
 
 
@@ -163,16 +163,23 @@ def test_anchor_significance_parameter(ctx, orc):
         Q.close()
 
 
-def test_unsupported_models_fail_loudly(ctx):
-    import andi_amd
+def test_logdet_ani_equal_runs(ctx, orc):
+    """model_count_equal's per-character path (src/model.c:256-278): identical
+    sequences, join separators inside anchors, skewed composition."""
     from andi_amd import synth
-    a, b = synth.pair(5000, 0.05)
-    Q = andi_amd.Queries(ctx, [a, b])
-    E = andi_amd.Esa(ctx, a)
+    rng = np.random.default_rng(17)
+    base = synth.base_codes(70000, 21)
+    a = synth.to_bytes(base)
+    b = synth.join_contigs(synth.to_bytes(synth.mutate_codes(base, 0.01, 22)), 6, seed=5)
+    skew = rand_dna(rng, 30000, b"AAAAACGT")
+    skew2 = synth.to_bytes(synth.mutate_codes(
+        np.frombuffer(skew.translate(bytes.maketrans(b"ACGT", bytes(range(4)))), np.uint8), 0.03, 3))
+    for model in (3, 4):
+        _check_set(ctx, orc, [a, a, b], segments=(0, 1500), model=model)
+        _check_set(ctx, orc, [skew, skew2], segments=(0,), model=model)
+    import andi_amd
     with pytest.raises(andi_amd.AndiHipError):
-        andi_amd.scan_rows(ctx, [E], [0], Q, model=andi_amd.M_LOGDET)
-    E.close()
-    Q.close()
+        _gpu_rows(ctx, [a, b], model=7)
 
 
 def test_golden_testfasta_s42(ctx, golden_s42):
