@@ -172,9 +172,9 @@ __device__ __forceinline__ void add_composition(uint32_t code, uint32_t sel16, u
 // model_count_equal (src/model.c:246-279) for the anchor Q[qpos..qpos+len).  RAW, JC and
 // Kimura split the length evenly; LogDet and ANI count the anchor's nucleotides, which
 // streams the anchor once more (16 bytes per lane and step).
-template <int G>
+template <int G, bool EXACT>
 __device__ __forceinline__ void count_anchor(const PairCtx &c, Tally &t, uint32_t qpos, uint32_t len) {
-	if (!c.exact) {
+	if constexpr (!EXACT) {
 		count_equal(t, len);
 		return;
 	}
@@ -371,7 +371,7 @@ __device__ __forceinline__ Probe probe_step(const PairCtx &c, uint32_t p, const 
 }
 
 // One trip of the while loop, src/process.c:153-197.  Uniform within the group.
-template <int G, int MODE>
+template <int G, int MODE, bool EXACT>
 __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st, Tally &tally,
 												 Window<G> &w) {
 	const uint32_t n = (uint32_t)c.E.n;
@@ -400,11 +400,11 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 		uint32_t endQ = st.lastQ + st.lastLen;
 		if (curS > endS && st.p - endQ == curS - endS &&
 			(curS < c.border) == (st.lastS < c.border)) {
-			count_anchor<G>(c, tally, st.lastQ, st.lastLen);
+			count_anchor<G, EXACT>(c, tally, st.lastQ, st.lastLen);
 			window_count_gap<G>(w, tally, c.Q, c.E.S, endQ, endS, st.p - endQ);
 			st.lwra = 1;
 		} else {
-			if (st.lwra || st.lastLen >= 2 * c.thr) count_anchor<G>(c, tally, st.lastQ, st.lastLen);
+			if (st.lwra || st.lastLen >= 2 * c.thr) count_anchor<G, EXACT>(c, tally, st.lastQ, st.lastLen);
 			st.lwra = 0;
 		}
 		st.lastS = curS;
@@ -455,7 +455,7 @@ __device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {
 // ------------------------------------------------------------------ pass A
 // MODE is a template parameter so that the kernel for probe-table subjects does
 // not carry the reference walk's code; blocks of the other mode's subjects exit.
-template <int G, int MODE>
+template <int G, int MODE, bool EXACT>
 __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 	__shared__ uint32_t s_hist[BLOCK / G][16];
 	if (a.subjects[blockIdx.y].mode != MODE) return;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, (uint32_t)c.E.n);
 	Window<G> w;
 	w.q0 = ~0u;
-	while (st.p < it.end) st = chain_step<G, MODE>(c, st, tally, w);
+	while (st.p < it.end) st = chain_step<G, MODE, EXACT>(c, st, tally, w);
 
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
 	uint32_t lane = Group<G>::sub();
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 // Replays the true chain (entering in state T) through [start, end) next to the
 // segment's cold chain.  On return T is the true chain's state on leaving the
 // segment and histT[0..16) the counts it added inside the segment.
-template <int G, int MODE>
+template <int G, int MODE, bool EXACT>
 __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, uint32_t start,
 											   uint32_t end, const ChainState &coldExit,
 											   const uint32_t *coldCounts, uint32_t *histT,
@@ -500,7 +500,7 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 		if (T.p >= end) break;
 		const bool stepT = C.p >= end || T.p <= C.p; // one call site keeps the code small
 		Tally tx = stepT ? tT : tC;
-		ChainState nx = chain_step<G, MODE>(c, stepT ? T : C, tx, w);
+		ChainState nx = chain_step<G, MODE, EXACT>(c, stepT ? T : C, tx, w);
 		if (stepT) {
 			T = nx, tT = tx;
 		} else {
@@ -516,7 +516,7 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 }
 
 // ------------------------------------------------------------------ pass B
-template <int G, int MODE>
+template <int G, int MODE, bool EXACT>
 __global__ __launch_bounds__(BLOCK, 6) void k_scan_stitch(ScanArgs a) {
 	__shared__ uint32_t s_hist[BLOCK / G][2][16];
 	if (a.subjects[blockIdx.y].mode != MODE) return;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_scan_stitch(ScanArgs a) {
 	uint32_t *histT = s_hist[threadIdx.x / G][0], *histC = s_hist[threadIdx.x / G][1];
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
 	ChainState T = a.cold_exit[slot - 1]; // assumed entry; verified in pass C
-	stitch_segment<G, MODE>(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
+	stitch_segment<G, MODE, EXACT>(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
 					  histC);
 	if (lane == 0) a.true_exit[slot] = T;
 	for (uint32_t t = lane; t < 16; t += G) a.owned[slot * 16 + t] = histT[t];
@@ -588,12 +588,21 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 				uint32_t start = k * a.seg;
 				uint32_t e = start + a.seg;
 				uint32_t end = e < c.qlen ? e : c.qlen;
+				// rare; the general variant (runtime mode, per-nucleotide counting if asked for)
 				if (c.E.mode == ANDI_MODE_REFERENCE) {
-					stitch_segment<64, ANDI_MODE_REFERENCE>(c, st, start, end, a.cold_exit[row + k],
-															 a.cold_counts + (row + k) * 16, histT, histC);
+					if (c.exact)
+						stitch_segment<64, ANDI_MODE_REFERENCE, true>(c, st, start, end, a.cold_exit[row + k],
+																	  a.cold_counts + (row + k) * 16, histT, histC);
+					else
+						stitch_segment<64, ANDI_MODE_REFERENCE, false>(c, st, start, end, a.cold_exit[row + k],
+																	   a.cold_counts + (row + k) * 16, histT, histC);
 				} else {
-					stitch_segment<64, ANDI_MODE_PROBE>(c, st, start, end, a.cold_exit[row + k],
-														 a.cold_counts + (row + k) * 16, histT, histC);
+					if (c.exact)
+						stitch_segment<64, ANDI_MODE_PROBE, true>(c, st, start, end, a.cold_exit[row + k],
+																  a.cold_counts + (row + k) * 16, histT, histC);
+					else
+						stitch_segment<64, ANDI_MODE_PROBE, false>(c, st, start, end, a.cold_exit[row + k],
+																   a.cold_counts + (row + k) * 16, histT, histC);
 				}
 				if (lane < 16) total[lane] += histT[lane];
 			}
@@ -605,10 +614,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	Tally last;
 	last.hist = total, last.quarter = 0, last.rest = 0;
 	last.same[0] = last.same[1] = last.same[2] = last.same[3] = 0;
-	if (fin.lastLen >= c.qlen) {
-		count_anchor<64>(c, last, 0, c.qlen);
-	} else if (fin.lwra || fin.lastLen >= 2 * c.thr) {
-		count_anchor<64>(c, last, fin.lastQ, fin.lastLen);
+	if (fin.lastLen >= c.qlen || fin.lwra || fin.lastLen >= 2 * c.thr) {
+		const bool whole = fin.lastLen >= c.qlen;
+		const uint32_t from = whole ? 0u : fin.lastQ, len = whole ? c.qlen : fin.lastLen;
+		if (c.exact)
+			count_anchor<64, true>(c, last, from, len);
+		else
+			count_anchor<64, false>(c, last, from, len);
 	}
 	tally_finish<64>(last);
 	if (lane < 16) out->counts[lane] = total[lane];
@@ -640,59 +652,51 @@ static int scan_group() {
 	static int g = [] {
 		const char *e = getenv("ANDI_SCAN_G");
 		int v = e ? atoi(e) : SCAN_G;
-		return (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : SCAN_G;
+		return (v == 2 || v == 4 || v == 8 || v == 16) ? v : SCAN_G;
 	}();
 	return g;
 }
 
-template <int G>
+template <int G, bool EXACT>
 static hipError_t launch_cold(const ScanArgs &a, hipStream_t st) {
 	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	k_scan_cold<G, ANDI_MODE_PROBE><<<grid, BLOCK, 0, st>>>(a);
+	k_scan_cold<G, ANDI_MODE_PROBE, EXACT><<<grid, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	if (a.any_reference) {
-		k_scan_cold<G, ANDI_MODE_REFERENCE><<<grid, BLOCK, 0, st>>>(a);
+		k_scan_cold<G, ANDI_MODE_REFERENCE, EXACT><<<grid, BLOCK, 0, st>>>(a);
 		CHECK_LAUNCH();
 	}
 	return hipSuccess;
 }
 
-template <int G>
+template <int G, bool EXACT>
 static hipError_t launch_stitch(const ScanArgs &a, hipStream_t st) {
 	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	k_scan_stitch<G, ANDI_MODE_PROBE><<<grid, BLOCK, 0, st>>>(a);
+	k_scan_stitch<G, ANDI_MODE_PROBE, EXACT><<<grid, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	if (a.any_reference) {
-		k_scan_stitch<G, ANDI_MODE_REFERENCE><<<grid, BLOCK, 0, st>>>(a);
+		k_scan_stitch<G, ANDI_MODE_REFERENCE, EXACT><<<grid, BLOCK, 0, st>>>(a);
 		CHECK_LAUNCH();
 	}
 	return hipSuccess;
 }
 
-hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
-	switch (scan_group()) {
-		case 2: return launch_cold<2>(a, st);
-		case 4: return launch_cold<4>(a, st);
-		case 8: return launch_cold<8>(a, st);
-		case 16: return launch_cold<16>(a, st);
-		case 32: return launch_cold<32>(a, st);
-		case 64: return launch_cold<64>(a, st);
-		default: return launch_cold<SCAN_G>(a, st);
+#define DISPATCH_G(FN)                                                                             \
+	switch (scan_group()) {                                                                        \
+		case 2: return a.exact_equal ? FN<2, true>(a, st) : FN<2, false>(a, st);                   \
+		case 8: return a.exact_equal ? FN<8, true>(a, st) : FN<8, false>(a, st);                   \
+		case 16: return a.exact_equal ? FN<16, true>(a, st) : FN<16, false>(a, st);                \
+		default: return a.exact_equal ? FN<SCAN_G, true>(a, st) : FN<SCAN_G, false>(a, st);        \
 	}
+
+hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
+	DISPATCH_G(launch_cold)
 }
 
 hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
-	switch (scan_group()) {
-		case 2: return launch_stitch<2>(a, st);
-		case 4: return launch_stitch<4>(a, st);
-		case 8: return launch_stitch<8>(a, st);
-		case 16: return launch_stitch<16>(a, st);
-		case 32: return launch_stitch<32>(a, st);
-		case 64: return launch_stitch<64>(a, st);
-		default: return launch_stitch<SCAN_G>(a, st);
-	}
+	DISPATCH_G(launch_stitch)
 }
 
 hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st) {
