@@ -517,7 +517,7 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 
 // ------------------------------------------------------------------ pass B
 template <int G, int MODE, bool EXACT>
-__global__ __launch_bounds__(BLOCK, 6) void k_scan_stitch(ScanArgs a) {
+__global__ __launch_bounds__(BLOCK, 5) void k_scan_stitch(ScanArgs a) {
 	__shared__ uint32_t s_hist[BLOCK / G][2][16];
 	if (a.subjects[blockIdx.y].mode != MODE) return;
 	WorkItem it = decode_item<G>(a);
