@@ -68,6 +68,8 @@ struct andi_hip_esa {
 	int32_t deepK = 0;
 	int32_t n = 0;
 	int32_t thr = 0;
+	size_t cap = 0;     // characters the buffers were sized for (>= n)
+	size_t ref_cap = 0; // same for the reference arrays
 	bool ref_built = false;   // LCP, CLD, FVC, tab valid
 	bool index_built = false; // deep, flags valid
 	size_t bytes = 0;
@@ -285,6 +287,54 @@ int andi_hip_copy_to_host(andi_hip_ctx *ctx, void *dst, const void *src, size_t 
 }
 
 // ------------------------------------------------------------------ subjects
+// Allocate a subject slot able to hold an RS of up to `cap` characters.
+static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
+	auto *e = new andi_hip_esa;
+	e->cap = cap;
+	hipError_t err = hipSuccess;
+	auto chk = [&](hipError_t x) {
+		if (err == hipSuccess) err = x;
+	};
+	const size_t deep_entries = (size_t)1 << (2 * pick_deep_k(cap));
+	chk(dmalloc(&e->S, cap + 1 + ANDI_PAD));
+	chk(dmalloc(&e->SA, cap));
+	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
+	chk(dmalloc(&e->rec, cap));
+	chk(dmalloc(&e->P2, (cap + 1) / 16 + 8));
+	chk(dmalloc(&e->V, (cap + 1) / 32 + 8));
+	chk(dmalloc(&e->flags, 4));
+	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault));
+	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 4 * cap + (cap + 1) / 4 + (cap + 1) / 8 + 80;
+	if (err != hipSuccess) {
+		andi_hip_esa_free(ctx, e);
+		return fail(ctx, "allocating a subject", err);
+	}
+	*out = e;
+	return 0;
+}
+
+// Put a (new) subject into a slot: uploads only.  The caller may release RS/SA
+// as soon as this returns.
+static int esa_upload(andi_hip_ctx *ctx, andi_hip_esa *e, const char *RS, const int32_t *SA, size_t n,
+					  size_t threshold) {
+	if (n > e->cap) {
+		ctx->err = "subject does not fit its slot";
+		return 1;
+	}
+	e->n = (int32_t)n;
+	e->thr = (int32_t)threshold;
+	e->deepK = pick_deep_k(n);
+	e->ref_built = e->index_built = false;
+	hipError_t err = hipMemsetAsync(e->flags, 0, 4 * sizeof(int32_t), ctx->stream);
+	if (err == hipSuccess) err = hipMemsetAsync(e->S + n, 0, 1 + ANDI_PAD, ctx->stream);
+	if (err == hipSuccess) err = hipMemcpyAsync(e->S, RS, n, hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess)
+		err = hipMemcpyAsync(e->SA, SA, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+	if (err != hipSuccess) return fail(ctx, "uploading a subject", err);
+	return 0;
+}
+
 int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, size_t n,
 					   size_t threshold, andi_hip_esa **out) {
 	if (!ctx || !RS || !SA || !out || n == 0 || n >= (size_t)INT32_MAX) {
@@ -292,44 +342,28 @@ int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, siz
 		return 1;
 	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	auto *e = new andi_hip_esa;
-	e->n = (int32_t)n;
-	e->thr = (int32_t)threshold;
-	hipError_t err = hipSuccess;
-	auto chk = [&](hipError_t x) {
-		if (err == hipSuccess) err = x;
-	};
-	e->deepK = pick_deep_k(n);
-	const size_t deep_entries = (size_t)1 << (2 * e->deepK);
-	chk(dmalloc(&e->S, n + 1 + ANDI_PAD));
-	chk(dmalloc(&e->SA, n));
-	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
-	chk(dmalloc(&e->rec, n));
-	chk(dmalloc(&e->P2, (n + 1) / 16 + 8));
-	chk(dmalloc(&e->V, (n + 1) / 32 + 8));
-	chk(dmalloc(&e->flags, 4));
-	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault));
-	e->bytes = (n + 1 + ANDI_PAD) + 4 * n + 8 * deep_entries + 4 * n + 16;
-	if (err == hipSuccess) err = hipMemsetAsync(e->flags, 0, 4 * sizeof(int32_t), ctx->stream);
-	if (err == hipSuccess) err = hipMemsetAsync(e->S + n, 0, 1 + ANDI_PAD, ctx->stream);
-	if (err == hipSuccess) err = hipMemcpyAsync(e->S, RS, n, hipMemcpyHostToDevice, ctx->stream);
-	if (err == hipSuccess)
-		err = hipMemcpyAsync(e->SA, SA, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-	// the caller may release RS/SA as soon as this returns
-	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
-	if (err != hipSuccess) {
+	andi_hip_esa *e = nullptr;
+	if (esa_reserve(ctx, n, &e)) return 1;
+	if (esa_upload(ctx, e, RS, SA, n, threshold)) {
 		andi_hip_esa_free(ctx, e);
-		return fail(ctx, "andi_hip_esa_stage", err);
+		return 1;
 	}
 	*out = e;
 	return 0;
 }
 
 static int ensure_reference_buffers(andi_hip_ctx *ctx, andi_hip_esa *e) {
-	if (e->LCP) return 0;
-	const size_t n = (size_t)e->n;
+	if (e->LCP && e->ref_cap >= (size_t)e->n) return 0;
+	if (e->LCP) { // slot reused for a longer subject
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		(void)hipFree(e->LCP), (void)hipFree(e->CLD), (void)hipFree(e->FVC), (void)hipFree(e->tab);
+		(void)hipFree(e->min_scratch);
+		e->LCP = e->CLD = nullptr, e->FVC = nullptr, e->tab = nullptr, e->min_scratch = nullptr;
+	}
+	const size_t n = e->cap;
+	e->ref_cap = n;
 	const size_t tab_entries = (size_t)1 << (2 * ANDI_CACHE_K);
-	const size_t mins = andi_min_tree_entries(e->n);
+	const size_t mins = andi_min_tree_entries((int32_t)n);
 	hipError_t err = hipSuccess;
 	auto chk = [&](hipError_t x) {
 		if (err == hipSuccess) err = x;
@@ -739,21 +773,42 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	andi_hip_ctx *ctx = nullptr;
 	if (andi_hip_ctx_create(&ctx, o.device, errbuf, errlen)) return 1;
 	andi_hip_queries *Q = nullptr;
-	andi_hip_model *d_row = nullptr;
+	andi_hip_model *d_rows = nullptr;
 	int rc = 0;
 	auto bail = [&](const char *what) {
 		set_err(errbuf, errlen, "%s: %s", what, andi_hip_last_error(ctx));
 		rc = 1;
 	};
 
-	if (andi_hip_queries_stage(ctx, seqs, n, &Q)) bail("staging queries");
-	if (!rc && andi_hip_dev_alloc(ctx, n * sizeof(andi_hip_model), (void **)&d_row)) bail("row buffer");
+	// Subject slots: device buffers sized for the longest genome, reused batch
+	// after batch (no allocation inside the loop).  Several subjects per scan call
+	// keep the GPU filled; low_memory keeps one index resident at a time, which is
+	// what distMatrixLM trades (src/dist_hack.h:14-16).
+	size_t longest = 0;
+	for (size_t i = 0; i < n; ++i) longest = std::max(longest, seqs[i].len);
+	const size_t rs_cap = 2 * longest + 1;
+	size_t batch = o.low_memory ? 1 : 8;
+	{
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+			const size_t per_slot = 10 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap))) + (1 << 20);
+			while (batch > 1 && batch * per_slot > free_b / 2) batch /= 2;
+		}
+	}
+	if (batch > n) batch = n;
+	std::vector<andi_hip_esa *> slots(batch, nullptr);
 
-	// host pool: subject preparation + suffix sorting, bounded look-ahead
+	if (andi_hip_queries_stage(ctx, seqs, n, &Q)) bail("staging queries");
+	for (size_t b = 0; b < batch && !rc; ++b)
+		if (esa_reserve(ctx, rs_cap, &slots[b])) bail("allocating subject slots");
+	if (!rc && andi_hip_dev_alloc(ctx, batch * n * sizeof(andi_hip_model), (void **)&d_rows)) bail("row buffer");
+
+	// host pool: subject preparation + suffix sorting (the role of the OpenMP
+	// subject loop, src/dist_hack.h:46-52), bounded look-ahead
 	int threads = o.host_threads > 0 ? o.host_threads : (int)std::thread::hardware_concurrency();
 	if (threads < 1) threads = 1;
 	if ((size_t)threads > n) threads = (int)n;
-	const size_t window = (size_t)threads + 2;
+	const size_t window = (size_t)threads + batch + 1;
 
 	std::mutex mu;
 	std::condition_variable cv;
@@ -791,43 +846,46 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	if (!rc)
 		for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
 
-	for (size_t i = 0; i < n && !rc; ++i) {
+	auto take = [&](size_t i) { // blocks until subject i is prepared
 		Prepared *p = nullptr;
-		{
-			std::unique_lock<std::mutex> lk(mu);
-			cv.wait(lk, [&] {
-				for (auto *c : ready)
-					if (c->idx == i) return true;
-				return false;
-			});
-			for (auto it = ready.begin(); it != ready.end(); ++it)
-				if ((*it)->idx == i) {
-					p = *it;
-					ready.erase(it);
-					break;
-				}
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [&] {
+			for (auto *c : ready)
+				if (c->idx == i) return true;
+			return false;
+		});
+		for (auto it = ready.begin(); it != ready.end(); ++it)
+			if ((*it)->idx == i) {
+				p = *it;
+				ready.erase(it);
+				break;
+			}
+		return p;
+	};
+
+	std::vector<int64_t> self(batch);
+	for (size_t i0 = 0; i0 < n && !rc; i0 += batch) {
+		const size_t nb = std::min(batch, n - i0);
+		for (size_t b = 0; b < nb && !rc; ++b) {
+			Prepared *p = take(i0 + b);
+			if (p->rc) {
+				set_err(errbuf, errlen, "Failed to create index for sequence %zu.", i0 + b); // src/dist_hack.h:53
+				rc = 1;
+			}
+			if (!rc && esa_upload(ctx, slots[b], p->RS, p->SA.data(), p->n, p->thr)) bail("staging subject");
+			if (!rc && andi_hip_esa_build_index(ctx, slots[b])) bail("index build");
+			self[b] = (int64_t)(i0 + b);
+			andi_hip_free(p->RS);
+			delete p;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				consumed = i0 + b + 1;
+			}
+			cv.notify_all();
 		}
-		if (p->rc) {
-			set_err(errbuf, errlen, "Failed to create index for sequence %zu.", i); // src/dist_hack.h:53
-			rc = 1;
-		}
-		andi_hip_esa *E = nullptr;
-		if (!rc && andi_hip_esa_stage(ctx, p->RS, p->SA.data(), p->n, p->thr, &E)) bail("staging subject");
-		if (!rc && andi_hip_esa_build_index(ctx, E)) bail("index build");
-		int64_t self = (int64_t)i;
-		andi_hip_esa *subj[1] = {E};
-		if (!rc && andi_hip_scan_rows(ctx, subj, &self, 1, Q, o.model, o.segment, d_row)) bail("scan");
-		if (!rc && andi_hip_copy_to_host(ctx, M + i * n, d_row, n * sizeof(andi_hip_model))) bail("row copy");
-		if (E) andi_hip_esa_free(ctx, E);
-		andi_hip_free(p->RS);
-		delete p;
-		{
-			std::lock_guard<std::mutex> lk(mu);
-			consumed = i + 1;
-			if (rc) abort_flag = true;
-		}
-		cv.notify_all();
-		if (!rc && o.progress) o.progress((i + 1) * (n - 1), n * n - n, o.ud);
+		if (!rc && andi_hip_scan_rows(ctx, slots.data(), self.data(), nb, Q, o.model, o.segment, d_rows)) bail("scan");
+		if (!rc && andi_hip_copy_to_host(ctx, M + i0 * n, d_rows, nb * n * sizeof(andi_hip_model))) bail("row copy");
+		if (!rc && o.progress) o.progress((i0 + nb) * (n - 1), n * n - n, o.ud);
 	}
 	{
 		std::lock_guard<std::mutex> lk(mu);
@@ -840,7 +898,9 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		andi_hip_free(p->RS);
 		delete p;
 	}
-	if (d_row) andi_hip_dev_free(ctx, d_row);
+	for (auto *e : slots)
+		if (e) andi_hip_esa_free(ctx, e);
+	if (d_rows) andi_hip_dev_free(ctx, d_rows);
 	if (Q) andi_hip_queries_free(ctx, Q);
 	andi_hip_ctx_destroy(ctx);
 	return rc;
