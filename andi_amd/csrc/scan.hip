@@ -117,17 +117,16 @@ __device__ __forceinline__ void tally_finish(Tally &t) {
 
 // A chain spends most of its steps on one diagonal (query offset p against
 // subject offset p + d), advancing ~1/divergence bytes per step.  Window keeps
-// what the group fetched last -- 16*G bytes of both strings, as 2-bit codes plus
-// ACGT masks, and a bitmask of the positions where the bytes differ -- in
-// registers: the following lucky comparisons, gap counts and K-mer codes on
+// what the group fetched last -- 16*G bytes of the query as 2-bit codes plus an
+// ACGT mask, and a bitmask of the positions where the subject's bytes differ --
+// in registers: the following lucky comparisons, gap counts and K-mer codes on
 // that diagonal are answered from it without touching memory, so each
 // 16*G-byte line of Q and S is fetched once.
 template <int G>
 struct Window {
 	uint32_t q0, s0; // offsets of byte 0; q0 == ~0u: empty
-	uint32_t qc, sc; // 2-bit codes of this lane's 16 bytes, first byte in the top bits
-	uint32_t mask;   // bits 0..15: byte differs; bits 16..31: Q byte is ACGT
-	uint32_t sv;     // bits 0..15: S byte is ACGT
+	uint32_t qc;   // 2-bit codes of this lane's 16 Q bytes, first byte in the top bits
+	uint32_t mask; // bits 0..15: byte differs; bits 16..31: Q byte is ACGT
 };
 
 __device__ __forceinline__ uint32_t diff_bits4(uint32_t x) { // one bit per non-zero byte
@@ -195,7 +194,6 @@ __device__ __forceinline__ void window_load(Window<G> &w, g_u8p Q, g_u8p S, uint
 	uint4 sb = ld_u128_unaligned(S + s0 + 16 * sub);
 	uint32_t qv;
 	codes16(qb, w.qc, qv);
-	codes16(sb, w.sc, w.sv);
 	w.mask = diff_bits4(qb.x ^ sb.x) | (diff_bits4(qb.y ^ sb.y) << 4) | (diff_bits4(qb.z ^ sb.z) << 8) |
 			 (diff_bits4(qb.w ^ sb.w) << 12) | (qv << 16);
 }
@@ -270,16 +268,17 @@ __device__ __forceinline__ void window_count_gap(Window<G> &w, Tally &tally, g_u
 		if (w.q0 == ~0u || s - q != w.s0 - w.q0 || q < w.q0 || q >= w.q0 + W) window_load(w, Q, S, q, s);
 		const uint32_t lo = q - w.q0, hi = lo + len < W ? lo + len : W;
 		uint32_t a = lo > mine ? lo - mine : 0, b = hi > mine ? (hi - mine < 16 ? hi - mine : 16) : 0;
-		// this lane's gap bytes where neither string has a separator (model.c:318-320)
+		// this lane's gap bytes whose query byte is a nucleotide (model.c:318-320)
 		uint32_t range = b > a ? ((0xffffu >> (16 - (b - a))) << a) : 0u;
-		uint32_t both = (w.mask >> 16) & w.sv & range;
-		// equal pairs (the bulk of a gap): per nucleotide by population count.  Byte t
-		// of the lane sits at bits 31-2t..30-2t of the code words.
-		add_composition(w.qc, both & ~w.mask & 0xffffu, tally.same);
-		// substitutions: one LDS add each
-		for (uint32_t d = both & w.mask & 0xffffu; d; d &= d - 1) {
+		uint32_t qok = (w.mask >> 16) & range;
+		// equal pairs (the bulk of a gap): per nucleotide by population count; an equal
+		// byte of the subject is a nucleotide too
+		add_composition(w.qc, qok & ~w.mask & 0xffffu, tally.same);
+		// substitutions: fetch the subject's byte, one LDS add each
+		for (uint32_t d = qok & w.mask & 0xffffu; d; d &= d - 1) {
 			uint32_t t = (uint32_t)__builtin_ctz(d);
-			atomicAdd(&tally.hist[(((w.sc >> (30 - 2 * t)) & 3u) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)], 1u);
+			uint8_t sb = S[w.s0 + mine + t];
+			if ((int8_t)sb >= 'A') atomicAdd(&tally.hist[(nt_code(sb) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)], 1u);
 		}
 		const uint32_t done = hi - lo;
 		q += done, s += done, len -= done;
