@@ -5,7 +5,7 @@
 //   S    uint8[n+1+PAD]  RS, NUL at n, zero padding so wide loads never fault
 //   SA   int32[n]        suffix array (host-built, src/esa.c:294-304)
 // scan index (what the anchor scan uses; built by k_suffix_prefixes + k_probe_table):
-//   deep uint32[4^K]     probe table: for every ACGT K-mer the outcome of the
+//   deep uint2[4^K]      probe table: for every ACGT K-mer the outcome of the
 //                        longest-match search as far as the K-mer alone decides
 //                        it, so most probes cost one random access
 //   rec  uint32[n]       scratch: K-mer code + valid length of every suffix
@@ -35,7 +35,7 @@ struct EsaDev {
 	const int32_t *CLD;
 	const uint8_t *FVC;
 	const int4 *tab; // x=l y=i z=j w=m
-	const uint32_t *deep;
+	const uint2 *deep;
 	const int32_t *flags;
 	int32_t n;
 	int32_t thr;
@@ -46,10 +46,11 @@ struct EsaDev {
 #define ANDI_MODE_PROBE 0     /* probe table + suffix-array search (true longest match) */
 #define ANDI_MODE_REFERENCE 1 /* 10-mer table + child-table walk, exactly as src/esa.c */
 
-// probe-table entry, 32 bits: kind in bits 1..0
-#define DEEP_FINAL 0u  /* K-mer absent: bit 2 = unique, bits 7..4 = match length l < K */
-#define DEEP_SINGLE 1u /* K-mer occurs once: entry >> 2 = its position in RS (n < 2^30) */
-#define DEEP_MULTI 2u  /* K-mer occurs more than once: entry >> 2 = SA index of the first occurrence */
+// probe-table entry: x = payload, y = kind | unique << 2 | l << 8
+#define DEEP_FINAL 0u  /* K-mer absent: match length l < K; x = SA index of the one suffix if unique */
+#define DEEP_SINGLE 1u /* K-mer occurs once: x = its position in RS */
+#define DEEP_MULTI 2u  /* K-mer occurs more than once: x = first SA index, y >> 8 = run length - 1 */
+#define DEEP_SEARCH 3u /* (run too long to encode) search the whole suffix array */
 
 // Device code addresses the index through global-address-space pointers so
 // the compiler emits global_load (not flat_load) for them.
@@ -57,14 +58,14 @@ struct EsaDev {
 typedef ANDI_GLOBAL const uint8_t *g_u8p;
 typedef ANDI_GLOBAL const int32_t *g_i32p;
 typedef ANDI_GLOBAL const int4 *g_i4p;
-typedef ANDI_GLOBAL const uint32_t *g_u32p;
+typedef ANDI_GLOBAL const uint2 *g_u2p;
 
 struct EsaG {
 	g_u8p S;
 	g_i32p SA, LCP, CLD;
 	g_u8p FVC;
 	g_i4p tab;
-	g_u32p deep;
+	g_u2p deep;
 	int32_t n, thr, deepK, mode;
 };
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
 	EsaG g;
 	g.S = (g_u8p)e.S, g.SA = (g_i32p)e.SA, g.LCP = (g_i32p)e.LCP, g.CLD = (g_i32p)e.CLD;
 	g.FVC = (g_u8p)e.FVC, g.tab = (g_i4p)e.tab;
-	g.deep = (g_u32p)e.deep;
+	g.deep = (g_u2p)e.deep;
 	g.n = e.n, g.thr = e.thr, g.deepK = e.deepK, g.mode = e.mode;
 	return g;
 }
@@ -390,14 +391,39 @@ __device__ __forceinline__ Probe sa_range_match(const EsaG &E, g_u8p q, uint32_t
 	}
 }
 
-// The probe of one chain step in ANDI_MODE_REFERENCE: the reference's own walk
-// (10-mer table, child table).  The probe-table form lives in scan.hip.
+// The probe of one chain step.  ANDI_MODE_PROBE: the K-mer at q decides most
+// outcomes with one table access; results are those of the true longest match,
+// which is what get_match_cached computes unless flags[0] is set.
+// ANDI_MODE_REFERENCE: the reference's own walk.
 template <int G>
 __device__ __forceinline__ Probe esa_probe(const EsaG &E, g_u8p q, uint32_t qlen) {
 	Probe r;
-	Ival m = esa_match_cached<G>(E, q, qlen);
-	r.len = m.l <= 0 ? 0u : (uint32_t)m.l;
-	r.unique = m.i == m.j;
-	r.pos = (uint32_t)E.SA[m.i];
-	return r;
+	if (E.mode == ANDI_MODE_REFERENCE) {
+		Ival m = esa_match_cached<G>(E, q, qlen);
+		r.len = m.l <= 0 ? 0u : (uint32_t)m.l;
+		r.unique = m.i == m.j;
+		r.pos = (uint32_t)E.SA[m.i];
+		return r;
+	}
+	const int K = E.deepK;
+	uint32_t code;
+	if (qlen > (uint32_t)K && kmer_code(q, K, code)) {
+		uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + code));
+		uint32_t x = (uint32_t)raw, y = (uint32_t)(raw >> 32);
+		uint32_t kind = y & 3u;
+		if (kind == DEEP_FINAL) {
+			r.len = y >> 8, r.unique = (y >> 2) & 1u;
+			r.pos = (r.unique && r.len >= (uint32_t)E.thr) ? (uint32_t)E.SA[x] : 0u;
+			return r;
+		}
+		if (kind == DEEP_SINGLE) {
+			r.pos = x, r.unique = true;
+			r.len = (uint32_t)K + common_prefix<G>(q + K, E.S + x + K, qlen - (uint32_t)K);
+			return r;
+		}
+		if (kind == DEEP_MULTI)
+			return sa_range_match<G>(E, q, qlen, (int32_t)x, (int32_t)(x + (y >> 8)), (uint32_t)K);
+	}
+	// short remainder, separator within the first K characters, or DEEP_SEARCH
+	return sa_range_match<G>(E, q, qlen, 0, E.n - 1, 0);
 }

@@ -60,7 +60,7 @@ struct andi_hip_esa {
 	uint8_t *FVC = nullptr;
 	int4 *tab = nullptr;
 	int32_t *min_scratch = nullptr;
-	uint32_t *deep = nullptr;
+	uint2 *deep = nullptr;
 	uint32_t *rec = nullptr;
 	uint32_t *P2 = nullptr, *V = nullptr; // packed text for the index build
 	int32_t *flags = nullptr;   // device, 4 ints
@@ -298,13 +298,13 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	const size_t deep_entries = (size_t)1 << (2 * pick_deep_k(cap));
 	chk(dmalloc(&e->S, cap + 1 + ANDI_PAD));
 	chk(dmalloc(&e->SA, cap));
-	chk(dmalloc(&e->deep, deep_entries + 4));
+	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
 	chk(dmalloc(&e->rec, cap));
 	chk(dmalloc(&e->P2, (cap + 1) / 16 + 8));
 	chk(dmalloc(&e->V, (cap + 1) / 32 + 8));
 	chk(dmalloc(&e->flags, 4));
 	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault));
-	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 4 * deep_entries + 4 * cap + (cap + 1) / 4 + (cap + 1) / 8 + 80;
+	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 4 * cap + (cap + 1) / 4 + (cap + 1) / 8 + 80;
 	if (err != hipSuccess) {
 		andi_hip_esa_free(ctx, e);
 		return fail(ctx, "allocating a subject", err);
@@ -620,8 +620,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			return 1;
 		}
 		int mode = ANDI_MODE_PROBE;
-		// (probe-table entries hold 30-bit positions)
-		if (!e->index_built || e->h_flags[0] != 0 || e->n >= (1 << 30) || getenv("ANDI_FORCE_REFERENCE")) {
+		if (!e->index_built || e->h_flags[0] != 0 || getenv("ANDI_FORCE_REFERENCE")) {
 			// a 10-mer table entry may span a separator: only the reference's
 			// own walk reproduces get_match_cached there
 			mode = ANDI_MODE_REFERENCE;
@@ -792,7 +791,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	{
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-			const size_t per_slot = 10 * rs_cap + ((size_t)4 << (2 * pick_deep_k(rs_cap))) + (1 << 20);
+			const size_t per_slot = 10 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap))) + (1 << 20);
 			while (batch > 1 && batch * per_slot > free_b / 2) batch /= 2;
 		}
 	}

@@ -19,7 +19,7 @@ struct EsaBuildArgs {
 	int32_t *CLD;       // n + 1   (out; doubles as PLCP scratch)
 	uint8_t *FVC;       // n       (out)
 	int4 *tab;          // 4^10    (out)
-	uint32_t *deep;     // 4^deepK (out)
+	uint2 *deep;        // 4^deepK (out)
 	uint32_t *rec;      // n       (scratch)
 	uint32_t *P2;       // (n+1)/16 + 4 words: 2-bit codes of the text (scratch)
 	uint32_t *V;        // (n+1)/32 + 4 words: ACGT bitmap of the text (scratch)

@@ -351,17 +351,17 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 
 // One thread per gap r = 0..n of the suffix array (between suffix r-1 and r).
 //  (a) if suffix r starts a run of suffixes with the same valid K-mer, write that
-//      K-mer's entry: SINGLE (position) or MULTI (SA index of the first of the run);
+//      K-mer's entry: SINGLE (position) or MULTI (first SA index and run length);
 //  (b) every K-mer that sorts strictly inside the gap is absent from RS: its
 //      longest match is the longer of its common prefixes with the two
-//      neighbours; write FINAL(l, unique);
+//      neighbours; write FINAL(l, unique, SA index);
 //  (c) detect what can make the reference's 10-mer table differ from the true
 //      longest match: a prefix w (1..8 ACGT characters) whose every occurrence is
 //      followed by the same separator, at least twice (SURVEY.md appendix C.11;
 //      this test is a superset of the exact condition) -> flags[0].
 __global__ __launch_bounds__(256) void k_probe_table(const uint32_t *__restrict__ rec,
 													 const int32_t *__restrict__ SA,
-													 uint32_t *__restrict__ deep,
+													 uint2 *__restrict__ deep,
 													 int32_t *__restrict__ flags, int32_t n, int K) {
 	int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (gid > n) return;
@@ -376,7 +376,13 @@ __global__ __launch_bounds__(256) void k_probe_table(const uint32_t *__restrict_
 		int32_t j = r;
 		while (j + 1 < n && rec[j + 1] == R) ++j;
 		uint32_t code = REC_CODE(R);
-		deep[code] = j == r ? (((uint32_t)SA[r] << 2) | DEEP_SINGLE) : (((uint32_t)r << 2) | DEEP_MULTI);
+		if (j == r) {
+			deep[code] = make_uint2((uint32_t)SA[r], DEEP_SINGLE | (1u << 2) | (full << 8));
+		} else if ((uint32_t)(j - r) < (1u << 24)) {
+			deep[code] = make_uint2((uint32_t)r, DEEP_MULTI | ((uint32_t)(j - r) << 8));
+		} else {
+			deep[code] = make_uint2(0, DEEP_SEARCH);
+		}
 	}
 
 	// (c) closed run of suffixes "w <sep>" with 1 <= |w| <= 8
@@ -417,18 +423,18 @@ __global__ __launch_bounds__(256) void k_probe_table(const uint32_t *__restrict_
 	for (int64_t c = lo; c <= hi; ++c) {
 		uint32_t lL = hasL ? rec_lcp_code((uint32_t)c, L, K) : 0u;
 		uint32_t lR = hasR ? rec_lcp_code((uint32_t)c, R, K) : 0u;
-		uint32_t l, uniq;
+		uint32_t l, uniq, idx;
 		if (lL > lR) {
-			l = lL;
+			l = lL, idx = (uint32_t)(r - 1);
 			uniq = (r < 2 || hLL < l) ? 1u : 0u;
 		} else if (lR > lL) {
-			l = lR;
+			l = lR, idx = (uint32_t)r;
 			uniq = (r + 1 >= n || hRR < l) ? 1u : 0u;
 		} else { // both neighbours share l characters (or l == 0: every suffix does)
-			l = lL, uniq = (n == 1) ? 1u : 0u;
+			l = lL, idx = 0, uniq = (n == 1) ? 1u : 0u;
 		}
 		if (l == 0) uniq = (n == 1) ? 1u : 0u;
-		deep[c] = DEEP_FINAL | (uniq << 2) | (l << 4);
+		deep[c] = make_uint2(idx, DEEP_FINAL | (uniq << 2) | (l << 8));
 	}
 }
 

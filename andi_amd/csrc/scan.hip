@@ -324,51 +324,46 @@ __device__ __forceinline__ Probe probe_step(const PairCtx &c, uint32_t p, const 
 	if ((valid & ((1u << K) - 1u)) != ((1u << K) - 1u)) // separator inside the K-mer
 		return root_search<G>(E, q, qrem);
 
-	const uint32_t e = E.deep[code >> (32 - 2 * K)], kind = e & 3u;
+	uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + (code >> (32 - 2 * K))));
+	const uint32_t x = (uint32_t)raw, y = (uint32_t)(raw >> 32), kind = y & 3u;
 	Probe r;
 	if (kind == DEEP_FINAL) {
-		r.len = (e >> 4) & 15u, r.unique = (e >> 2) & 1u, r.pos = 0;
-		// a unique match that is already long enough to be an anchor needs its position;
-		// only tiny subjects have thresholds below K
-		if (r.unique && r.len >= (uint32_t)E.thr) return root_search<G>(E, q, qrem);
+		r.len = y >> 8, r.unique = (y >> 2) & 1u;
+		r.pos = (r.unique && r.len >= (uint32_t)E.thr) ? (uint32_t)E.SA[x] : 0u;
 		return r;
 	}
 	if (kind == DEEP_SINGLE) {
-		r.pos = e >> 2, r.unique = true;
-		r.len = K + common_prefix<G>(q + K, E.S + r.pos + K, qrem - K);
+		r.pos = x, r.unique = true;
+		r.len = K + common_prefix<G>(q + K, E.S + x + K, qrem - K);
 		return r;
 	}
+	if (kind != DEEP_MULTI) return root_search<G>(E, q, qrem);
 
-	// Several occurrences, at consecutive SA indices from e >> 2: the longest match is
-	// the best of their own common prefixes with the query and it is unique iff exactly
-	// one attains it.  One occurrence per lane, G at a time, until a lane meets a suffix
-	// that does not start with the K-mer any more.
-	const uint32_t sub = Group<G>::sub(), first = e >> 2;
+	// Several occurrences: the longest match is the best of their own common
+	// prefixes with the query and it is unique iff exactly one attains it.  One
+	// occurrence per lane, G at a time.
+	const uint32_t sub = Group<G>::sub(), cnt = (y >> 8) + 1;
 	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
-	for (uint32_t off = 0;; off += G) {
+	for (uint32_t off = 0; off < cnt; off += G) {
+		const bool mine = off + sub < cnt;
 		uint32_t pos = 0, len = 0;
-		if (first + off + sub < (uint32_t)E.n) {
-			pos = (uint32_t)E.SA[first + off + sub];
-			len = common_prefix<1>(q, E.S + pos, qrem);
+		if (mine) {
+			pos = (uint32_t)E.SA[x + off + sub];
+			len = K + common_prefix<1>(q + K, E.S + pos + K, qrem - K);
 		}
-		const bool mine = len >= K;
-		uint32_t best = mine ? len : 0u;
+		uint32_t best = len;
 		for (int d = G / 2; d; d >>= 1) {
 			uint32_t other = (uint32_t)__shfl_xor((int)best, d);
 			best = other > best ? other : best;
 		}
-		uint64_t members = Group<G>::slice(__ballot(mine));
 		uint64_t who = Group<G>::slice(__ballot(mine && len == best));
-		if (who) {
-			uint32_t cnt = (uint32_t)__builtin_popcountll(who);
-			uint32_t bp = (uint32_t)__shfl((int)pos, (int)(Group<G>::base() + (uint32_t)__builtin_ctzll(who)));
-			if (bestCnt == 0 || best > bestLen) {
-				bestLen = best, bestCnt = cnt, bestPos = bp;
-			} else if (best == bestLen) {
-				bestCnt += cnt;
-			}
+		uint32_t n = (uint32_t)__builtin_popcountll(who);
+		uint32_t bp = (uint32_t)__shfl((int)pos, (int)(Group<G>::base() + (uint32_t)__builtin_ctzll(who)));
+		if (bestCnt == 0 || best > bestLen) {
+			bestLen = best, bestCnt = n, bestPos = bp;
+		} else if (best == bestLen) {
+			bestCnt += n;
 		}
-		if (members != (G == 64 ? ~0ull : ((1ull << G) - 1))) break; // the run ended inside this chunk
 	}
 	r.len = bestLen, r.unique = bestCnt == 1, r.pos = bestPos;
 	return r;
