@@ -116,6 +116,23 @@ def test_separator_spanning_table_entry(ctx, orc):
     Q.close()
 
 
+def test_mixed_modes_in_one_scan_call(ctx, orc):
+    """One andi_hip_scan_rows call over subjects that use the probe table and one
+    that needs the reference walk (two kernel variants write disjoint rows)."""
+    import andi_amd
+    from andi_amd import synth
+    rng = np.random.default_rng(58)
+    flagged = _separator_spanning_subject(rng)
+    base = synth.base_codes(20000, 2)
+    seqs = [synth.to_bytes(base), flagged, synth.to_bytes(synth.mutate_codes(base, 0.04, 3)),
+            flagged.replace(b"!", b"")[:8000]]
+    want = orc.dist_matrix(seqs, threads=4)
+    ctx.timings_reset()
+    got, t = _gpu_rows(ctx, seqs, segment=900)
+    assert t["reference_subjects"] == 1
+    assert (got == want).all()
+
+
 def test_probe_table_depths_and_reference_walk_agree(ctx, orc, monkeypatch):
     """Every probe-table depth K and the reference walk give the same counts."""
     import andi_amd
