@@ -39,8 +39,7 @@ struct EventPair {
 
 struct andi_hip_ctx {
 	int device = 0;
-	hipStream_t stream = nullptr;       // uploads, scans, copies
-	hipStream_t build_stream = nullptr; // index builds, so that they overlap the scan of earlier subjects
+	hipStream_t stream = nullptr;
 	std::string err;
 	// scan scratch
 	void *scratch = nullptr;
@@ -66,8 +65,6 @@ struct andi_hip_esa {
 	uint32_t *P2 = nullptr, *V = nullptr; // packed text for the index build
 	int32_t *flags = nullptr;   // device, 4 ints
 	int32_t *h_flags = nullptr; // pinned host copy, refreshed after every index build
-	hipEvent_t built_ev = nullptr;   // recorded on the build stream after the index build
-	hipEvent_t scanned_ev = nullptr; // recorded on the scan stream after the last scan that read the index
 	int32_t deepK = 0;
 	int32_t n = 0;
 	int32_t thr = 0;
@@ -144,21 +141,20 @@ void resolve_events(andi_hip_ctx *ctx) {
 
 struct Timed {
 	andi_hip_ctx *ctx;
-	hipStream_t st;
 	EventPair ev;
 	bool ok;
-	Timed(andi_hip_ctx *c, int kind, hipStream_t stream = nullptr) : ctx(c), st(stream ? stream : c->stream), ok(false) {
+	Timed(andi_hip_ctx *c, int kind) : ctx(c), ok(false) {
 		ev.kind = kind;
 		if (hipEventCreate(&ev.a) != hipSuccess) return;
 		if (hipEventCreate(&ev.b) != hipSuccess) {
 			(void)hipEventDestroy(ev.a);
 			return;
 		}
-		ok = hipEventRecord(ev.a, st) == hipSuccess;
+		ok = hipEventRecord(ev.a, c->stream) == hipSuccess;
 	}
 	void stop() {
 		if (!ok) return;
-		(void)hipEventRecord(ev.b, st);
+		(void)hipEventRecord(ev.b, ctx->stream);
 		ctx->pending.push_back(ev);
 		ok = false;
 		if (ctx->pending.size() > 256) resolve_events(ctx);
@@ -234,7 +230,6 @@ int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t err
 	auto *ctx = new andi_hip_ctx;
 	ctx->device = device;
 	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
@@ -251,7 +246,6 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-	if (ctx->build_stream) (void)hipStreamSynchronize(ctx->build_stream);
 	resolve_events(ctx);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
@@ -259,7 +253,6 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->d_fixups) (void)hipFree(ctx->d_fixups);
 	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-	if (ctx->build_stream) (void)hipStreamDestroy(ctx->build_stream);
 	delete ctx;
 }
 
@@ -269,7 +262,6 @@ const char *andi_hip_last_error(const andi_hip_ctx *ctx) {
 
 int andi_hip_sync(andi_hip_ctx *ctx) {
 	if (!ctx) return 1;
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->build_stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return 0;
 }
@@ -312,8 +304,6 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	chk(dmalloc(&e->V, (cap + 1) / 32 + 8));
 	chk(dmalloc(&e->flags, 4));
 	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault));
-	chk(hipEventCreateWithFlags(&e->built_ev, hipEventDisableTiming));
-	chk(hipEventCreateWithFlags(&e->scanned_ev, hipEventDisableTiming));
 	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 4 * cap + (cap + 1) / 4 + (cap + 1) / 8 + 80;
 	if (err != hipSuccess) {
 		andi_hip_esa_free(ctx, e);
@@ -335,8 +325,7 @@ static int esa_upload(andi_hip_ctx *ctx, andi_hip_esa *e, const char *RS, const 
 	e->thr = (int32_t)threshold;
 	e->deepK = pick_deep_k(n);
 	e->ref_built = e->index_built = false;
-	hipError_t err = hipStreamSynchronize(ctx->build_stream); // nothing may still be building in this slot
-	if (err == hipSuccess) err = hipMemsetAsync(e->flags, 0, 4 * sizeof(int32_t), ctx->stream);
+	hipError_t err = hipMemsetAsync(e->flags, 0, 4 * sizeof(int32_t), ctx->stream);
 	if (err == hipSuccess) err = hipMemsetAsync(e->S + n, 0, 1 + ANDI_PAD, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(e->S, RS, n, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess)
@@ -404,14 +393,11 @@ int andi_hip_esa_build(andi_hip_ctx *ctx, andi_hip_esa *e) {
 int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!ctx || !e) return 1;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	// a scan that still reads this subject's table must finish first
-	hipError_t err = hipStreamWaitEvent(ctx->build_stream, e->scanned_ev, 0);
-	Timed t(ctx, 0, ctx->build_stream);
-	if (err == hipSuccess) err = andi_launch_index_build(build_args(e), ctx->build_stream);
+	Timed t(ctx, 0);
+	hipError_t err = andi_launch_index_build(build_args(e), ctx->stream);
 	t.stop();
 	if (err == hipSuccess)
-		err = hipMemcpyAsync(e->h_flags, e->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->build_stream);
-	if (err == hipSuccess) err = hipEventRecord(e->built_ev, ctx->build_stream);
+		err = hipMemcpyAsync(e->h_flags, e->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index", err);
 	e->index_built = true;
 	return 0;
@@ -419,7 +405,6 @@ int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
 
 int andi_hip_esa_flags(andi_hip_ctx *ctx, const andi_hip_esa *e, int32_t *out4) {
 	if (!ctx || !e || !out4) return 1;
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->build_stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	HIP_TRY(ctx, hipMemcpy(out4, e->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
 	return 0;
@@ -446,11 +431,8 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!e) return;
 	if (ctx) {
 		(void)hipSetDevice(ctx->device);
-		(void)hipStreamSynchronize(ctx->build_stream);
 		(void)hipStreamSynchronize(ctx->stream);
 	}
-	if (e->built_ev) (void)hipEventDestroy(e->built_ev);
-	if (e->scanned_ev) (void)hipEventDestroy(e->scanned_ev);
 	(void)hipFree(e->S);
 	(void)hipFree(e->SA);
 	(void)hipFree(e->LCP);
@@ -629,17 +611,13 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	auto *h_self = (int64_t *)(h_esa + nsub);
 	uint64_t pairs = 0, nt = 0;
 	int any_reference = 0;
+	// the index builds must have finished: their flags decide which walk is exact
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	for (size_t s = 0; s < nsub; ++s) {
 		andi_hip_esa *e = subjects[s];
 		if (!e || (!e->index_built && !e->ref_built)) {
 			ctx->err = "andi_hip_scan_rows: subject index not built";
 			return 1;
-		}
-		if (e->index_built) {
-			// this subject's index build must have finished: its flags decide which
-			// walk is exact (builds of later subjects keep running on their stream)
-			HIP_TRY(ctx, hipEventSynchronize(e->built_ev));
-			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e->built_ev, 0));
 		}
 		int mode = ANDI_MODE_PROBE;
 		if (!e->index_built || e->h_flags[0] != 0 || getenv("ANDI_FORCE_REFERENCE")) {
@@ -705,7 +683,6 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		t.stop();
 		if (e != hipSuccess) return fail(ctx, "scan passes B/C", e);
 	}
-	for (size_t s = 0; s < nsub; ++s) HIP_TRY(ctx, hipEventRecord(subjects[s]->scanned_ev, ctx->stream));
 	ctx->acc.scan_pairs += pairs;
 	ctx->acc.scan_query_nt += nt;
 	return 0;
@@ -737,7 +714,6 @@ int andi_hip_bootstrap(andi_hip_ctx *ctx, const andi_hip_model *M, size_t n, uin
 
 int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t) {
 	if (!ctx || !t) return 1;
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->build_stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	resolve_events(ctx);
 	unsigned long long fx = 0;
@@ -749,7 +725,6 @@ int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t) {
 
 void andi_hip_timings_reset(andi_hip_ctx *ctx) {
 	if (!ctx) return;
-	(void)hipStreamSynchronize(ctx->build_stream);
 	(void)hipStreamSynchronize(ctx->stream);
 	resolve_events(ctx);
 	(void)hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));

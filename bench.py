@@ -44,7 +44,6 @@ def parse():
     ap.add_argument("--dlo", type=float, default=0.0004)
     ap.add_argument("--dhi", type=float, default=0.03)
     ap.add_argument("--segment", type=int, default=0)
-    ap.add_argument("--batches", type=int, default=4, help="subject batches per step (build/scan overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1729)
     return ap.parse_args()
@@ -120,23 +119,13 @@ def main():
     block = torch.zeros((shard.max_rows(G, world), G, 17), dtype=torch.int32, device="cuda")
     gathered = [None]
     selfs = list(range(r0, r1))
-
-    # subjects go through in batches: the index builds of batch k+1 run on the engine's
-    # build stream while batch k is being scanned
-    nb = max(1, min(args.batches, nsub))
-    cuts = [round(k * nsub / nb) for k in range(nb + 1)]
-    row_bytes = G * 17 * 4
+    dptr = andi_amd.lib._P(block.data_ptr())
 
     def step():
-        for e in esas[cuts[0]:cuts[1]]:
-            e.build()  # device index build (asynchronous)
-        for k in range(nb):
-            for e in esas[cuts[k + 1]:cuts[k + 2] if k + 2 <= nb else cuts[k + 1]]:
-                e.build()
-            lo, hi = cuts[k], cuts[k + 1]
-            lib.scan_rows_dev(ctx, esas[lo:hi], selfs[lo:hi], Q, model, args.segment,
-                              andi_amd.lib._P(block.data_ptr() + lo * row_bytes))  # anchor scan
-        ctx.sync()  # the engine's streams are not torch's: finish before the collective
+        for e in esas:
+            e.build()  # device index build
+        lib.scan_rows_dev(ctx, esas, selfs, Q, model, args.segment, dptr)  # anchor scan
+        ctx.sync()  # the engine's stream is not torch's: finish before the collective
         if use_dist:  # RCCL over xGMI: the one exchange of the job, 68 B per ordered pair
             gathered[0] = shard.gather_matrix(block, G, dist, world, rank, force=True)
 
