@@ -127,6 +127,7 @@ struct Window {
 	uint32_t q0, s0; // offsets of byte 0; q0 == ~0u: empty
 	uint32_t qc;   // 2-bit codes of this lane's 16 Q bytes, first byte in the top bits
 	uint32_t mask; // bits 0..15: byte differs; bits 16..31: Q byte is ACGT
+	uint4 sb;      // this lane's 16 S bytes (read where a substitution is counted)
 };
 
 __device__ __forceinline__ uint32_t diff_bits4(uint32_t x) { // one bit per non-zero byte
@@ -194,6 +195,7 @@ __device__ __forceinline__ void window_load(Window<G> &w, g_u8p Q, g_u8p S, uint
 	uint4 sb = ld_u128_unaligned(S + s0 + 16 * sub);
 	uint32_t qv;
 	codes16(qb, w.qc, qv);
+	w.sb = sb;
 	w.mask = diff_bits4(qb.x ^ sb.x) | (diff_bits4(qb.y ^ sb.y) << 4) | (diff_bits4(qb.z ^ sb.z) << 8) |
 			 (diff_bits4(qb.w ^ sb.w) << 12) | (qv << 16);
 }
@@ -277,7 +279,8 @@ __device__ __forceinline__ void window_count_gap(Window<G> &w, Tally &tally, g_u
 		// substitutions: fetch the subject's byte, one LDS add each
 		for (uint32_t d = qok & w.mask & 0xffffu; d; d &= d - 1) {
 			uint32_t t = (uint32_t)__builtin_ctz(d);
-			uint8_t sb = S[w.s0 + mine + t];
+			uint32_t word = t < 8 ? (t < 4 ? w.sb.x : w.sb.y) : (t < 12 ? w.sb.z : w.sb.w);
+			uint8_t sb = (uint8_t)(word >> (8 * (t & 3u)));
 			if ((int8_t)sb >= 'A') atomicAdd(&tally.hist[(nt_code(sb) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)], 1u);
 		}
 		const uint32_t done = hi - lo;
