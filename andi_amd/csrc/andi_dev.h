@@ -9,12 +9,18 @@
 //                        longest-match search as far as the K-mer alone decides
 //                        it, so most probes cost one random access
 //   rec  uint32[n]       scratch: K-mer code + valid length of every suffix
+//   N0   uint8[n/2+..]   the text as 4-bit symbols (A C G T ! ; # NUL = 0..7), symbol i in
+//                        the low (i even) or high half of byte i/2; N1 the same shifted by
+//                        one symbol (byte b = symbols 2b-1, 2b), so that a 16-byte load can
+//                        start at any symbol.  16 readable bytes in front, 128 behind.
 //   flags int32[4]       [0] != 0: some 10-mer table entry may span a separator
 //                        (SURVEY.md appendix C.11): the reference's cached lookup
 //                        is then not the true longest match and the scan follows
 //                        the reference walk below instead of the probe table
 //                        [2] set by the 10-mer table kernel when it really
 //                        produced such an entry (diagnostic)
+//                        [3] != 0: the text holds a byte outside {A C G T ! ; # NUL};
+//                        the packed-symbol scan is then not applicable
 // reference arrays (esa_s, src/esa.h:42-59; built on request or when flags[0]):
 //   LCP  int32[n+1]      LCP[0]=LCP[n]=-1          (K1, src/esa.c:373-426)
 //   CLD  int32[n+1]      child table                (K2, src/esa.c:312-363)
@@ -27,6 +33,7 @@
 #define ANDI_CACHE_K 10
 #define ANDI_PAD 2048 /* bytes of zero padding behind every byte pool */
 #define ANDI_MAX_DEEP_K 13
+#define ANDI_NIB_BACK 128 /* readable bytes behind the packed symbols of a text */
 
 struct EsaDev {
 	const uint8_t *S;
@@ -37,6 +44,7 @@ struct EsaDev {
 	const int4 *tab; // x=l y=i z=j w=m
 	const uint2 *deep;
 	const int32_t *flags;
+	const uint8_t *N0, *N1; // nibble-packed text, two alignments (scan_lane.hip)
 	int32_t n;
 	int32_t thr;
 	int32_t deepK;
@@ -66,6 +74,7 @@ struct EsaG {
 	g_u8p FVC;
 	g_i4p tab;
 	g_u2p deep;
+	g_u8p N0, N1;
 	int32_t n, thr, deepK, mode;
 };
 
@@ -74,6 +83,7 @@ __device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
 	g.S = (g_u8p)e.S, g.SA = (g_i32p)e.SA, g.LCP = (g_i32p)e.LCP, g.CLD = (g_i32p)e.CLD;
 	g.FVC = (g_u8p)e.FVC, g.tab = (g_i4p)e.tab;
 	g.deep = (g_u2p)e.deep;
+	g.N0 = (g_u8p)e.N0, g.N1 = (g_u8p)e.N1;
 	g.n = e.n, g.thr = e.thr, g.deepK = e.deepK, g.mode = e.mode;
 	return g;
 }

@@ -62,7 +62,8 @@ struct andi_hip_esa {
 	int32_t *min_scratch = nullptr;
 	uint2 *deep = nullptr;
 	uint32_t *rec = nullptr;
-	uint32_t *P2 = nullptr, *V = nullptr; // packed text for the index build
+	uint8_t *Nraw = nullptr;              // 4-bit symbols for the lane scan: N0 and N1 with their padding
+	uint8_t *N0 = nullptr, *N1 = nullptr;
 	int32_t *flags = nullptr;   // device, 4 ints
 	int32_t *h_flags = nullptr; // pinned host copy, refreshed after every index build
 	int32_t deepK = 0;
@@ -77,6 +78,8 @@ struct andi_hip_esa {
 
 struct andi_hip_queries {
 	uint8_t *pool = nullptr;
+	uint8_t *nib = nullptr;       // the pool as 4-bit symbols
+	int32_t *h_foreign = nullptr; // pinned: set if the pool holds bytes outside the alphabet
 	uint64_t *d_off = nullptr;
 	uint32_t *d_len = nullptr;
 	std::vector<uint64_t> off;
@@ -165,6 +168,7 @@ EsaDev esa_view(const andi_hip_esa *e, int mode) {
 	EsaDev v;
 	v.S = e->S, v.SA = e->SA, v.LCP = e->LCP, v.CLD = e->CLD, v.FVC = e->FVC, v.tab = e->tab;
 	v.deep = e->deep, v.flags = e->flags;
+	v.N0 = e->N0, v.N1 = e->N1;
 	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.mode = mode;
 	return v;
 }
@@ -183,7 +187,8 @@ int pick_deep_k(size_t n) {
 EsaBuildArgs build_args(const andi_hip_esa *e) {
 	EsaBuildArgs a;
 	a.S = e->S, a.SA = e->SA, a.LCP = e->LCP, a.CLD = e->CLD, a.FVC = e->FVC, a.tab = e->tab;
-	a.deep = e->deep, a.rec = e->rec, a.P2 = e->P2, a.V = e->V, a.flags = e->flags, a.deepK = e->deepK;
+	a.deep = e->deep, a.rec = e->rec, a.flags = e->flags, a.deepK = e->deepK;
+	a.N0 = e->N0, a.N1 = e->N1;
 	a.min_scratch = e->min_scratch;
 	a.n = e->n;
 	return a;
@@ -300,11 +305,17 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	chk(dmalloc(&e->SA, cap));
 	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
 	chk(dmalloc(&e->rec, cap));
-	chk(dmalloc(&e->P2, (cap + 1) / 16 + 8));
-	chk(dmalloc(&e->V, (cap + 1) / 32 + 8));
 	chk(dmalloc(&e->flags, 4));
+	// symbols: [16 B front][N0: cap/2 + 1 + back][N1: same], each part 16-byte aligned
+	const size_t nib_part = (cap / 2 + 1 + ANDI_NIB_BACK + 15) & ~(size_t)15;
+	chk(dmalloc(&e->Nraw, 2 * (16 + nib_part)));
+	if (err == hipSuccess) {
+		e->N0 = e->Nraw + 16, e->N1 = e->Nraw + 16 + nib_part + 16;
+		chk(hipMemsetAsync(e->Nraw, 0x77, 2 * (16 + nib_part), ctx->stream));
+	}
 	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault));
-	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 4 * cap + (cap + 1) / 4 + (cap + 1) / 8 + 80;
+	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 4 * cap + 80 +
+			   2 * (16 + nib_part);
 	if (err != hipSuccess) {
 		andi_hip_esa_free(ctx, e);
 		return fail(ctx, "allocating a subject", err);
@@ -441,8 +452,7 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	(void)hipFree(e->tab);
 	(void)hipFree(e->deep);
 	(void)hipFree(e->rec);
-	(void)hipFree(e->P2);
-	(void)hipFree(e->V);
+	(void)hipFree(e->Nraw);
 	(void)hipFree(e->flags);
 	(void)hipFree(e->min_scratch);
 	if (e->h_flags) (void)hipHostFree(e->h_flags);
@@ -483,6 +493,10 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 		if (err == hipSuccess) err = x;
 	};
 	chk(dmalloc(&q->pool, pool_bytes));
+	chk(dmalloc(&q->nib, pool_bytes / 2 + 16));
+	chk(hipHostMalloc((void **)&q->h_foreign, sizeof(int32_t), hipHostMallocDefault));
+	int32_t *d_foreign = nullptr;
+	chk(dmalloc(&d_foreign, 1));
 	chk(dmalloc(&q->d_off, n));
 	chk(dmalloc(&q->d_len, n));
 	if (err == hipSuccess) err = hipMemsetAsync(q->pool, 0, pool_bytes, ctx->stream);
@@ -493,7 +507,14 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 		err = hipMemcpyAsync(q->d_off, q->off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess)
 		err = hipMemcpyAsync(q->d_len, q->len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+	// 4-bit symbols of the whole pool (pool_bytes is a multiple of 16)
+	if (err == hipSuccess) err = hipMemsetAsync(d_foreign, 0, sizeof(int32_t), ctx->stream);
+	if (err == hipSuccess)
+		err = andi_launch_pack_symbols(q->pool, pool_bytes, q->nib, nullptr, d_foreign, ctx->stream);
+	if (err == hipSuccess)
+		err = hipMemcpyAsync(q->h_foreign, d_foreign, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
 	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d_foreign);
 	if (err != hipSuccess) {
 		andi_hip_queries_free(ctx, q);
 		return fail(ctx, "andi_hip_queries_stage", err);
@@ -509,6 +530,8 @@ void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q) {
 		(void)hipStreamSynchronize(ctx->stream);
 	}
 	(void)hipFree(q->pool);
+	(void)hipFree(q->nib);
+	if (q->h_foreign) (void)hipHostFree(q->h_foreign);
 	(void)hipFree(q->d_off);
 	(void)hipFree(q->d_len);
 	(void)hipFree(q->d_qseg_start);
@@ -610,7 +633,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	auto *h_esa = (EsaDev *)ctx->desc_host;
 	auto *h_self = (int64_t *)(h_esa + nsub);
 	uint64_t pairs = 0, nt = 0;
-	int any_reference = 0;
+	int any_reference = 0, any_foreign = 0;
 	// the index builds must have finished: their flags decide which walk is exact
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	for (size_t s = 0; s < nsub; ++s) {
@@ -628,6 +651,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			ctx->acc.reference_subjects++;
 			any_reference = 1;
 		}
+		if (e->index_built && e->h_flags[3]) any_foreign = 1;
 		h_esa[s] = esa_view(e, mode);
 		h_self[s] = self ? self[s] : -1;
 		bool has_self = h_self[s] >= 0 && (size_t)h_self[s] < q->nq;
@@ -654,7 +678,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.subjects = (const EsaDev *)ctx->desc_dev;
 	a.self = (const int64_t *)((const EsaDev *)ctx->desc_dev + nsub);
 	a.nsub = (uint32_t)nsub;
-	a.qpool = q->pool, a.qoff = q->d_off, a.qlen = q->d_len, a.nq = (uint32_t)q->nq;
+	a.qpool = q->pool, a.qnib = q->nib, a.qoff = q->d_off, a.qlen = q->d_len, a.nq = (uint32_t)q->nq;
 	a.qseg_start = q->d_qseg_start, a.seg2query = q->d_seg2query;
 	a.total_segs = q->total_segs, a.seg = segment;
 	char *p = (char *)ctx->scratch;
@@ -668,6 +692,10 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.M = M_dev;
 	a.fixups = ctx->d_fixups;
 	a.any_reference = any_reference;
+	a.group = andi_scan_group();
+	// the packed scan needs every byte inside the alphabet (the staging kernels check)
+	a.lanes = a.group == 0 && !*q->h_foreign && !any_foreign;
+	if (!a.lanes && a.group == 0) a.group = 4;
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 
 	{

@@ -21,8 +21,7 @@ struct EsaBuildArgs {
 	int4 *tab;          // 4^10    (out)
 	uint2 *deep;        // 4^deepK (out)
 	uint32_t *rec;      // n       (scratch)
-	uint32_t *P2;       // (n+1)/16 + 4 words: 2-bit codes of the text (scratch)
-	uint32_t *V;        // (n+1)/32 + 4 words: ACGT bitmap of the text (scratch)
+	uint8_t *N0, *N1;   // 4-bit symbols of the text, two alignments (out; see andi_dev.h)
 	int32_t *flags;     // 4 ints  (out)
 	int32_t deepK;
 	int32_t *min_scratch; // andi_min_tree_entries(n) ints

@@ -19,6 +19,7 @@
 //   K5b probe_table      4^K outcome table, one thread per suffix-array gap
 #include "andi_dev.h"
 #include "esa_build.h"
+#include "scan.h"
 
 #include <cstring>
 
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 // The anchor scan needs, per probe, only (match length, unique?, position).
 // The probe table answers that from the first K query characters.  It is built
 // bottom-up from the suffix array in two streaming passes; the only random
-// accesses are one 16-byte read of S per suffix.
+// accesses are one 8-byte read of the packed text per suffix.
 //
 // rec[r] describes suffix SA[r]: bits 31..6 the 2-bit code of its first K
 // characters (first character most significant, garbage past the valid part),
@@ -269,67 +270,36 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 #define REC_SEP(x) (((x) >> 4) & 3u)
 #define REC_CODE(x) ((x) >> 6)
 
-// K5p: 2-bit codes (16 per word, first character in the top bits) and an ACGT
-// bitmap (32 per word, first character in the top bit) of the text.  Together
-// 3 bits per character = 3.7 MB for a 9.8 M-character RS: the per-suffix random
-// reads of k_suffix_prefixes then mostly stay inside one XCD's L2.
-__global__ __launch_bounds__(256) void k_pack_text(const uint8_t *__restrict__ Sd, uint32_t *__restrict__ P2,
-												   uint32_t *__restrict__ V, int64_t words32) {
-	int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // 32 characters per thread
-	if (j >= words32) return;
-	g_u8p S = (g_u8p)Sd + 32 * j; // padding behind the text reads as NUL = not ACGT
-	uint32_t code[2], ok = 0;
-#pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		uint4 w = ld_u128_unaligned(S + 16 * h);
-		uint32_t words[4] = {w.x, w.y, w.z, w.w};
-		uint32_t c = 0;
-#pragma unroll
-		for (int d = 0; d < 4; ++d) {
-			uint32_t x = words[d] & 0x06060606u;
-			x ^= x >> 1;
-			x = (x >> 1) & 0x03030303u;
-			c = (c << 8) | ((x & 0xffu) << 6) | (((x >> 8) & 0xffu) << 4) | (((x >> 16) & 0xffu) << 2) | (x >> 24);
-			uint32_t m = words[d] & 0x40404040u; // bit 6: ACGT
-			ok = (ok << 4) | (((m >> 6) & 1u) << 3) | (((m >> 14) & 1u) << 2) | (((m >> 22) & 1u) << 1) | ((m >> 30) & 1u);
-		}
-		code[h] = c;
-	}
-	P2[2 * j] = code[0], P2[2 * j + 1] = code[1];
-	V[j] = ok;
-}
-
-// One thread per suffix; the two random reads are 8 bytes each (two adjacent
-// words of the packed arrays).  Measured ~97 us for 9.8 M suffixes whether the
-// reads are 4 x 4 B or 2 x 8 B, one or four suffixes per thread: the kernel sits
-// at the L2's random-request rate (~2 x 10^11 requests/s), not at bandwidth or
-// latency.
-__global__ __launch_bounds__(256) void k_suffix_prefixes(const uint8_t *__restrict__ Sd,
-														 const uint32_t *__restrict__ P2,
-														 const uint32_t *__restrict__ V,
+// One thread per suffix: one 8-byte read of the text's 4-bit symbols (N0, see
+// andi_dev.h) at the suffix's position -- the only random access of the build --
+// holds its first 15 symbols: K-mer code, number of leading nucleotides and the
+// separator behind them all come from that word.
+__global__ __launch_bounds__(256) void k_suffix_prefixes(const uint8_t *__restrict__ N0,
 														 const int32_t *__restrict__ SA,
 														 uint32_t *__restrict__ rec, int32_t n, int K) {
 	int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n) return;
 	const uint32_t p = (uint32_t)SA[r];
-	// words j, j+1 as one 8-byte load: low half = word j
-	uint64_t c2 = ld_u64_unaligned((g_u8p)(P2 + (p >> 4)));
-	uint64_t v2 = ld_u64_unaligned((g_u8p)(V + (p >> 5)));
-	// 16 codes starting at p
-	uint64_t cw = (c2 << 32) | (c2 >> 32);
-	uint32_t code = (uint32_t)((cw << (2 * (p & 15u))) >> 32);
-	// ACGT flags of the 32 characters starting at p, first character in the top bit
-	uint64_t vw = (v2 << 32) | (v2 >> 32);
-	uint32_t valid = (uint32_t)((vw << (p & 31u)) >> 32);
-	uint32_t v = (uint32_t)__builtin_clz(~valid | 1u); // leading ACGT characters
+	const uint64_t w = ld_u64_unaligned((g_u8p)N0 + (p >> 1)) >> (4 * (p & 1u)); // symbol i at bits 4i..4i+3
+	const uint64_t stop = (w & 0x4444444444444444ull) | (1ull << 62); // not a nucleotide (bit 2); symbol 15 is outside
+	uint32_t v = (uint32_t)__builtin_ctzll(stop) >> 2;                // leading ACGT characters, <= 15
 	uint32_t sep = 0;
 	if (v < (uint32_t)K) {
-		uint8_t c = ((g_u8p)Sd)[p + v]; // rare: suffix within K characters of a separator
-		sep = c == '!' ? 1u : (c == ';' ? 2u : 3u);
+		const uint32_t c = (uint32_t)(w >> (4 * v)) & 7u; // 4 '!', 5 ';', 6 '#', 7 NUL
+		sep = c == 4 ? 1u : (c == 5 ? 2u : 3u);
 	} else {
 		v = (uint32_t)K;
 	}
-	rec[r] = ((code >> (32 - 2 * K)) << 6) | (sep << 4) | v;
+	auto squeeze = [](uint32_t x) { // 8 nibbles -> 8 x 2 bits, first symbol in the low bits
+		x &= 0x33333333u;
+		x = (x | (x >> 2)) & 0x0f0f0f0fu;
+		x = (x | (x >> 4)) & 0x00ff00ffu;
+		x = (x | (x >> 8)) & 0x0000ffffu;
+		return x;
+	};
+	uint32_t y = __brev(squeeze((uint32_t)w) | (squeeze((uint32_t)(w >> 32)) << 16));
+	y = ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u); // first symbol in the top two bits
+	rec[r] = ((y >> (32 - 2 * K)) << 6) | (sep << 4) | v;
 }
 
 // leading characters two suffixes share, counting ACGT only, capped at K
@@ -454,11 +424,12 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
 	const int B = 256;
 	auto blocks = [&](int64_t items) { return (unsigned)((items + B - 1) / B); };
 	hipError_t e = hipMemsetAsync(a.flags, 0, 2 * sizeof(int32_t), st);
+	if (e == hipSuccess) e = hipMemsetAsync(a.flags + 3, 0, sizeof(int32_t), st);
 	if (e != hipSuccess) return e;
-	const int64_t words32 = ((int64_t)n + 1 + 31) / 32 + 1; // one spare word: two-word reads at the end
-	k_pack_text<<<blocks(words32), B, 0, st>>>(a.S, a.P2, a.V, words32);
-	CHECK_LAUNCH();
-	k_suffix_prefixes<<<blocks(n), B, 0, st>>>(a.S, a.P2, a.V, a.SA, a.rec, n, a.deepK);
+	// symbols for the lane scan: the text, its NUL and 64 bytes of the zero padding behind it
+	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 3, st);
+	if (e != hipSuccess) return e;
+	k_suffix_prefixes<<<blocks(n), B, 0, st>>>(a.N0, a.SA, a.rec, n, a.deepK);
 	CHECK_LAUNCH();
 	k_probe_table<<<blocks((int64_t)n + 1), B, 0, st>>>(a.rec, a.SA, a.deep, a.flags, n, a.deepK);
 	CHECK_LAUNCH();

@@ -23,6 +23,7 @@ struct ScanArgs {
 	uint32_t nsub;
 	// query pool
 	const uint8_t *qpool;
+	const uint8_t *qnib;  // the pool as 4-bit symbols: sequence q starts at qnib + qoff[q] / 2
 	const uint64_t *qoff; // [nq]
 	const uint32_t *qlen; // [nq]
 	uint32_t nq;
@@ -40,8 +41,20 @@ struct ScanArgs {
 	unsigned long long *fixups;
 	int exact_equal;   // LogDet/ANI: count the nucleotides of every anchor (src/model.c:256-278)
 	int any_reference; // some subject is in ANDI_MODE_REFERENCE: launch the reference-walk kernels too
+	int lanes;         // probe-table subjects: one lane per chain on packed symbols (scan_lane.hip)
+	int group;         // otherwise: lanes per chain of scan.hip's kernels (2, 4, 8)
 };
 
+// 4-bit symbols of `bytes` source bytes (a NUL-padded pool or text) into N0 and, if not
+// null, the one-symbol-shifted copy N1; `bytes` is rounded up to a multiple of 8; *foreign is
+// set to 1 if a byte is none of A C G T ! ; # NUL (the packed scan is then not applicable)
+hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N0, uint8_t *N1,
+									int32_t *foreign, hipStream_t st);
+// lanes per chain the scan runs with: 0 = one lane per chain on packed symbols
+// (scan_lane.hip, default), 1/2/4/8/16 = scan.hip's lane groups on bytes (ANDI_SCAN_G)
+int andi_scan_group(void);
+hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
+hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st);

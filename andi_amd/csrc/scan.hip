@@ -30,90 +30,9 @@
 // per group).  Every step of a chain is a handful of dependent, mostly random
 // memory accesses, so throughput is set by the number of chains in flight; the
 // result is bit-identical to the sequential loop.
-#include "scan.h"
+#include "scan_dev.h"
 
 #include <cstdlib>
-
-#define WAVES_PER_BLOCK 4
-#define BLOCK (64 * WAVES_PER_BLOCK)
-#define SCAN_G 4 /* lanes per chain in passes A and B (measured best of 4/8/16 on MI355X) */
-
-#define CHECK_LAUNCH()                                                                             \
-	do {                                                                                           \
-		hipError_t e_ = hipGetLastError();                                                         \
-		if (e_ != hipSuccess) return e_;                                                           \
-	} while (0)
-
-struct PairCtx {
-	EsaG E;
-	g_u8p Q;
-	uint32_t qlen;
-	uint32_t thr;
-	uint32_t border; // n / 2, src/process.c:149
-	bool exact;      // LogDet/ANI: equal runs are counted per nucleotide (src/model.c:256-278)
-};
-
-__device__ __forceinline__ bool same_state(const ChainState &a, const ChainState &b) {
-	return a.p == b.p && a.lastS == b.lastS && a.lastQ == b.lastQ && a.lastLen == b.lastLen &&
-		   a.lwra == b.lwra;
-}
-
-__device__ __forceinline__ ChainState initial_state() {
-	ChainState s;
-	s.p = s.lastS = s.lastQ = s.lastLen = s.lwra = 0;
-	s.pad[0] = s.pad[1] = s.pad[2] = 0;
-	return s;
-}
-
-// A state no real chain can be in: the "last anchor" sits at RS offset n, so
-// neither the lucky test (try_pos_S >= len, src/process.c:90) nor the
-// right-anchor test (pos_S > end_S, src/process.c:160) can fire until a real
-// anchor has replaced it, and its length 0 never gets counted.
-__device__ __forceinline__ ChainState cold_state(uint32_t start, uint32_t n) {
-	ChainState s = initial_state();
-	s.p = start;
-	s.lastS = n;
-	return s;
-}
-
-// What a chain adds to the 4x4 matrix.  Substitutions between anchors go to a
-// per-group histogram in LDS; the equal runs of model_count_equal (RAW/JC/Kimura:
-// len/4 to A->A, C->C, G->G and len/4 + len%4 to T->T, src/model.c:247-253) are
-// two running sums in registers, folded into the histogram at the end.
-struct Tally {
-	uint32_t *hist;        // LDS, 16 cells: substitutions found in gaps
-	uint32_t quarter, rest; // equal runs (uniform within the group)
-	uint32_t same[4];      // A->A, C->C, G->G, T->T pairs this lane saw in gaps
-};
-
-__device__ __forceinline__ void count_equal(Tally &t, uint32_t len) {
-	t.quarter += len >> 2;
-	t.rest += len & 3u;
-}
-
-template <int G>
-__device__ __forceinline__ void tally_begin(Tally &t, uint32_t *hist) {
-	t.hist = hist, t.quarter = 0, t.rest = 0;
-	t.same[0] = t.same[1] = t.same[2] = t.same[3] = 0;
-	for (uint32_t c = Group<G>::sub(); c < 16; c += G) hist[c] = 0;
-}
-
-// Fold the register-held parts into the LDS histogram (once, when the chain is done).
-template <int G>
-__device__ __forceinline__ void tally_finish(Tally &t) {
-#pragma unroll
-	for (int x = 0; x < 4; ++x) {
-		uint32_t v = t.same[x];
-		for (int d = G / 2; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
-		t.same[x] = v;
-	}
-	if (Group<G>::sub() == 0) {
-		t.hist[0] += t.quarter + t.same[0];
-		t.hist[5] += t.quarter + t.same[1];
-		t.hist[10] += t.quarter + t.same[2];
-		t.hist[15] += t.quarter + t.rest + t.same[3];
-	}
-}
 
 // A chain spends most of its steps on one diagonal (query offset p against
 // subject offset p + d), advancing ~1/divergence bytes per step.  Window keeps
@@ -281,7 +200,7 @@ __device__ __forceinline__ void window_count_gap(Window<G> &w, Tally &tally, g_u
 			uint32_t t = (uint32_t)__builtin_ctz(d);
 			uint32_t word = t < 8 ? (t < 4 ? w.sb.x : w.sb.y) : (t < 12 ? w.sb.z : w.sb.w);
 			uint8_t sb = (uint8_t)(word >> (8 * (t & 3u)));
-			if ((int8_t)sb >= 'A') atomicAdd(&tally.hist[(nt_code(sb) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)], 1u);
+			if ((int8_t)sb >= 'A') atomicAdd(&tally.hist[((nt_code(sb) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)) * tally.hs], 1u);
 		}
 		const uint32_t done = hi - lo;
 		q += done, s += done, len -= done;
@@ -417,54 +336,17 @@ __device__ __forceinline__ ChainState chain_step(const PairCtx &c, ChainState st
 	return st;
 }
 
-struct WorkItem {
-	uint32_t sub, w, qidx, seg_in_q, start, end;
-	bool valid, is_self;
-};
-
-__device__ __forceinline__ PairCtx make_ctx(const ScanArgs &a, uint32_t sub, uint32_t qidx) {
-	PairCtx c;
-	c.E = esa_global(a.subjects[sub]);
-	c.Q = (g_u8p)(a.qpool + a.qoff[qidx]);
-	c.qlen = a.qlen[qidx];
-	c.thr = (uint32_t)c.E.thr;
-	c.border = (uint32_t)c.E.n / 2;
-	c.exact = a.exact_equal != 0;
-	return c;
-}
-
-// work item of this lane's group: segment w of subject blockIdx.y
-template <int G>
-__device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {
-	WorkItem it;
-	it.sub = blockIdx.y;
-	it.w = (blockIdx.x * BLOCK + threadIdx.x) / G;
-	it.valid = it.w < a.total_segs;
-	it.qidx = it.seg_in_q = it.start = it.end = 0;
-	it.is_self = false;
-	if (it.valid) {
-		it.qidx = a.seg2query[it.w];
-		it.seg_in_q = it.w - a.qseg_start[it.qidx];
-		uint32_t qlen = a.qlen[it.qidx];
-		it.start = it.seg_in_q * a.seg;
-		uint32_t e = it.start + a.seg;
-		it.end = e < qlen ? e : qlen;
-		it.is_self = a.self[it.sub] == (int64_t)it.qidx;
-	}
-	return it;
-}
-
 // ------------------------------------------------------------------ pass A
 // MODE is a template parameter so that the kernel for probe-table subjects does
 // not carry the reference walk's code; blocks of the other mode's subjects exit.
 template <int G, int MODE, bool EXACT>
 __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
-	__shared__ uint32_t s_hist[BLOCK / G][16];
+	__shared__ uint32_t s_hist[BLOCK / G * 16];
 	if (a.subjects[blockIdx.y].mode != MODE) return;
 	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
 	Tally tally;
-	tally_begin<G>(tally, s_hist[threadIdx.x / G]);
+	tally_begin<G>(tally, G == 1 ? s_hist + threadIdx.x : s_hist + threadIdx.x / G * 16);
 
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
 	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, (uint32_t)c.E.n);
@@ -476,7 +358,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 	uint32_t lane = Group<G>::sub();
 	if (lane == 0) a.cold_exit[slot] = st;
 	tally_finish<G>(tally);
-	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = tally.hist[t];
+	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = tally.hist[t * tally.hs];
 }
 
 // Replays the true chain (entering in state T) through [start, end) next to the
@@ -512,7 +394,7 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 	tally_finish<G>(tT);
 	tally_finish<G>(tC);
 	if (synced) { // from the meeting point on, the cold chain's trajectory is the true one
-		for (uint32_t t = Group<G>::sub(); t < 16; t += G) histT[t] += coldCounts[t] - histC[t];
+		for (uint32_t t = Group<G>::sub(); t < 16; t += G) histT[t * tT.hs] += coldCounts[t] - histC[t * tT.hs];
 		T = coldExit;
 	}
 }
@@ -520,7 +402,7 @@ __device__ __forceinline__ void stitch_segment(const PairCtx &c, ChainState &T, 
 // ------------------------------------------------------------------ pass B
 template <int G, int MODE, bool EXACT>
 __global__ __launch_bounds__(BLOCK, 5) void k_scan_stitch(ScanArgs a) {
-	__shared__ uint32_t s_hist[BLOCK / G][2][16];
+	__shared__ uint32_t s_hist[2][BLOCK / G * 16];
 	if (a.subjects[blockIdx.y].mode != MODE) return;
 	WorkItem it = decode_item<G>(a);
 	if (!it.valid || it.is_self) return;
@@ -532,13 +414,14 @@ __global__ __launch_bounds__(BLOCK, 5) void k_scan_stitch(ScanArgs a) {
 		for (uint32_t t = lane; t < 16; t += G) a.owned[slot * 16 + t] = a.cold_counts[slot * 16 + t];
 		return;
 	}
-	uint32_t *histT = s_hist[threadIdx.x / G][0], *histC = s_hist[threadIdx.x / G][1];
+	const uint32_t cell0 = G == 1 ? threadIdx.x : threadIdx.x / G * 16;
+	uint32_t *histT = s_hist[0] + cell0, *histC = s_hist[1] + cell0;
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
 	ChainState T = a.cold_exit[slot - 1]; // assumed entry; verified in pass C
 	stitch_segment<G, MODE, EXACT>(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
 					  histC);
 	if (lane == 0) a.true_exit[slot] = T;
-	for (uint32_t t = lane; t < 16; t += G) a.owned[slot * 16 + t] = histT[t];
+	for (uint32_t t = lane; t < 16; t += G) a.owned[slot * 16 + t] = histT[t * hist_stride<G>()];
 }
 
 // ------------------------------------------------------------------ pass C
@@ -614,7 +497,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 
 	// src/process.c:199-211
 	Tally last;
-	last.hist = total, last.quarter = 0, last.rest = 0;
+	last.hist = total, last.hs = 1, last.quarter = 0, last.rest = 0;
 	last.same[0] = last.same[1] = last.same[2] = last.same[3] = 0;
 	if (fin.lastLen >= c.qlen || fin.lwra || fin.lastLen >= 2 * c.thr) {
 		const bool whole = fin.lastLen >= c.qlen;
@@ -649,22 +532,24 @@ __global__ __launch_bounds__(256) void k_match_positions(EsaDev Ed, const uint8_
 }
 
 // ------------------------------------------------------------------ launchers
-// lanes per chain; ANDI_SCAN_G overrides the default for experiments
-static int scan_group() {
-	static int g = [] {
-		const char *e = getenv("ANDI_SCAN_G");
-		int v = e ? atoi(e) : SCAN_G;
-		return (v == 2 || v == 4 || v == 8 || v == 16) ? v : SCAN_G;
-	}();
-	return g;
+// Which implementation passes A and B run with: 0 = one lane per chain on packed symbols
+// (scan_lane.hip, the default), 2/4/8 = this file's lane groups on bytes.  Subjects
+// that need the reference's own walk (ANDI_MODE_REFERENCE) always take the latter.
+int andi_scan_group(void) {
+	const char *e = getenv("ANDI_SCAN_G");
+	if (!e) return 0;
+	int v = atoi(e);
+	return (v == 0 || v == 2 || v == 4 || v == 8) ? v : 0;
 }
 
 template <int G, bool EXACT>
-static hipError_t launch_cold(const ScanArgs &a, hipStream_t st) {
+static hipError_t launch_cold(const ScanArgs &a, hipStream_t st, bool probe) {
 	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	k_scan_cold<G, ANDI_MODE_PROBE, EXACT><<<grid, BLOCK, 0, st>>>(a);
-	CHECK_LAUNCH();
+	if (probe) {
+		k_scan_cold<G, ANDI_MODE_PROBE, EXACT><<<grid, BLOCK, 0, st>>>(a);
+		CHECK_LAUNCH();
+	}
 	if (a.any_reference) {
 		k_scan_cold<G, ANDI_MODE_REFERENCE, EXACT><<<grid, BLOCK, 0, st>>>(a);
 		CHECK_LAUNCH();
@@ -673,11 +558,13 @@ static hipError_t launch_cold(const ScanArgs &a, hipStream_t st) {
 }
 
 template <int G, bool EXACT>
-static hipError_t launch_stitch(const ScanArgs &a, hipStream_t st) {
+static hipError_t launch_stitch(const ScanArgs &a, hipStream_t st, bool probe) {
 	const uint32_t per_block = BLOCK / G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	k_scan_stitch<G, ANDI_MODE_PROBE, EXACT><<<grid, BLOCK, 0, st>>>(a);
-	CHECK_LAUNCH();
+	if (probe) {
+		k_scan_stitch<G, ANDI_MODE_PROBE, EXACT><<<grid, BLOCK, 0, st>>>(a);
+		CHECK_LAUNCH();
+	}
 	if (a.any_reference) {
 		k_scan_stitch<G, ANDI_MODE_REFERENCE, EXACT><<<grid, BLOCK, 0, st>>>(a);
 		CHECK_LAUNCH();
@@ -685,20 +572,30 @@ static hipError_t launch_stitch(const ScanArgs &a, hipStream_t st) {
 	return hipSuccess;
 }
 
-#define DISPATCH_G(FN)                                                                             \
-	switch (scan_group()) {                                                                        \
-		case 2: return a.exact_equal ? FN<2, true>(a, st) : FN<2, false>(a, st);                   \
-		case 8: return a.exact_equal ? FN<8, true>(a, st) : FN<8, false>(a, st);                   \
-		case 16: return a.exact_equal ? FN<16, true>(a, st) : FN<16, false>(a, st);                \
-		default: return a.exact_equal ? FN<SCAN_G, true>(a, st) : FN<SCAN_G, false>(a, st);        \
+#define DISPATCH_G(FN, GROUP, PROBE)                                                               \
+	switch (GROUP) {                                                                               \
+		case 2: return a.exact_equal ? FN<2, true>(a, st, PROBE) : FN<2, false>(a, st, PROBE);     \
+		case 8: return a.exact_equal ? FN<8, true>(a, st, PROBE) : FN<8, false>(a, st, PROBE);     \
+		default:                                                                                   \
+			return a.exact_equal ? FN<SCAN_G, true>(a, st, PROBE) : FN<SCAN_G, false>(a, st, PROBE); \
 	}
 
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
-	DISPATCH_G(launch_cold)
+	if (a.lanes) {
+		hipError_t e = andi_launch_lane_cold(a, st);
+		if (e != hipSuccess || !a.any_reference) return e;
+		DISPATCH_G(launch_cold, SCAN_G, false)
+	}
+	DISPATCH_G(launch_cold, a.group, true)
 }
 
 hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
-	DISPATCH_G(launch_stitch)
+	if (a.lanes) {
+		hipError_t e = andi_launch_lane_stitch(a, st);
+		if (e != hipSuccess || !a.any_reference) return e;
+		DISPATCH_G(launch_stitch, SCAN_G, false)
+	}
+	DISPATCH_G(launch_stitch, a.group, true)
 }
 
 hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st) {

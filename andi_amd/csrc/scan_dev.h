@@ -1,0 +1,134 @@
+// scan_dev.h — device-side definitions shared by the two implementations of the
+// anchor scan: scan.hip (a group of G lanes per chain, byte sequences) and
+// scan_lane.hip (one lane per chain, nibble-packed sequences).
+#pragma once
+#include "scan.h"
+
+#define WAVES_PER_BLOCK 4
+#define BLOCK (64 * WAVES_PER_BLOCK)
+#define SCAN_G 4 /* lanes per chain in passes A and B (measured best of 4/8/16 on MI355X) */
+
+#define CHECK_LAUNCH()                                                                             \
+	do {                                                                                           \
+		hipError_t e_ = hipGetLastError();                                                         \
+		if (e_ != hipSuccess) return e_;                                                           \
+	} while (0)
+
+struct PairCtx {
+	EsaG E;
+	g_u8p Q;
+	g_u8p Qn; // packed symbols of the query
+	uint32_t qlen;
+	uint32_t thr;
+	uint32_t border; // n / 2, src/process.c:149
+	bool exact;      // LogDet/ANI: equal runs are counted per nucleotide (src/model.c:256-278)
+};
+
+__device__ __forceinline__ bool same_state(const ChainState &a, const ChainState &b) {
+	return a.p == b.p && a.lastS == b.lastS && a.lastQ == b.lastQ && a.lastLen == b.lastLen &&
+		   a.lwra == b.lwra;
+}
+
+__device__ __forceinline__ ChainState initial_state() {
+	ChainState s;
+	s.p = s.lastS = s.lastQ = s.lastLen = s.lwra = 0;
+	s.pad[0] = s.pad[1] = s.pad[2] = 0;
+	return s;
+}
+
+// A state no real chain can be in: the "last anchor" sits at RS offset n, so
+// neither the lucky test (try_pos_S >= len, src/process.c:90) nor the
+// right-anchor test (pos_S > end_S, src/process.c:160) can fire until a real
+// anchor has replaced it, and its length 0 never gets counted.
+__device__ __forceinline__ ChainState cold_state(uint32_t start, uint32_t n) {
+	ChainState s = initial_state();
+	s.p = start;
+	s.lastS = n;
+	return s;
+}
+
+// What a chain adds to the 4x4 matrix.  Substitutions between anchors go to a
+// per-group histogram in LDS; the equal runs of model_count_equal (RAW/JC/Kimura:
+// len/4 to A->A, C->C, G->G and len/4 + len%4 to T->T, src/model.c:247-253) are
+// two running sums in registers, folded into the histogram at the end.
+struct Tally {
+	uint32_t *hist;        // LDS, 16 cells `hs` words apart: substitutions found in gaps
+	uint32_t hs;
+	uint32_t quarter, rest; // equal runs (uniform within the group)
+	uint32_t same[4];      // A->A, C->C, G->G, T->T pairs this lane saw in gaps
+};
+
+__device__ __forceinline__ void count_equal(Tally &t, uint32_t len) {
+	t.quarter += len >> 2;
+	t.rest += len & 3u;
+}
+
+// One lane per chain: cell-major layout (cell c of chain k at [c][k]) keeps the lanes of a
+// wavefront on different LDS banks; otherwise the 16 cells of a group are contiguous.
+template <int G>
+__device__ __forceinline__ constexpr uint32_t hist_stride() {
+	return G == 1 ? BLOCK : 1;
+}
+
+template <int G>
+__device__ __forceinline__ void tally_begin(Tally &t, uint32_t *hist) {
+	t.hist = hist, t.hs = hist_stride<G>(), t.quarter = 0, t.rest = 0;
+	t.same[0] = t.same[1] = t.same[2] = t.same[3] = 0;
+	for (uint32_t c = Group<G>::sub(); c < 16; c += G) hist[c * t.hs] = 0;
+}
+
+// Fold the register-held parts into the LDS histogram (once, when the chain is done).
+template <int G>
+__device__ __forceinline__ void tally_finish(Tally &t) {
+#pragma unroll
+	for (int x = 0; x < 4; ++x) {
+		uint32_t v = t.same[x];
+		for (int d = G / 2; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+		t.same[x] = v;
+	}
+	if (Group<G>::sub() == 0) {
+		t.hist[0] += t.quarter + t.same[0];
+		t.hist[5 * t.hs] += t.quarter + t.same[1];
+		t.hist[10 * t.hs] += t.quarter + t.same[2];
+		t.hist[15 * t.hs] += t.quarter + t.rest + t.same[3];
+	}
+}
+
+struct WorkItem {
+	uint32_t sub, w, qidx, seg_in_q, start, end;
+	bool valid, is_self;
+};
+
+__device__ __forceinline__ PairCtx make_ctx(const ScanArgs &a, uint32_t sub, uint32_t qidx) {
+	PairCtx c;
+	c.E = esa_global(a.subjects[sub]);
+	c.Q = (g_u8p)(a.qpool + a.qoff[qidx]);
+	c.Qn = (g_u8p)(a.qnib + a.qoff[qidx] / 2);
+	c.qlen = a.qlen[qidx];
+	c.thr = (uint32_t)c.E.thr;
+	c.border = (uint32_t)c.E.n / 2;
+	c.exact = a.exact_equal != 0;
+	return c;
+}
+
+// work item of this lane's group: segment w of subject blockIdx.y
+template <int G>
+__device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {
+	WorkItem it;
+	it.sub = blockIdx.y;
+	it.w = (blockIdx.x * BLOCK + threadIdx.x) / G;
+	it.valid = it.w < a.total_segs;
+	it.qidx = it.seg_in_q = it.start = it.end = 0;
+	it.is_self = false;
+	if (it.valid) {
+		it.qidx = a.seg2query[it.w];
+		it.seg_in_q = it.w - a.qseg_start[it.qidx];
+		uint32_t qlen = a.qlen[it.qidx];
+		it.start = it.seg_in_q * a.seg;
+		uint32_t e = it.start + a.seg;
+		it.end = e < qlen ? e : qlen;
+		it.is_self = a.self[it.sub] == (int64_t)it.qidx;
+	}
+	return it;
+}
+

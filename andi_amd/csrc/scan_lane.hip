@@ -1,0 +1,463 @@
+// scan_lane.hip — passes A and B of the anchor scan (dist_anchor, src/process.c:141-214)
+// with ONE LANE PER CHAIN on nibble-packed sequences.
+//
+// scan.hip runs a chain on a group of G lanes that share every byte comparison.
+// A chain step is mostly control (src/process.c:153-197), and the groups of a
+// wavefront diverge, so there a wavefront pays the whole step for 64/G chains.
+// Here every lane owns a chain (segment) of its own: 64 chains per wavefront pay
+// each instruction once.  What makes that affordable is the packing: a symbol is
+// 4 bits (A C G T ! ; # NUL = 0..7, so equal bytes <=> equal nibbles), a 16-byte
+// load is a window of 32 symbols, and a lane compares, counts and forms K-mer
+// codes on its own registers with shifts, masks and population counts -- no
+// cross-lane traffic at all.  The subject text is kept in two alignments (N0,
+// N1 = N0 shifted by one symbol) so that a window of the subject can start at
+// any symbol while the query window starts at an even one.
+//
+// The chain logic, the probe table and the three-pass scheme (cold chains,
+// stitch, reduce) are those of scan.hip; the results are bit-identical.
+#include "scan_dev.h"
+
+#include <cstdlib>
+
+namespace {
+
+constexpr uint32_t WNT = 32; // symbols per window
+constexpr uint32_t EMPTY = ~0u;
+constexpr int32_t NO_DIAG = INT32_MIN;
+constexpr uint32_t ONES = 0x11111111u;
+constexpr uint32_t MULTI_MAX = 8; // occurrences a lane extends along one by one; more: binary search
+
+// 32 symbols of the query from q0 (even) and, if dg != NO_DIAG, of the subject from q0 + dg
+struct LWin {
+	uint32_t q0;
+	int32_t dg;
+	uint4 q, s;
+	uint4 d; // bit 4k of word j: symbols 8j + k differ
+};
+
+__device__ __forceinline__ uint32_t pick(const uint4 &v, uint32_t j) {
+	return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : j == 3 ? v.w : 0u;
+}
+
+__device__ __forceinline__ uint32_t neq8(uint32_t a, uint32_t b) { // one bit per differing nibble
+	uint32_t x = a ^ b;
+	x |= x >> 1;
+	x |= x >> 2;
+	return x & ONES;
+}
+
+__device__ __forceinline__ uint4 neq32(const uint4 &a, const uint4 &b) {
+	return make_uint4(neq8(a.x, b.x), neq8(a.y, b.y), neq8(a.z, b.z), neq8(a.w, b.w));
+}
+
+// index (0..31) of the first marked symbol at or after symbol o, 32 if none
+__device__ __forceinline__ uint32_t first_from(const uint4 &d, uint32_t o) {
+	uint64_t lo = d.x | ((uint64_t)d.y << 32), hi = d.z | ((uint64_t)d.w << 32);
+	const uint32_t sh = 4 * o;
+	if (sh < 64) {
+		lo = (lo >> sh) << sh;
+	} else {
+		lo = 0;
+		hi = sh < 128 ? (hi >> (sh - 64)) << (sh - 64) : 0;
+	}
+	if (lo) return (uint32_t)__builtin_ctzll(lo) >> 2;
+	if (hi) return 16 + ((uint32_t)__builtin_ctzll(hi) >> 2);
+	return WNT;
+}
+
+// bits 4a, 4a+4, ... 4b-4 (0 <= a < b <= 8)
+__device__ __forceinline__ uint32_t symbol_range(uint32_t a, uint32_t b) {
+	return (0xffffffffu >> (32 - 4 * b)) & ~((1u << (4 * a)) - 1u) & ONES;
+}
+
+__device__ __forceinline__ uint4 ld_query(const PairCtx &c, uint32_t qa) { // qa even
+	return ld_u128_unaligned(c.Qn + (qa >> 1));
+}
+
+__device__ __forceinline__ uint4 ld_subject(const PairCtx &c, int32_t sa) { // sa >= -32
+	const int32_t odd = sa & 1;
+	g_u8p base = odd ? c.E.N1 : c.E.N0;
+	return ld_u128_unaligned(base + ((sa + odd) >> 1));
+}
+
+__device__ __forceinline__ void win_load(LWin &w, const PairCtx &c, uint32_t qa, int32_t dg) {
+	w.q0 = qa, w.dg = dg;
+	w.q = ld_query(c, qa);
+	if (dg != NO_DIAG) {
+		w.s = ld_subject(c, (int32_t)qa + dg);
+		w.d = neq32(w.q, w.s);
+	}
+}
+
+// lcp(Q + p, S + t, maxlen) (src/process.c:59-65).  A window that has to be fetched
+// starts `back` (<= 16) symbols before p, where the gap since the last anchor begins,
+// so that the gap's substitutions can be counted from it too; a match that runs out
+// of the window slides the window along.
+__device__ __forceinline__ uint32_t lane_lcp(LWin &w, const PairCtx &c, uint32_t p, uint32_t t, uint32_t maxlen,
+											 uint32_t back) {
+	const int32_t dg = (int32_t)(t - p);
+	uint32_t o = p - w.q0;
+	if (w.q0 == EMPTY || w.dg != dg || p < w.q0 || o >= WNT) {
+		if (back > 16) back = 16;
+		const uint32_t qa = (p - back) & ~1u;
+		win_load(w, c, qa, dg);
+		o = p - qa;
+	}
+	uint32_t f = first_from(w.d, o);
+	if (f < WNT) {
+		const uint32_t len = f - o;
+		return len < maxlen ? len : maxlen;
+	}
+	uint32_t len = WNT - o;
+	while (len < maxlen) {
+		win_load(w, c, w.q0 + WNT, dg);
+		f = first_from(w.d, 0);
+		if (f < WNT) {
+			len += f;
+			break;
+		}
+		len += WNT;
+	}
+	return len < maxlen ? len : maxlen;
+}
+
+// Common prefix of Q[q0 + from ..] and S[q0 + from + dg ..], at most lim, where the
+// window holds the query symbols q0 .. q0 + 31 (the subject side is fetched).
+__device__ __forceinline__ uint32_t lane_extend(const LWin &w, const PairCtx &c, uint32_t from, int32_t dg,
+												uint32_t lim) {
+	uint4 d = neq32(w.q, ld_subject(c, (int32_t)w.q0 + dg));
+	uint32_t f = first_from(d, from);
+	if (f < WNT) {
+		const uint32_t len = f - from;
+		return len < lim ? len : lim;
+	}
+	uint32_t len = WNT - from, qa = w.q0 + WNT;
+	while (len < lim) {
+		d = neq32(ld_query(c, qa), ld_subject(c, (int32_t)qa + dg));
+		f = first_from(d, 0);
+		if (f < WNT) {
+			len += f;
+			break;
+		}
+		len += WNT, qa += WNT;
+	}
+	return len < lim ? len : lim;
+}
+
+// 2-bit code (first symbol most significant) of the K symbols at offset o of the
+// window (o + K <= 32); false if one of them is not a nucleotide.
+__device__ __forceinline__ bool lane_kmer(const LWin &w, uint32_t o, uint32_t K, uint32_t &code) {
+	const uint32_t j = o >> 3, r = (o & 7u) * 4u;
+	const uint32_t a = pick(w.q, j), b = pick(w.q, j + 1), e = pick(w.q, j + 2);
+	const uint32_t lo = __builtin_amdgcn_alignbit(b, a, r), hi = __builtin_amdgcn_alignbit(e, b, r);
+	const uint64_t v = lo | ((uint64_t)hi << 32);
+	const uint64_t inside = ~0ull >> (64 - 4 * K);
+	auto squeeze = [](uint32_t x) { // 8 nibbles -> 8 x 2 bits, first symbol in the low bits
+		x &= 0x33333333u;
+		x = (x | (x >> 2)) & 0x0f0f0f0fu;
+		x = (x | (x >> 4)) & 0x00ff00ffu;
+		x = (x | (x >> 8)) & 0x0000ffffu;
+		return x;
+	};
+	uint32_t y = __brev(squeeze(lo) | (squeeze(hi) << 16)); // first symbol on top, bits of a pair swapped
+	y = ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
+	code = y >> (32 - 2 * K);
+	return (v & inside & 0x4444444444444444ull) == 0;
+}
+
+// model_count (src/model.c:309-337) of Q[q..q+len) against S[s..s+len) through the window.
+__device__ __forceinline__ void lane_count_gap(LWin &w, const PairCtx &c, Tally &tally, uint32_t q, uint32_t s,
+											   uint32_t len) {
+	const int32_t dg = (int32_t)(s - q);
+	while (len) {
+		if (w.q0 == EMPTY || w.dg != dg || q < w.q0 || q >= w.q0 + WNT) win_load(w, c, q & ~1u, dg);
+		const uint32_t lo = q - w.q0, hi = lo + len < WNT ? lo + len : WNT;
+		for (uint32_t j = lo >> 3; 8 * j < hi; ++j) {
+			const uint32_t a = lo > 8 * j ? lo - 8 * j : 0u, b = hi - 8 * j < 8 ? hi - 8 * j : 8u;
+			const uint32_t qw = pick(w.q, j), sw = pick(w.s, j), dw = pick(w.d, j);
+			// both symbols are nucleotides (bit 2 clear), src/model.c:318-320
+			const uint32_t ok = symbol_range(a, b) & ~(qw >> 2) & ~(sw >> 2);
+			const uint32_t eq = ok & ~dw, b0 = qw, b1 = qw >> 1;
+			tally.same[0] += (uint32_t)__builtin_popcount(eq & ~(b0 | b1));
+			tally.same[1] += (uint32_t)__builtin_popcount(eq & b0 & ~b1);
+			tally.same[2] += (uint32_t)__builtin_popcount(eq & b1 & ~b0);
+			tally.same[3] += (uint32_t)__builtin_popcount(eq & b0 & b1);
+			for (uint32_t ne = ok & dw; ne; ne &= ne - 1) {
+				const uint32_t k = (uint32_t)__builtin_ctz(ne);
+				atomicAdd(&tally.hist[((((sw >> k) & 3u) << 2) | ((qw >> k) & 3u)) * tally.hs], 1u);
+			}
+		}
+		const uint32_t done = hi - lo;
+		q += done, s += done, len -= done;
+	}
+}
+
+// model_count_equal (src/model.c:246-279) for the anchor Q[qpos..qpos+len)
+template <bool EXACT>
+__device__ __forceinline__ void lane_count_anchor(const PairCtx &c, Tally &t, uint32_t qpos, uint32_t len) {
+	if constexpr (!EXACT) {
+		count_equal(t, len);
+		return;
+	}
+	const uint32_t qa = qpos & ~1u, end = qpos - qa + len;
+	uint32_t lo = qpos - qa;
+	for (uint32_t base = 0; base < end; base += WNT, lo = 0) {
+		const uint4 qv = ld_query(c, qa + base);
+		const uint32_t hi = end - base < WNT ? end - base : WNT;
+		for (uint32_t j = lo >> 3; 8 * j < hi; ++j) {
+			const uint32_t a = lo > 8 * j ? lo - 8 * j : 0u, b = hi - 8 * j < 8 ? hi - 8 * j : 8u;
+			const uint32_t qw = pick(qv, j);
+			const uint32_t ok = symbol_range(a, b) & ~(qw >> 2), b0 = qw, b1 = qw >> 1;
+			t.same[0] += (uint32_t)__builtin_popcount(ok & ~(b0 | b1));
+			t.same[1] += (uint32_t)__builtin_popcount(ok & b0 & ~b1);
+			t.same[2] += (uint32_t)__builtin_popcount(ok & b1 & ~b0);
+			t.same[3] += (uint32_t)__builtin_popcount(ok & b0 & b1);
+		}
+	}
+}
+
+// anchor() (src/process.c:113-123) through the probe table, as scan.hip's probe_step
+__device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &w) {
+	const EsaG &E = c.E;
+	const uint32_t qrem = c.qlen - p, K = (uint32_t)E.deepK;
+	g_u8p q = c.Q + p;
+	if (qrem <= K) return sa_range_match<1>(E, q, qrem, 0, E.n - 1, 0);
+	uint32_t o = p - w.q0;
+	if (w.q0 == EMPTY || p < w.q0 || o + K > WNT) {
+		const uint32_t qa = p & ~1u;
+		int32_t dg = w.dg; // stay on the diagonal the window was on while that is inside the text
+		if (dg != NO_DIAG && (uint32_t)((int32_t)qa + dg) >= (uint32_t)E.n) dg = NO_DIAG;
+		win_load(w, c, qa, dg);
+		o = p & 1u;
+	}
+	uint32_t code;
+	if (!lane_kmer(w, o, K, code)) return sa_range_match<1>(E, q, qrem, 0, E.n - 1, 0); // separator inside
+
+	const uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + code));
+	const uint32_t x = (uint32_t)raw, y = (uint32_t)(raw >> 32), kind = y & 3u;
+	Probe r;
+	if (kind == DEEP_FINAL) {
+		r.len = y >> 8, r.unique = (y >> 2) & 1u;
+		r.pos = (r.unique && r.len >= (uint32_t)E.thr) ? (uint32_t)E.SA[x] : 0u;
+		return r;
+	}
+	if (kind == DEEP_SINGLE) {
+		r.pos = x, r.unique = true;
+		r.len = K + lane_extend(w, c, o + K, (int32_t)(x - p), qrem - K);
+		return r;
+	}
+	if (kind != DEEP_MULTI) return sa_range_match<1>(E, q, qrem, 0, E.n - 1, 0);
+	const uint32_t cnt = (y >> 8) + 1;
+	if (cnt > MULTI_MAX) return sa_range_match<1>(E, q, qrem, (int32_t)x, (int32_t)(x + cnt - 1), K);
+	// the longest match is the best of the occurrences' own common prefixes with the
+	// query and it is unique iff exactly one attains it
+	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
+	for (uint32_t i = 0; i < cnt; ++i) {
+		const uint32_t pos = (uint32_t)E.SA[x + i];
+		const uint32_t len = K + lane_extend(w, c, o + K, (int32_t)(pos - p), qrem - K);
+		if (len > bestLen) {
+			bestLen = len, bestCnt = 1, bestPos = pos;
+		} else if (len == bestLen) {
+			++bestCnt;
+		}
+	}
+	r.len = bestLen, r.unique = bestCnt == 1, r.pos = bestPos;
+	return r;
+}
+
+// One trip of the while loop, src/process.c:153-197.
+template <bool EXACT>
+__device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st, Tally &tally, LWin &w) {
+	const uint32_t n = (uint32_t)c.E.n;
+	uint32_t curS = 0, curLen = 0;
+	bool found = false;
+
+	// lucky_anchor, src/process.c:82-100
+	const uint32_t advance = st.p - st.lastQ;
+	const uint32_t gap = advance - st.lastLen;
+	const uint32_t tryS = st.lastS + advance;
+	if (tryS < n && gap <= c.thr) {
+		curS = tryS;
+		curLen = lane_lcp(w, c, st.p, tryS, c.qlen - st.p, gap);
+		found = curLen >= c.thr;
+	}
+	// anchor, src/process.c:113-123
+	if (!found) {
+		Probe pr = lane_probe(c, st.p, w);
+		curS = pr.pos;
+		curLen = pr.len;
+		found = pr.unique && curLen >= c.thr;
+	}
+
+	if (found) {
+		const uint32_t endS = st.lastS + st.lastLen;
+		const uint32_t endQ = st.lastQ + st.lastLen;
+		if (curS > endS && st.p - endQ == curS - endS && (curS < c.border) == (st.lastS < c.border)) {
+			lane_count_anchor<EXACT>(c, tally, st.lastQ, st.lastLen);
+			lane_count_gap(w, c, tally, endQ, endS, st.p - endQ);
+			st.lwra = 1;
+		} else {
+			if (st.lwra || st.lastLen >= 2 * c.thr) lane_count_anchor<EXACT>(c, tally, st.lastQ, st.lastLen);
+			st.lwra = 0;
+		}
+		st.lastS = curS;
+		st.lastQ = st.p;
+		st.lastLen = curLen;
+	}
+	st.p += curLen + 1;
+	return st;
+}
+
+// ------------------------------------------------------------------ pass A
+// The lanes of a wavefront take consecutive segments of one query, so they see the
+// same divergence and stay in step.  (Persistent lanes that fetch their next segment
+// from a counter when done were measured 15-50 % slower: they mix pairs of different
+// divergence in one wavefront.)
+template <bool EXACT, int OCC>
+__global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
+	__shared__ uint32_t s_hist[16 * BLOCK];
+	if (a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
+	WorkItem it = decode_item<1>(a);
+	if (!it.valid || it.is_self) return;
+	Tally tally;
+	tally_begin<1>(tally, s_hist + threadIdx.x);
+
+	PairCtx c = make_ctx(a, it.sub, it.qidx);
+	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, (uint32_t)c.E.n);
+	LWin w;
+	w.q0 = EMPTY, w.dg = NO_DIAG;
+	while (st.p < it.end) st = lane_step<EXACT>(c, st, tally, w);
+
+	const size_t slot = (size_t)it.sub * a.total_segs + it.w;
+	a.cold_exit[slot] = st;
+	tally_finish<1>(tally);
+	uint32_t out[16];
+#pragma unroll
+	for (int t = 0; t < 16; ++t) out[t] = tally.hist[t * BLOCK];
+	uint4 *dst = (uint4 *)(a.cold_counts + slot * 16);
+#pragma unroll
+	for (int t = 0; t < 4; ++t) dst[t] = make_uint4(out[4 * t], out[4 * t + 1], out[4 * t + 2], out[4 * t + 3]);
+}
+
+// ------------------------------------------------------------------ pass B
+// as stitch_segment in scan.hip: the true chain (entering in state T) is replayed next
+// to the segment's cold chain until both are in the same state
+template <bool EXACT>
+__global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
+	__shared__ uint32_t s_hist[2][16 * BLOCK];
+	if (a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
+	WorkItem it = decode_item<1>(a);
+	if (!it.valid || it.is_self) return;
+	const size_t slot = (size_t)it.sub * a.total_segs + it.w;
+	const uint32_t *coldCounts = a.cold_counts + slot * 16;
+	uint32_t *owned = a.owned + slot * 16;
+
+	if (it.seg_in_q == 0) { // the first segment's "cold" chain is the true chain
+		a.true_exit[slot] = a.cold_exit[slot];
+		for (int t = 0; t < 16; ++t) owned[t] = coldCounts[t];
+		return;
+	}
+	PairCtx c = make_ctx(a, it.sub, it.qidx);
+	ChainState T = a.cold_exit[slot - 1]; // assumed entry; verified in pass C
+	ChainState C = cold_state(it.start, (uint32_t)c.E.n);
+	Tally tT, tC;
+	tally_begin<1>(tT, s_hist[0] + threadIdx.x);
+	tally_begin<1>(tC, s_hist[1] + threadIdx.x);
+	LWin w; // shared by both chains: they run next to each other
+	w.q0 = EMPTY, w.dg = NO_DIAG;
+	bool synced = false;
+	for (;;) {
+		if (same_state(T, C)) {
+			synced = true;
+			break;
+		}
+		if (T.p >= it.end) break;
+		const bool stepT = C.p >= it.end || T.p <= C.p; // one call site keeps the code small
+		Tally tx = stepT ? tT : tC;
+		ChainState nx = lane_step<EXACT>(c, stepT ? T : C, tx, w);
+		if (stepT) {
+			T = nx, tT = tx;
+		} else {
+			C = nx, tC = tx;
+		}
+	}
+	tally_finish<1>(tT);
+	tally_finish<1>(tC);
+	// from the meeting point on, the cold chain's trajectory is the true one
+	for (int t = 0; t < 16; ++t) {
+		uint32_t v = tT.hist[t * BLOCK];
+		if (synced) v += coldCounts[t] - tC.hist[t * BLOCK];
+		owned[t] = v;
+	}
+	a.true_exit[slot] = synced ? a.cold_exit[slot] : T;
+}
+
+// ------------------------------------------------------------------ packing
+__device__ __forceinline__ uint32_t symbol_of(uint8_t ch) {
+	return ch >= 'A' ? nt_code(ch) : (ch == '!' ? 4u : ch == ';' ? 5u : ch == '#' ? 6u : 7u);
+}
+
+__device__ __forceinline__ bool in_alphabet(uint8_t ch) {
+	return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == '!' || ch == ';' || ch == '#' || ch == 0;
+}
+
+// word j of N0 = symbols 8j .. 8j+7, word j of N1 = symbols 8j-1 .. 8j+6
+__global__ __launch_bounds__(256) void k_pack_symbols(const uint8_t *__restrict__ src, int64_t words,
+													  uint32_t *__restrict__ N0, uint32_t *__restrict__ N1,
+													  int32_t *__restrict__ foreign) {
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= words) return;
+	const uint64_t v = ld_u64_unaligned((g_u8p)src + 8 * j);
+	uint32_t w0 = 0;
+	bool ok = true;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const uint8_t ch = (uint8_t)(v >> (8 * k));
+		w0 |= symbol_of(ch) << (4 * k);
+		ok = ok && in_alphabet(ch);
+	}
+	if (!ok && foreign) *foreign = 1; // a byte outside the alphabet: only the byte kernels are exact
+	N0[j] = w0;
+	if (N1) N1[j] = (w0 << 4) | (j ? symbol_of(src[8 * j - 1]) : 7u);
+}
+
+} // namespace
+
+hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N0, uint8_t *N1,
+									int32_t *foreign, hipStream_t st) {
+	const int64_t words = (int64_t)((bytes + 7) / 8);
+	if (words == 0) return hipSuccess;
+	k_pack_symbols<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(src, words, (uint32_t *)N0, (uint32_t *)N1, foreign);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+static int lane_occupancy() { // waves per SIMD pass A is compiled for (experiments: ANDI_LANE_OCC)
+	const char *e = getenv("ANDI_LANE_OCC");
+	int v = e ? atoi(e) : 0;
+	return (v == 4 || v == 6 || v == 8) ? v : 8;
+}
+
+template <bool EXACT>
+static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
+	switch (lane_occupancy()) {
+		case 4: k_lane_cold<EXACT, 4><<<grid, BLOCK, 0, st>>>(a); break;
+		case 6: k_lane_cold<EXACT, 6><<<grid, BLOCK, 0, st>>>(a); break;
+		default: k_lane_cold<EXACT, 8><<<grid, BLOCK, 0, st>>>(a); break;
+	}
+	return hipGetLastError();
+}
+
+hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st) {
+	dim3 grid((a.total_segs + BLOCK - 1) / BLOCK, a.nsub);
+	return a.exact_equal ? lane_cold<true>(a, grid, st) : lane_cold<false>(a, grid, st);
+}
+
+hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st) {
+	dim3 grid((a.total_segs + BLOCK - 1) / BLOCK, a.nsub);
+	if (a.exact_equal)
+		k_lane_stitch<true><<<grid, BLOCK, 0, st>>>(a);
+	else
+		k_lane_stitch<false><<<grid, BLOCK, 0, st>>>(a);
+	return hipGetLastError();
+}
