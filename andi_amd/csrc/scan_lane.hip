@@ -17,7 +17,19 @@
 // stitch, reduce) are those of scan.hip; the results are bit-identical.
 #include "scan_dev.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+
+// -DANDI_LANE_STATS: count the memory accesses of pass A by kind (diagnostic builds only)
+#ifdef ANDI_LANE_STATS
+__device__ unsigned long long g_lane_stats[16];
+#define STAT(k) atomicAdd(&g_lane_stats[k], 1ull)
+#else
+#define STAT(k) ((void)0)
+#endif
+enum { ST_STEP, ST_LCP_RELOAD, ST_LCP_SLIDE, ST_PROBE, ST_PROBE_RELOAD, ST_TABLE, ST_FINAL_SA, ST_SINGLE, ST_EXT_LOOP,
+	   ST_MULTI, ST_MULTI_CAND, ST_SEARCH, ST_GAP_RELOAD, ST_GAP_WORDS, ST_SUBST, ST_LUCKY_TRY };
 
 namespace {
 
@@ -89,36 +101,41 @@ __device__ __forceinline__ void win_load(LWin &w, const PairCtx &c, uint32_t qa,
 	}
 }
 
-// lcp(Q + p, S + t, maxlen) (src/process.c:59-65).  A window that has to be fetched
-// starts `back` (<= 16) symbols before p, where the gap since the last anchor begins,
-// so that the gap's substitutions can be counted from it too; a match that runs out
-// of the window slides the window along.
-__device__ __forceinline__ uint32_t lane_lcp(LWin &w, const PairCtx &c, uint32_t p, uint32_t t, uint32_t maxlen,
-											 uint32_t back) {
+// lcp(Q + p, S + t, maxlen) (src/process.c:59-65) in two parts.  lcp_window answers from
+// the window: a window that has to be fetched starts `back` (<= 16) symbols before p,
+// where the gap since the last anchor begins, so that the gap's substitutions can be
+// counted from it too.  It returns the matching symbols inside the window and sets
+// `open` if the match runs on past the window's end; lcp_slide then follows it, moving
+// the window along (the caller counts the gap first, while the window still holds it).
+__device__ __forceinline__ uint32_t lcp_window(LWin &w, const PairCtx &c, uint32_t p, uint32_t t, uint32_t back,
+											   bool &open) {
 	const int32_t dg = (int32_t)(t - p);
 	uint32_t o = p - w.q0;
 	if (w.q0 == EMPTY || w.dg != dg || p < w.q0 || o >= WNT) {
 		if (back > 16) back = 16;
 		const uint32_t qa = (p - back) & ~1u;
 		win_load(w, c, qa, dg);
+		STAT(ST_LCP_RELOAD);
 		o = p - qa;
 	}
-	uint32_t f = first_from(w.d, o);
-	if (f < WNT) {
-		const uint32_t len = f - o;
-		return len < maxlen ? len : maxlen;
-	}
-	uint32_t len = WNT - o;
+	const uint32_t f = first_from(w.d, o);
+	open = f >= WNT;
+	return f - o;
+}
+
+// Follows a match past the window, one window per round trip.  (Fetching a whole cache
+// line of each sequence -- four windows -- per round trip was measured slower, also when
+// only matches that survive the next window are followed that way: most matches end
+// early and the extra pieces are wasted accesses.)
+__device__ __forceinline__ uint32_t lcp_slide(LWin &w, const PairCtx &c, uint32_t len, uint32_t maxlen) {
 	while (len < maxlen) {
-		win_load(w, c, w.q0 + WNT, dg);
-		f = first_from(w.d, 0);
-		if (f < WNT) {
-			len += f;
-			break;
-		}
+		win_load(w, c, w.q0 + WNT, w.dg);
+		STAT(ST_LCP_SLIDE);
+		const uint32_t f = first_from(w.d, 0);
+		if (f < WNT) return len + f;
 		len += WNT;
 	}
-	return len < maxlen ? len : maxlen;
+	return len;
 }
 
 // Common prefix of Q[q0 + from ..] and S[q0 + from + dg ..], at most lim, where the
@@ -134,6 +151,7 @@ __device__ __forceinline__ uint32_t lane_extend(const LWin &w, const PairCtx &c,
 	uint32_t len = WNT - from, qa = w.q0 + WNT;
 	while (len < lim) {
 		d = neq32(ld_query(c, qa), ld_subject(c, (int32_t)qa + dg));
+		STAT(ST_EXT_LOOP);
 		f = first_from(d, 0);
 		if (f < WNT) {
 			len += f;
@@ -170,11 +188,15 @@ __device__ __forceinline__ void lane_count_gap(LWin &w, const PairCtx &c, Tally 
 											   uint32_t len) {
 	const int32_t dg = (int32_t)(s - q);
 	while (len) {
-		if (w.q0 == EMPTY || w.dg != dg || q < w.q0 || q >= w.q0 + WNT) win_load(w, c, q & ~1u, dg);
+		if (w.q0 == EMPTY || w.dg != dg || q < w.q0 || q >= w.q0 + WNT) {
+			win_load(w, c, q & ~1u, dg);
+			STAT(ST_GAP_RELOAD);
+		}
 		const uint32_t lo = q - w.q0, hi = lo + len < WNT ? lo + len : WNT;
 		for (uint32_t j = lo >> 3; 8 * j < hi; ++j) {
 			const uint32_t a = lo > 8 * j ? lo - 8 * j : 0u, b = hi - 8 * j < 8 ? hi - 8 * j : 8u;
 			const uint32_t qw = pick(w.q, j), sw = pick(w.s, j), dw = pick(w.d, j);
+			STAT(ST_GAP_WORDS);
 			// both symbols are nucleotides (bit 2 clear), src/model.c:318-320
 			const uint32_t ok = symbol_range(a, b) & ~(qw >> 2) & ~(sw >> 2);
 			const uint32_t eq = ok & ~dw, b0 = qw, b1 = qw >> 1;
@@ -184,6 +206,7 @@ __device__ __forceinline__ void lane_count_gap(LWin &w, const PairCtx &c, Tally 
 			tally.same[3] += (uint32_t)__builtin_popcount(eq & b0 & b1);
 			for (uint32_t ne = ok & dw; ne; ne &= ne - 1) {
 				const uint32_t k = (uint32_t)__builtin_ctz(ne);
+				STAT(ST_SUBST);
 				atomicAdd(&tally.hist[((((sw >> k) & 3u) << 2) | ((qw >> k) & 3u)) * tally.hs], 1u);
 			}
 		}
@@ -221,6 +244,7 @@ __device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &
 	const EsaG &E = c.E;
 	const uint32_t qrem = c.qlen - p, K = (uint32_t)E.deepK;
 	g_u8p q = c.Q + p;
+	STAT(ST_PROBE);
 	if (qrem <= K) return sa_range_match<1>(E, q, qrem, 0, E.n - 1, 0);
 	uint32_t o = p - w.q0;
 	if (w.q0 == EMPTY || p < w.q0 || o + K > WNT) {
@@ -228,32 +252,39 @@ __device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &
 		int32_t dg = w.dg; // stay on the diagonal the window was on while that is inside the text
 		if (dg != NO_DIAG && (uint32_t)((int32_t)qa + dg) >= (uint32_t)E.n) dg = NO_DIAG;
 		win_load(w, c, qa, dg);
+		STAT(ST_PROBE_RELOAD);
 		o = p & 1u;
 	}
 	uint32_t code;
 	if (!lane_kmer(w, o, K, code)) return sa_range_match<1>(E, q, qrem, 0, E.n - 1, 0); // separator inside
 
 	const uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + code));
+	STAT(ST_TABLE);
 	const uint32_t x = (uint32_t)raw, y = (uint32_t)(raw >> 32), kind = y & 3u;
 	Probe r;
 	if (kind == DEEP_FINAL) {
 		r.len = y >> 8, r.unique = (y >> 2) & 1u;
 		r.pos = (r.unique && r.len >= (uint32_t)E.thr) ? (uint32_t)E.SA[x] : 0u;
+		if (r.unique && r.len >= (uint32_t)E.thr) STAT(ST_FINAL_SA);
 		return r;
 	}
 	if (kind == DEEP_SINGLE) {
 		r.pos = x, r.unique = true;
+		STAT(ST_SINGLE);
 		r.len = K + lane_extend(w, c, o + K, (int32_t)(x - p), qrem - K);
 		return r;
 	}
 	if (kind != DEEP_MULTI) return sa_range_match<1>(E, q, qrem, 0, E.n - 1, 0);
 	const uint32_t cnt = (y >> 8) + 1;
+	STAT(ST_MULTI);
+	if (cnt > MULTI_MAX) STAT(ST_SEARCH);
 	if (cnt > MULTI_MAX) return sa_range_match<1>(E, q, qrem, (int32_t)x, (int32_t)(x + cnt - 1), K);
 	// the longest match is the best of the occurrences' own common prefixes with the
 	// query and it is unique iff exactly one attains it
 	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
 	for (uint32_t i = 0; i < cnt; ++i) {
 		const uint32_t pos = (uint32_t)E.SA[x + i];
+		STAT(ST_MULTI_CAND);
 		const uint32_t len = K + lane_extend(w, c, o + K, (int32_t)(pos - p), qrem - K);
 		if (len > bestLen) {
 			bestLen = len, bestCnt = 1, bestPos = pos;
@@ -265,20 +296,50 @@ __device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &
 	return r;
 }
 
+// What an anchor at subject offset curS found at query offset st.p does to the counts
+// (src/process.c:157-190), apart from recording its own length.
+template <bool EXACT>
+__device__ __forceinline__ void lane_account(const PairCtx &c, ChainState &st, Tally &tally, LWin &w, uint32_t curS) {
+	const uint32_t endS = st.lastS + st.lastLen;
+	const uint32_t endQ = st.lastQ + st.lastLen;
+	if (curS > endS && st.p - endQ == curS - endS && (curS < c.border) == (st.lastS < c.border)) {
+		lane_count_anchor<EXACT>(c, tally, st.lastQ, st.lastLen);
+		lane_count_gap(w, c, tally, endQ, endS, st.p - endQ);
+		st.lwra = 1;
+	} else {
+		if (st.lwra || st.lastLen >= 2 * c.thr) lane_count_anchor<EXACT>(c, tally, st.lastQ, st.lastLen);
+		st.lwra = 0;
+	}
+}
+
 // One trip of the while loop, src/process.c:153-197.
 template <bool EXACT>
 __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st, Tally &tally, LWin &w) {
 	const uint32_t n = (uint32_t)c.E.n;
 	uint32_t curS = 0, curLen = 0;
-	bool found = false;
+	bool found = false, accounted = false;
+	STAT(ST_STEP);
 
 	// lucky_anchor, src/process.c:82-100
 	const uint32_t advance = st.p - st.lastQ;
 	const uint32_t gap = advance - st.lastLen;
 	const uint32_t tryS = st.lastS + advance;
 	if (tryS < n && gap <= c.thr) {
+		STAT(ST_LUCKY_TRY);
+		const uint32_t maxlen = c.qlen - st.p;
+		bool open;
 		curS = tryS;
-		curLen = lane_lcp(w, c, st.p, tryS, c.qlen - st.p, gap);
+		curLen = lcp_window(w, c, st.p, tryS, gap, open);
+		if (open) {
+			// certainly an anchor already: count the gap while the window still holds it
+			// (only then: a gap that starts before the window would move the window)
+			if (curLen >= c.thr && maxlen >= c.thr && st.p - gap >= w.q0) {
+				lane_account<EXACT>(c, st, tally, w, curS);
+				accounted = true;
+			}
+			curLen = lcp_slide(w, c, curLen, maxlen);
+		}
+		if (curLen > maxlen) curLen = maxlen;
 		found = curLen >= c.thr;
 	}
 	// anchor, src/process.c:113-123
@@ -290,16 +351,7 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 	}
 
 	if (found) {
-		const uint32_t endS = st.lastS + st.lastLen;
-		const uint32_t endQ = st.lastQ + st.lastLen;
-		if (curS > endS && st.p - endQ == curS - endS && (curS < c.border) == (st.lastS < c.border)) {
-			lane_count_anchor<EXACT>(c, tally, st.lastQ, st.lastLen);
-			lane_count_gap(w, c, tally, endQ, endS, st.p - endQ);
-			st.lwra = 1;
-		} else {
-			if (st.lwra || st.lastLen >= 2 * c.thr) lane_count_anchor<EXACT>(c, tally, st.lastQ, st.lastLen);
-			st.lwra = 0;
-		}
+		if (!accounted) lane_account<EXACT>(c, st, tally, w, curS);
 		st.lastS = curS;
 		st.lastQ = st.p;
 		st.lastLen = curLen;
@@ -450,7 +502,21 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st) {
 	dim3 grid((a.total_segs + BLOCK - 1) / BLOCK, a.nsub);
-	return a.exact_equal ? lane_cold<true>(a, grid, st) : lane_cold<false>(a, grid, st);
+	hipError_t e = a.exact_equal ? lane_cold<true>(a, grid, st) : lane_cold<false>(a, grid, st);
+#ifdef ANDI_LANE_STATS
+	if (e == hipSuccess && getenv("ANDI_LANE_STATS")) {
+		static const char *names[16] = {"steps", "lcp_reload", "lcp_slide", "probes", "probe_reload", "table", "final_sa",
+										"single", "ext_loop", "multi", "multi_cand", "search", "gap_reload", "gap_words",
+										"substitutions", "lucky_tries"};
+		unsigned long long h[16];
+		(void)hipStreamSynchronize(st);
+		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lane_stats), sizeof h);
+		for (int k = 0; k < 16; ++k) fprintf(stderr, "lane_stats %-14s %llu\n", names[k], h[k]);
+		memset(h, 0, sizeof h);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), h, sizeof h);
+	}
+#endif
+	return e;
 }
 
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st) {

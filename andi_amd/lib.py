@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libandihip.so")
+LIB_PATH = os.environ.get("ANDI_HIP_LIB") or os.path.join(_HERE, "libandihip.so")  # override: diagnostic builds
 
 M_RAW, M_JC, M_KIMURA, M_LOGDET, M_ANI = range(5)
 MODEL_NAMES = {"raw": M_RAW, "jc": M_JC, "kimura": M_KIMURA, "logdet": M_LOGDET, "ani": M_ANI}

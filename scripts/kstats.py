@@ -11,7 +11,7 @@ tot = defaultdict(float)
 cnt = defaultdict(int)
 for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0]
+        k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         tot[k] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
         cnt[k] += 1
 allt = sum(tot.values())
