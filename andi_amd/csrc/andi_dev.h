@@ -17,10 +17,10 @@
 //                        (SURVEY.md appendix C.11): the reference's cached lookup
 //                        is then not the true longest match and the scan follows
 //                        the reference walk below instead of the probe table
+//                        [1] != 0: the text holds a byte outside {A C G T ! ; # NUL};
+//                        the packed-symbol scan is then not applicable
 //                        [2] set by the 10-mer table kernel when it really
 //                        produced such an entry (diagnostic)
-//                        [3] != 0: the text holds a byte outside {A C G T ! ; # NUL};
-//                        the packed-symbol scan is then not applicable
 // reference arrays (esa_s, src/esa.h:42-59; built on request or when flags[0]):
 //   LCP  int32[n+1]      LCP[0]=LCP[n]=-1          (K1, src/esa.c:373-426)
 //   CLD  int32[n+1]      child table                (K2, src/esa.c:312-363)

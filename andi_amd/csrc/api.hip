@@ -651,7 +651,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			ctx->acc.reference_subjects++;
 			any_reference = 1;
 		}
-		if (e->index_built && e->h_flags[3]) any_foreign = 1;
+		if (e->index_built && e->h_flags[1]) any_foreign = 1;
 		h_esa[s] = esa_view(e, mode);
 		h_self[s] = self ? self[s] : -1;
 		bool has_self = h_self[s] >= 0 && (size_t)h_self[s] < q->nq;

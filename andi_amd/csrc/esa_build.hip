@@ -319,87 +319,146 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 	return same < va ? same : va;
 }
 
-// One thread per gap r = 0..n of the suffix array (between suffix r-1 and r).
-//  (a) if suffix r starts a run of suffixes with the same valid K-mer, write that
-//      K-mer's entry: SINGLE (position) or MULTI (first SA index and run length);
-//  (b) every K-mer that sorts strictly inside the gap is absent from RS: its
-//      longest match is the longer of its common prefixes with the two
-//      neighbours; write FINAL(l, unique, SA index);
-//  (c) detect what can make the reference's 10-mer table differ from the true
+// One thread per gap r = 0..n of the suffix array (between suffix r-1 and r) works out
+// what the gap owns:
+//  (a) if suffix r starts a run of suffixes with the same valid K-mer, that K-mer's
+//      entry: SINGLE (position) or MULTI (first SA index and run length);
+//  (b) every K-mer that sorts strictly inside the gap is absent from RS: its longest
+//      match is the longer of its common prefixes with the two neighbours,
+//      FINAL(l, unique, SA index);
+//  (c) it detects what can make the reference's 10-mer table differ from the true
 //      longest match: a prefix w (1..8 ACGT characters) whose every occurrence is
 //      followed by the same separator, at least twice (SURVEY.md appendix C.11;
 //      this test is a superset of the exact condition) -> flags[0].
-__global__ __launch_bounds__(256) void k_probe_table(const uint32_t *__restrict__ rec,
-													 const int32_t *__restrict__ SA,
-													 uint2 *__restrict__ deep,
-													 int32_t *__restrict__ flags, int32_t n, int K) {
-	int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (gid > n) return;
-	const int32_t r = (int32_t)gid;
-	const bool hasL = r > 0, hasR = r < n;
+// The codes owned by consecutive gaps are consecutive ranges (absent codes of gap r,
+// then the K-mer of suffix r), so a block of 256 gaps owns one contiguous piece of the
+// table.  The block writes that piece together, entry t by thread t mod 256 (coalesced,
+// no divergent per-gap loops); a binary search over the gaps' offsets tells an entry
+// which gap it belongs to.
+#define PT_BLOCK 256
+__global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint32_t *__restrict__ rec,
+														  const int32_t *__restrict__ SA,
+														  uint2 *__restrict__ deep,
+														  int32_t *__restrict__ flags, int32_t n, int K) {
+	__shared__ uint32_t s_off[PT_BLOCK + 1]; // exclusive prefix sums of the gaps' entry counts
+	__shared__ uint32_t s_first[PT_BLOCK];   // first code a gap owns
+	__shared__ uint32_t s_absent[PT_BLOCK];  // number of absent codes it owns (they come first)
+	__shared__ uint32_t s_L[PT_BLOCK], s_R[PT_BLOCK], s_hh[PT_BLOCK];
+	__shared__ uint2 s_present[PT_BLOCK];    // entry of the K-mer of suffix r, if the gap owns it
+	__shared__ uint32_t s_wave[PT_BLOCK / 64];
+
+	const int64_t gid = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+	const bool live = gid <= n;
+	const int32_t r = (int32_t)(live ? gid : 0);
+	const bool hasL = live && r > 0, hasR = live && r < n;
 	const uint32_t L = hasL ? rec[r - 1] : 0u, R = hasR ? rec[r] : 0u;
 	const uint32_t full = (uint32_t)K;
 	const uint32_t h = (hasL && hasR) ? rec_lcp(L, R, K) : 0u;
+	uint32_t absent = 0, first = 0, owns_present = 0;
+	uint2 present = make_uint2(0, 0);
 
-	// (a) present K-mers
-	if (hasR && REC_V(R) == full && !(hasL && REC_V(L) == full && REC_CODE(L) == REC_CODE(R))) {
-		int32_t j = r;
-		while (j + 1 < n && rec[j + 1] == R) ++j;
-		uint32_t code = REC_CODE(R);
-		if (j == r) {
-			deep[code] = make_uint2((uint32_t)SA[r], DEEP_SINGLE | (1u << 2) | (full << 8));
-		} else if ((uint32_t)(j - r) < (1u << 24)) {
-			deep[code] = make_uint2((uint32_t)r, DEEP_MULTI | ((uint32_t)(j - r) << 8));
-		} else {
-			deep[code] = make_uint2(0, DEEP_SEARCH);
-		}
-	}
-
-	// (c) closed run of suffixes "w <sep>" with 1 <= |w| <= 8
-	if (hasR) {
-		uint32_t k = REC_V(R), sp = REC_SEP(R);
-		if (k >= 1 && k <= 8 && k < full && (sp == 1 || sp == 2) && (!hasL || h < k)) {
+	if (live) {
+		// (a) present K-mers
+		if (hasR && REC_V(R) == full && !(hasL && REC_V(L) == full && REC_CODE(L) == REC_CODE(R))) {
 			int32_t j = r;
-			while (j + 1 < n) {
-				uint32_t X = rec[j + 1];
-				if (REC_V(X) == k && REC_SEP(X) == sp && rec_lcp(R, X, K) == k) ++j; else break;
+			while (j + 1 < n && rec[j + 1] == R) ++j;
+			if (j == r) {
+				present = make_uint2((uint32_t)SA[r], DEEP_SINGLE | (1u << 2) | (full << 8));
+			} else if ((uint32_t)(j - r) < (1u << 24)) {
+				present = make_uint2((uint32_t)r, DEEP_MULTI | ((uint32_t)(j - r) << 8));
+			} else {
+				present = make_uint2(0, DEEP_SEARCH);
 			}
-			if (j > r && (j + 1 == n || rec_lcp(R, rec[j + 1], K) < k)) atomicOr(&flags[0], 1);
+			owns_present = 1;
+			first = REC_CODE(R);
+		}
+
+		// (c) closed run of suffixes "w <sep>" with 1 <= |w| <= 8
+		if (hasR) {
+			uint32_t k = REC_V(R), sp = REC_SEP(R);
+			if (k >= 1 && k <= 8 && k < full && (sp == 1 || sp == 2) && (!hasL || h < k)) {
+				int32_t j = r;
+				while (j + 1 < n) {
+					uint32_t X = rec[j + 1];
+					if (REC_V(X) == k && REC_SEP(X) == sp && rec_lcp(R, X, K) == k) ++j; else break;
+				}
+				if (j > r && (j + 1 == n || rec_lcp(R, rec[j + 1], K) < k)) atomicOr(&flags[0], 1);
+			}
+		}
+
+		// (b) absent K-mers inside this gap
+		int64_t lo, hi;
+		if (!hasL) {
+			lo = 0;
+		} else if (REC_V(L) == full) {
+			lo = (int64_t)REC_CODE(L) + 1;
+		} else { // w <sep> sorts before every K-mer that starts with w
+			uint32_t sh = 2 * (full - REC_V(L));
+			lo = (int64_t)((REC_CODE(L) >> sh) << sh);
+		}
+		if (!hasR) {
+			hi = ((int64_t)1 << (2 * K)) - 1;
+		} else if (REC_V(R) == full) {
+			hi = (int64_t)REC_CODE(R) - 1;
+		} else {
+			uint32_t sh = 2 * (full - REC_V(R));
+			hi = (int64_t)((REC_CODE(R) >> sh) << sh) - 1;
+		}
+		if (lo <= hi) {
+			absent = (uint32_t)(hi - lo + 1);
+			first = (uint32_t)lo;
 		}
 	}
-
-	// (b) absent K-mers inside this gap
-	int64_t lo, hi;
-	if (!hasL) {
-		lo = 0;
-	} else if (REC_V(L) == full) {
-		lo = (int64_t)REC_CODE(L) + 1;
-	} else { // w <sep> sorts before every K-mer that starts with w
-		uint32_t sh = 2 * (full - REC_V(L));
-		lo = (int64_t)((REC_CODE(L) >> sh) << sh);
-	}
-	if (!hasR) {
-		hi = ((int64_t)1 << (2 * K)) - 1;
-	} else if (REC_V(R) == full) {
-		hi = (int64_t)REC_CODE(R) - 1;
-	} else {
-		uint32_t sh = 2 * (full - REC_V(R));
-		hi = (int64_t)((REC_CODE(R) >> sh) << sh) - 1;
-	}
-	if (lo > hi) return;
 	// is the left (right) neighbour the only suffix sharing a given prefix length with it?
-	const uint32_t hLL = (r >= 2) ? rec_lcp(rec[r - 2], L, K) : 0u;  // lcp(suffix r-2, suffix r-1)
-	const uint32_t hRR = (r + 1 < n) ? rec_lcp(R, rec[r + 1], K) : 0u; // lcp(suffix r, suffix r+1)
-	for (int64_t c = lo; c <= hi; ++c) {
-		uint32_t lL = hasL ? rec_lcp_code((uint32_t)c, L, K) : 0u;
-		uint32_t lR = hasR ? rec_lcp_code((uint32_t)c, R, K) : 0u;
+	const uint32_t hLL = (live && r >= 2) ? rec_lcp(rec[r - 2], L, K) : 0u;      // lcp(suffix r-2, suffix r-1)
+	const uint32_t hRR = (live && r + 1 < n) ? rec_lcp(R, rec[r + 1], K) : 0u; // lcp(suffix r, suffix r+1)
+
+	// block-wide exclusive scan of the entry counts
+	const uint32_t mine = absent + owns_present, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t incl = mine;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t other = (uint32_t)__shfl_up((int)incl, d);
+		if (lane >= (uint32_t)d) incl += other;
+	}
+	if (lane == 63) s_wave[wave] = incl;
+	s_first[threadIdx.x] = first, s_absent[threadIdx.x] = absent;
+	s_L[threadIdx.x] = L, s_R[threadIdx.x] = R, s_hh[threadIdx.x] = hLL | (hRR << 8);
+	s_present[threadIdx.x] = present;
+	__syncthreads();
+	uint32_t before = 0;
+	for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+	s_off[threadIdx.x] = before + incl - mine;
+	uint32_t total = 0;
+	for (uint32_t w = 0; w < PT_BLOCK / 64; ++w) total += s_wave[w];
+	if (threadIdx.x == 0) s_off[PT_BLOCK] = total;
+	__syncthreads();
+
+	const int64_t r0 = (int64_t)blockIdx.x * PT_BLOCK;
+	for (uint32_t t = threadIdx.x; t < total; t += PT_BLOCK) {
+		// the gap that owns entry t: the last one whose offset is <= t
+		uint32_t a = 0, b = PT_BLOCK; // invariant: s_off[a] <= t < s_off[b]
+		while (b - a > 1) {
+			uint32_t mid = (a + b) >> 1;
+			if (s_off[mid] <= t) a = mid; else b = mid;
+		}
+		const uint32_t k = t - s_off[a], c = s_first[a] + k;
+		if (k >= s_absent[a]) { // the K-mer of suffix r itself
+			deep[c] = s_present[a];
+			continue;
+		}
+		const int64_t rr = r0 + a;
+		const bool gL = rr > 0, gR = rr < n;
+		const uint32_t gl = s_L[a], gr = s_R[a], hll = s_hh[a] & 0xffu, hrr = s_hh[a] >> 8;
+		uint32_t lL = gL ? rec_lcp_code(c, gl, K) : 0u;
+		uint32_t lR = gR ? rec_lcp_code(c, gr, K) : 0u;
 		uint32_t l, uniq, idx;
 		if (lL > lR) {
-			l = lL, idx = (uint32_t)(r - 1);
-			uniq = (r < 2 || hLL < l) ? 1u : 0u;
+			l = lL, idx = (uint32_t)(rr - 1);
+			uniq = (rr < 2 || hll < l) ? 1u : 0u;
 		} else if (lR > lL) {
-			l = lR, idx = (uint32_t)r;
-			uniq = (r + 1 >= n || hRR < l) ? 1u : 0u;
+			l = lR, idx = (uint32_t)rr;
+			uniq = (rr + 1 >= n || hrr < l) ? 1u : 0u;
 		} else { // both neighbours share l characters (or l == 0: every suffix does)
 			l = lL, idx = 0, uniq = (n == 1) ? 1u : 0u;
 		}
@@ -424,14 +483,14 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
 	const int B = 256;
 	auto blocks = [&](int64_t items) { return (unsigned)((items + B - 1) / B); };
 	hipError_t e = hipMemsetAsync(a.flags, 0, 2 * sizeof(int32_t), st);
-	if (e == hipSuccess) e = hipMemsetAsync(a.flags + 3, 0, sizeof(int32_t), st);
 	if (e != hipSuccess) return e;
 	// symbols for the lane scan: the text, its NUL and 64 bytes of the zero padding behind it
-	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 3, st);
+	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 1, st);
 	if (e != hipSuccess) return e;
 	k_suffix_prefixes<<<blocks(n), B, 0, st>>>(a.N0, a.SA, a.rec, n, a.deepK);
 	CHECK_LAUNCH();
-	k_probe_table<<<blocks((int64_t)n + 1), B, 0, st>>>(a.rec, a.SA, a.deep, a.flags, n, a.deepK);
+	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_BLOCK - 1) / PT_BLOCK), PT_BLOCK, 0, st>>>(a.rec, a.SA, a.deep, a.flags, n,
+																				  a.deepK);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }

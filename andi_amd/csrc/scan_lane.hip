@@ -453,33 +453,40 @@ __device__ __forceinline__ bool in_alphabet(uint8_t ch) {
 	return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == '!' || ch == ';' || ch == '#' || ch == 0;
 }
 
-// word j of N0 = symbols 8j .. 8j+7, word j of N1 = symbols 8j-1 .. 8j+6
-__global__ __launch_bounds__(256) void k_pack_symbols(const uint8_t *__restrict__ src, int64_t words,
-													  uint32_t *__restrict__ N0, uint32_t *__restrict__ N1,
+// word j of N0 = symbols 8j .. 8j+7, word j of N1 = symbols 8j-1 .. 8j+6.  One thread
+// packs 16 bytes (two words of each copy) through a 256-entry table in LDS.
+__global__ __launch_bounds__(256) void k_pack_symbols(const uint8_t *__restrict__ src, int64_t pairs,
+													  uint2 *__restrict__ N0, uint2 *__restrict__ N1,
 													  int32_t *__restrict__ foreign) {
+	__shared__ uint8_t lut[256]; // symbol | 0x80 if the byte is outside the alphabet
+	lut[threadIdx.x] = (uint8_t)(symbol_of((uint8_t)threadIdx.x) | (in_alphabet((uint8_t)threadIdx.x) ? 0u : 0x80u));
+	__syncthreads();
 	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= words) return;
-	const uint64_t v = ld_u64_unaligned((g_u8p)src + 8 * j);
-	uint32_t w0 = 0;
-	bool ok = true;
+	if (j >= pairs) return;
+	const uint4 v = ld_u128_unaligned((g_u8p)src + 16 * j);
+	const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+	uint32_t w[2] = {0, 0}, bad = 0;
 #pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		const uint8_t ch = (uint8_t)(v >> (8 * k));
-		w0 |= symbol_of(ch) << (4 * k);
-		ok = ok && in_alphabet(ch);
+	for (int k = 0; k < 16; ++k) {
+		const uint32_t e = lut[(in[k >> 2] >> (8 * (k & 3))) & 0xffu];
+		w[k >> 3] |= (e & 7u) << (4 * (k & 7));
+		bad |= e;
 	}
-	if (!ok && foreign) *foreign = 1; // a byte outside the alphabet: only the byte kernels are exact
-	N0[j] = w0;
-	if (N1) N1[j] = (w0 << 4) | (j ? symbol_of(src[8 * j - 1]) : 7u);
+	if ((bad & 0x80u) && foreign) *foreign = 1; // a byte outside the alphabet: only the byte kernels are exact
+	N0[j] = make_uint2(w[0], w[1]);
+	if (N1) {
+		const uint32_t prev = j ? (lut[src[16 * j - 1]] & 7u) : 7u;
+		N1[j] = make_uint2((w[0] << 4) | prev, (w[1] << 4) | (w[0] >> 28));
+	}
 }
 
 } // namespace
 
 hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N0, uint8_t *N1,
 									int32_t *foreign, hipStream_t st) {
-	const int64_t words = (int64_t)((bytes + 7) / 8);
-	if (words == 0) return hipSuccess;
-	k_pack_symbols<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(src, words, (uint32_t *)N0, (uint32_t *)N1, foreign);
+	const int64_t pairs = (int64_t)((bytes + 15) / 16);
+	if (pairs == 0) return hipSuccess;
+	k_pack_symbols<<<(unsigned)((pairs + 255) / 256), 256, 0, st>>>(src, pairs, (uint2 *)N0, (uint2 *)N1, foreign);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
