@@ -519,6 +519,7 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 		andi_hip_queries_free(ctx, q);
 		return fail(ctx, "andi_hip_queries_stage", err);
 	}
+
 	*out = q;
 	return 0;
 }
@@ -608,6 +609,10 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		return 1;
 	}
 	auto *q = const_cast<andi_hip_queries *>(q_const);
+	if (*q->h_foreign) { // the reference's reader never produces that (src/sequence.c:260-282)
+		ctx->err = "andi_hip_scan_rows: a query holds a byte outside {A,C,G,T,!}";
+		return 1;
+	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (segment == 0) {
 		uint64_t nt = q->total_nt * (uint64_t)nsub;
@@ -633,7 +638,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	auto *h_esa = (EsaDev *)ctx->desc_host;
 	auto *h_self = (int64_t *)(h_esa + nsub);
 	uint64_t pairs = 0, nt = 0;
-	int any_reference = 0, any_foreign = 0;
+	int any_reference = 0;
 	// the index builds must have finished: their flags decide which walk is exact
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	for (size_t s = 0; s < nsub; ++s) {
@@ -651,7 +656,10 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			ctx->acc.reference_subjects++;
 			any_reference = 1;
 		}
-		if (e->index_built && e->h_flags[1]) any_foreign = 1;
+		if (e->index_built && e->h_flags[1]) {
+			ctx->err = "andi_hip_scan_rows: a subject holds a byte outside {A,C,G,T,!,;,#}";
+			return 1;
+		}
 		h_esa[s] = esa_view(e, mode);
 		h_self[s] = self ? self[s] : -1;
 		bool has_self = h_self[s] >= 0 && (size_t)h_self[s] < q->nq;
@@ -693,9 +701,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.fixups = ctx->d_fixups;
 	a.any_reference = any_reference;
 	a.group = andi_scan_group();
-	// the packed scan needs every byte inside the alphabet (the staging kernels check)
-	a.lanes = a.group == 0 && !*q->h_foreign && !any_foreign;
-	if (!a.lanes && a.group == 0) a.group = 4;
+	a.lanes = a.group == 0;
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 
 	{

@@ -494,7 +494,7 @@ hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N
 static int lane_occupancy() { // waves per SIMD pass A is compiled for (experiments: ANDI_LANE_OCC)
 	const char *e = getenv("ANDI_LANE_OCC");
 	int v = e ? atoi(e) : 0;
-	return (v == 4 || v == 6 || v == 8) ? v : 8;
+	return (v == 4 || v == 6 || v == 8) ? v : 6; // 6: no spills, measured best
 }
 
 template <bool EXACT>

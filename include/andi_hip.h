@@ -29,7 +29,9 @@ extern "C" {
 enum { ANDI_M_RAW = 0, ANDI_M_JC = 1, ANDI_M_KIMURA = 2, ANDI_M_LOGDET = 3, ANDI_M_ANI = 4 };
 
 /* seq_t (src/sequence.h:18-25) without the name: NUL-terminated, over
- * {A,C,G,T,!} as produced by normalize() (src/sequence.c:260-282). */
+ * {A,C,G,T,!} as produced by normalize() (src/sequence.c:260-282).  Any other
+ * byte is refused by the scan (andi_hip_scan_rows / andi_hip_dist_matrix return an
+ * error): the device index codes a symbol in 2 or 4 bits. */
 typedef struct {
 	const char *seq;
 	size_t len;

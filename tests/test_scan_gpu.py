@@ -251,3 +251,40 @@ def test_full_size_properties(ctx, orc):
     # and equal to the sequential oracle
     want = orc.dist_matrix([a, b], threads=2)
     assert (got == want).all()
+
+
+@pytest.mark.parametrize("group", ["0", "2", "4", "8"])
+def test_every_scan_implementation_agrees(ctx, orc, monkeypatch, group):
+    """ANDI_SCAN_G selects passes A/B: 0 = one lane per chain on packed symbols
+    (scan_lane.hip, the default), 2/4/8 = lane groups on bytes (scan.hip)."""
+    from andi_amd import synth
+    monkeypatch.setenv("ANDI_SCAN_G", group)
+    rng = np.random.default_rng(5)
+    a, b = synth.pair(80000, 0.04, seed=3)
+    c = synth.to_bytes(synth.mutate_codes(synth.base_codes(80000, 3), 0.003, 11))
+    joined = a[:30000] + b"!" + rand_dna(rng, 500) + b"!" + b[30000:60000]  # contigs, src/sequence.c:260-282
+    _check_set(ctx, orc, [a, b, c, joined], segments=(0, 777))
+    for model in (3, 4):  # LogDet, ANI: per-nucleotide anchor counts
+        _check_set(ctx, orc, [a, b, joined], model=model)
+
+
+def test_bytes_outside_the_alphabet_are_refused(ctx):
+    """The engine's contract is the alphabet the reference's reader produces
+    (src/sequence.c:260-282: A C G T and '!'); anything else fails loudly instead of
+    being silently treated as a nucleotide."""
+    import andi_amd
+    from andi_amd import synth
+    a, b = synth.pair(50000, 0.02, seed=8)
+    a2 = bytearray(a)
+    a2[7000] = ord("N")
+    Qbad = andi_amd.Queries(ctx, [bytes(a2), b])
+    Q = andi_amd.Queries(ctx, [a, b])
+    Ebad = andi_amd.Esa(ctx, bytes(a2))  # subject text with a foreign byte: noticed by the index build
+    E = andi_amd.Esa(ctx, a)
+    with pytest.raises(andi_amd.AndiHipError, match="outside"):
+        andi_amd.scan_rows(ctx, [E], [-1], Qbad, 1, 0)
+    with pytest.raises(andi_amd.AndiHipError, match="outside"):
+        andi_amd.scan_rows(ctx, [Ebad], [-1], Q, 1, 0)
+    assert andi_amd.scan_rows(ctx, [E], [0], Q, 1, 0).shape == (1, 2, 17)
+    for x in (E, Ebad, Q, Qbad):
+        x.close()
