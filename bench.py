@@ -9,10 +9,10 @@ against the 8 TB/s roofline.
 Workload at --gpus 1: BASELINE.json configs[1] as synthetic data ("C2-synth",
 SURVEY.md §8d): 29 genomes of 4.9 Mbp, each diverged from a common base by
 d_k ~ U[0.0004, 0.03], JC model.  One step = one pass of the device path over
-the whole set: per subject the device index build (the scan index: K-mer probe
-table, from the resident RS + suffix array), then the anchor scan of every query
-against every subject (passes A/B/C of scan.hip), then (N > 1) the RCCL gather of
-the row blocks.  Suffix arrays are built on the host and uploaded before the
+the whole set: per subject the device index build (the scan index: packed text and
+K-mer probe table, from the resident RS + suffix array), then the anchor scan of
+every query against every subject (passes A/B of scan_lane.hip, pass C of
+scan.hip), then (N > 1) the RCCL gather of the row blocks.  Suffix arrays are built on the host and uploaded before the
 timed region (north_star: "SA ... on host"); their cost is reported under
 "end_to_end", never in "value".
 
@@ -169,6 +169,22 @@ def main():
         except Exception:
             traffic = None
 
+    # measured device-copy ceiling beside the nominal peak: 1 GiB D2D, read + write bytes
+    copy_gbps = None
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.int32, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
+    scan_kernel = "k_lane_cold" if os.environ.get("ANDI_SCAN_G", "0") == "0" else "k_scan_cold"
     out = None
     if rank == 0:
         full = gathered[0] if use_dist else shard.gather_matrix(block, G)
@@ -183,8 +199,9 @@ def main():
                                    % (G, args.length, args.dlo, args.dhi, args.seed, world),
                        "genomes": G, "length": args.length, "model": "JC", "pairs": pairs_total,
                        "segment": args.segment or "auto (4096 for this set)"},
-            "roofline": {"bound": "hbm", "kernel": "k_scan_cold", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "measured_copy_GBps": copy_gbps,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_ms,
                          "launches": int(tm["scan_launches"])},
             "breakdown_ms_per_step": {"index_build": tm["build_ms"] / args.steps,
