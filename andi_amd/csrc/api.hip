@@ -65,7 +65,7 @@ struct andi_hip_esa {
 	uint8_t *Nraw = nullptr;              // 4-bit symbols for the lane scan: N0 and N1 with their padding
 	uint8_t *N0 = nullptr, *N1 = nullptr;
 	int32_t *flags = nullptr;   // device, 4 ints
-	int32_t *h_flags = nullptr; // pinned host copy, refreshed after every index build
+	int32_t *h_flags = nullptr; // the same 4 ints as the host sees them (flags live in pinned host memory)
 	int32_t deepK = 0;
 	int32_t n = 0;
 	int32_t thr = 0;
@@ -305,7 +305,6 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	chk(dmalloc(&e->SA, cap));
 	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
 	chk(dmalloc(&e->rec, cap));
-	chk(dmalloc(&e->flags, 4));
 	// symbols: [16 B front][N0: cap/2 + 1 + back][N1: same], each part 16-byte aligned
 	const size_t nib_part = (cap / 2 + 1 + ANDI_NIB_BACK + 15) & ~(size_t)15;
 	chk(dmalloc(&e->Nraw, 2 * (16 + nib_part)));
@@ -313,7 +312,10 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 		e->N0 = e->Nraw + 16, e->N1 = e->Nraw + 16 + nib_part + 16;
 		chk(hipMemsetAsync(e->Nraw, 0x77, 2 * (16 + nib_part), ctx->stream));
 	}
-	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocDefault));
+	// flags: pinned host memory the kernels write directly (rare, idempotent plain stores) --
+	// no per-build memset or copy; the host reads them after a stream synchronisation
+	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocMapped));
+	if (err == hipSuccess) chk(hipHostGetDevicePointer((void **)&e->flags, e->h_flags, 0));
 	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 4 * cap + 80 +
 			   2 * (16 + nib_part);
 	if (err != hipSuccess) {
@@ -336,7 +338,9 @@ static int esa_upload(andi_hip_ctx *ctx, andi_hip_esa *e, const char *RS, const 
 	e->thr = (int32_t)threshold;
 	e->deepK = pick_deep_k(n);
 	e->ref_built = e->index_built = false;
-	hipError_t err = hipMemsetAsync(e->flags, 0, 4 * sizeof(int32_t), ctx->stream);
+	// the flags are functions of the text and its suffix array: cleared here, only ever set by the builds
+	hipError_t err = hipStreamSynchronize(ctx->stream);
+	memset(e->h_flags, 0, 4 * sizeof(int32_t));
 	if (err == hipSuccess) err = hipMemsetAsync(e->S + n, 0, 1 + ANDI_PAD, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(e->S, RS, n, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess)
@@ -407,8 +411,6 @@ int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	Timed t(ctx, 0);
 	hipError_t err = andi_launch_index_build(build_args(e), ctx->stream);
 	t.stop();
-	if (err == hipSuccess)
-		err = hipMemcpyAsync(e->h_flags, e->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index", err);
 	e->index_built = true;
 	return 0;
@@ -417,7 +419,7 @@ int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
 int andi_hip_esa_flags(andi_hip_ctx *ctx, const andi_hip_esa *e, int32_t *out4) {
 	if (!ctx || !e || !out4) return 1;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	HIP_TRY(ctx, hipMemcpy(out4, e->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+	memcpy(out4, e->h_flags, 4 * sizeof(int32_t));
 	return 0;
 }
 
@@ -453,7 +455,6 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	(void)hipFree(e->deep);
 	(void)hipFree(e->rec);
 	(void)hipFree(e->Nraw);
-	(void)hipFree(e->flags);
 	(void)hipFree(e->min_scratch);
 	if (e->h_flags) (void)hipHostFree(e->h_flags);
 	delete e;

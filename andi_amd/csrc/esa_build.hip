@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 				decided = true;
 				// such an entry makes get_match_cached differ from the true
 				// longest match
-				atomicOr(&flags[2], 1);
+				flags[2] = 1; // (pinned host memory: plain idempotent store)
 				break;
 			}
 			if (e != sym(k)) {
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint32_t *__rest
 					uint32_t X = rec[j + 1];
 					if (REC_V(X) == k && REC_SEP(X) == sp && rec_lcp(R, X, K) == k) ++j; else break;
 				}
-				if (j > r && (j + 1 == n || rec_lcp(R, rec[j + 1], K) < k)) atomicOr(&flags[0], 1);
+				if (j > r && (j + 1 == n || rec_lcp(R, rec[j + 1], K) < k)) flags[0] = 1; // (pinned host memory: plain idempotent store)
 			}
 		}
 
@@ -482,8 +482,7 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
 	const int32_t n = a.n;
 	const int B = 256;
 	auto blocks = [&](int64_t items) { return (unsigned)((items + B - 1) / B); };
-	hipError_t e = hipMemsetAsync(a.flags, 0, 2 * sizeof(int32_t), st);
-	if (e != hipSuccess) return e;
+	hipError_t e;
 	// symbols for the lane scan: the text, its NUL and 64 bytes of the zero padding behind it
 	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 1, st);
 	if (e != hipSuccess) return e;
@@ -537,8 +536,6 @@ hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st) {
 	E.S = a.S, E.SA = a.SA, E.LCP = a.LCP, E.CLD = a.CLD, E.FVC = a.FVC, E.tab = a.tab;
 	E.flags = a.flags;
 	E.n = n, E.mode = ANDI_MODE_REFERENCE;
-	e = hipMemsetAsync(a.flags + 2, 0, sizeof(int32_t), st);
-	if (e != hipSuccess) return e;
 	k_kmer_table<<<blocks(1 << (2 * ANDI_CACHE_K)), B, 0, st>>>(E, a.tab, a.flags);
 	CHECK_LAUNCH();
 	return hipSuccess;
