@@ -27,10 +27,13 @@
 #define ANDI_MIN_SEGMENT 4096u
 #define ANDI_MAX_SEGMENT 65536u
 #define ANDI_TARGET_CHAINS (1u << 20)
+// per-pair segment lengths: classes seg/2, seg, 2 seg, 4 seg of the call's length; one block lays them out
+#define ANDI_ADAPTIVE_MAX_PAIRS 16384u
 
 static_assert(sizeof(andi_hip_model) == 68, "struct model must be 17 x u32 (src/model.h:52-57)");
 static_assert(sizeof(andi_hip_interval) == 16, "lcp_inter_t is 4 x int32 (src/esa.h:25-34)");
 static_assert(sizeof(ChainState) == 32, "ChainState is padded to 32 bytes");
+static_assert(sizeof(ColdMark) == 96, "ColdMark is a state and 16 counts");
 
 struct EventPair {
 	hipEvent_t a, b;
@@ -615,6 +618,11 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		return 1;
 	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	// segment == 0: the engine chooses.  With the lane scan and a moderate number of pairs
+	// the segment length is chosen per pair (scan_lane.hip: k_pair_estimate); otherwise one
+	// length for the call.
+	const bool want_adaptive = segment == 0 && andi_scan_group() == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
+							   !getenv("ANDI_UNIFORM_SEGMENTS");
 	if (segment == 0) {
 		uint64_t nt = q->total_nt * (uint64_t)nsub;
 		segment = ANDI_MIN_SEGMENT;
@@ -672,8 +680,27 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	HIP_TRY(ctx, hipEventRecord(ctx->desc_done, ctx->stream));
 
 	// scratch: per (subject, segment) two states and two count vectors
-	const size_t slots = nsub * (size_t)q->total_segs;
-	const size_t need = slots * (2 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t));
+	const bool adaptive = want_adaptive && !any_reference;
+	uint32_t seg0 = segment / 2; // classes: 1/2, 1, 2, 4 times the call's segment length
+	if (const char *e0 = getenv("ANDI_SEG0")) { // experiments: shortest segment of the adaptive classes
+		if (atoi(e0) >= 64) seg0 = (uint32_t)atoi(e0);
+	}
+	uint64_t max_waves = 0; // adaptive: wavefronts (64 segments of one pair) if every pair had the shortest segments
+	if (adaptive) {
+		for (size_t s = 0; s < nsub; ++s)
+			for (size_t i = 0; i < q->nq; ++i) {
+				if (h_self[s] == (int64_t)i) continue;
+				max_waves += ((q->len[i] + (uint64_t)seg0 - 1) / seg0 + 63) / 64;
+			}
+		if (max_waves >= (1u << 26)) {
+			ctx->err = "too many scan segments; raise opts.segment";
+			return 1;
+		}
+	}
+	const size_t pairs_all = nsub * q->nq;
+	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
+	const size_t need = slots * (2 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark)) +
+						(adaptive ? pairs_all * 9 + 64 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -698,6 +725,18 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.cold_counts = (uint32_t *)p;
 	p += slots * 16 * sizeof(uint32_t);
 	a.owned = (uint32_t *)p;
+	p += slots * 16 * sizeof(uint32_t);
+	a.marks = (ColdMark *)p;
+	p += slots * ANDI_COLD_MARKS * sizeof(ColdMark);
+	a.adaptive = adaptive ? 1 : 0;
+	a.seg0 = seg0, a.max_waves = (uint32_t)max_waves;
+	a.pair_waves = (uint32_t *)p;
+	a.pair_wave0 = a.pair_waves + pairs_all;
+	a.pair_class = (uint8_t *)(a.pair_wave0 + pairs_all + 1);
+	{
+		const char *f = getenv("ANDI_SEG_FACTOR");
+		a.seg_factor = f && atoi(f) > 0 ? (uint32_t)atoi(f) : 16u; // measured best of 8/16/32 with seg0 = 2048
+	}
 	a.M = M_dev;
 	a.fixups = ctx->d_fixups;
 	a.any_reference = any_reference;
@@ -705,6 +744,12 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.lanes = a.group == 0;
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 
+	if (a.adaptive) {
+		Timed t(ctx, 2);
+		hipError_t e = andi_launch_pair_layout(a, ctx->stream);
+		t.stop();
+		if (e != hipSuccess) return fail(ctx, "scan layout", e);
+	}
 	{
 		Timed t(ctx, 1);
 		hipError_t e = andi_launch_scan_cold(a, ctx->stream);

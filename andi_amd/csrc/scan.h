@@ -17,6 +17,16 @@ struct __attribute__((aligned(16))) ChainState {
 	uint32_t pad[3];
 };
 
+// What pass A of the lane scan remembers of a cold chain besides its exit: the state and
+// the counts right after its 2nd (.. ANDI_COLD_MARKS + 1 th) anchor.  The true chain
+// usually falls in step with the cold chain there; pass B then need not replay the cold
+// chain.  (1, 2 and 3 marks measured: the first one does nearly all of it.)
+#define ANDI_COLD_MARKS 1
+struct __attribute__((aligned(16))) ColdMark {
+	ChainState st; // st.pad[0] != 0: valid
+	uint32_t counts[16];
+};
+
 struct ScanArgs {
 	const EsaDev *subjects; // [nsub] device array
 	const int64_t *self;    // [nsub] query index of the subject itself or -1
@@ -35,6 +45,7 @@ struct ScanArgs {
 	// per (subject, segment) scratch
 	ChainState *cold_exit; // state when the cold chain leaves the segment
 	uint32_t *cold_counts; // [..][16] counts the cold chain added inside the segment
+	ColdMark *marks;       // [..][ANDI_COLD_MARKS] (lane scan only)
 	ChainState *true_exit; // state of the true chain when it leaves the segment
 	uint32_t *owned;       // [..][16] counts the true chain adds inside the segment
 	andi_hip_model *M;     // [nsub][nq]
@@ -42,6 +53,16 @@ struct ScanArgs {
 	int exact_equal;   // LogDet/ANI: count the nucleotides of every anchor (src/model.c:256-278)
 	int any_reference; // some subject is in ANDI_MODE_REFERENCE: launch the reference-walk kernels too
 	int lanes;         // probe-table subjects: one lane per chain on packed symbols (scan_lane.hip)
+	// Per-pair segment lengths (lane scan, all subjects on the probe table).  A pair is
+	// subject * nq + query; its segments are seg0 << pair_class long and occupy the slots
+	// 64 * pair_wave0[pair] ..., i.e. whole wavefronts; pair_wave0[nsub * nq] = wavefronts in use.
+	int adaptive;
+	uint32_t seg0;
+	uint32_t seg_factor; // a pair's segments are at least this many mean match lengths long
+	uint8_t *pair_class;
+	uint32_t *pair_waves; // scratch: wavefronts per pair
+	uint32_t *pair_wave0;
+	uint32_t max_waves;   // upper bound (every pair in class 0): the grid
 	int group;         // otherwise: lanes per chain of scan.hip's kernels (2, 4, 8)
 };
 
@@ -53,6 +74,8 @@ hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N
 // lanes per chain the scan runs with: 0 = one lane per chain on packed symbols
 // (scan_lane.hip, default), 1/2/4/8/16 = scan.hip's lane groups on bytes (ANDI_SCAN_G)
 int andi_scan_group(void);
+// adaptive mode: sample every pair's match lengths, choose its segment length, lay out the slots
+hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st);

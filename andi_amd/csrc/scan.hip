@@ -445,9 +445,16 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	uint32_t *histT = s_hist[threadIdx.x >> 6][1], *histC = s_hist[threadIdx.x >> 6][2];
 	if (lane < 16) total[lane] = 0;
 
-	const uint32_t base = a.qseg_start[qidx];
-	const uint32_t nseg = a.qseg_start[qidx + 1] - base;
-	const size_t row = (size_t)sub * a.total_segs + base;
+	uint32_t nseg, seg;
+	size_t row;
+	if (a.adaptive) {
+		const PairGeom g = pair_geometry(a, sub, qidx);
+		nseg = g.nseg, seg = g.seg, row = g.slot0;
+	} else {
+		const uint32_t base = a.qseg_start[qidx];
+		nseg = a.qseg_start[qidx + 1] - base, seg = a.seg;
+		row = (size_t)sub * a.total_segs + base;
+	}
 	PairCtx c = make_ctx(a, sub, qidx);
 
 	// every segment k >= 1 was stitched assuming it is entered in cold_exit[k-1]
@@ -470,8 +477,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 				st = a.true_exit[row + k];
 			} else {
 				if (lane == 0) atomicAdd(a.fixups, 1ull);
-				uint32_t start = k * a.seg;
-				uint32_t e = start + a.seg;
+				uint32_t start = k * seg;
+				uint32_t e = start + seg;
 				uint32_t end = e < c.qlen ? e : c.qlen;
 				// rare; the general variant (runtime mode, per-nucleotide counting if asked for)
 				if (c.E.mode == ANDI_MODE_REFERENCE) {

@@ -111,6 +111,21 @@ __device__ __forceinline__ PairCtx make_ctx(const ScanArgs &a, uint32_t sub, uin
 	return c;
 }
 
+// adaptive mode: first slot, segment length and segment count of a pair
+struct PairGeom {
+	size_t slot0;
+	uint32_t seg, nseg;
+};
+
+__device__ __forceinline__ PairGeom pair_geometry(const ScanArgs &a, uint32_t sub, uint32_t qidx) {
+	const uint32_t pair = sub * a.nq + qidx;
+	PairGeom g;
+	g.slot0 = (size_t)64 * a.pair_wave0[pair];
+	g.seg = a.seg0 << a.pair_class[pair];
+	g.nseg = (a.qlen[qidx] + g.seg - 1) / g.seg;
+	return g;
+}
+
 // work item of this lane's group: segment w of subject blockIdx.y
 template <int G>
 __device__ __forceinline__ WorkItem decode_item(const ScanArgs &a) {

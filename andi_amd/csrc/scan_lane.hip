@@ -240,9 +240,10 @@ __device__ __forceinline__ void lane_count_anchor(const PairCtx &c, Tally &t, ui
 }
 
 // anchor() (src/process.c:113-123) through the probe table, as scan.hip's probe_step
-__device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &w) {
+// (`cap`: the caller does not care about match lengths beyond it)
+__device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &w, uint32_t cap = ~0u) {
 	const EsaG &E = c.E;
-	const uint32_t qrem = c.qlen - p, K = (uint32_t)E.deepK;
+	const uint32_t qrem = c.qlen - p < cap ? c.qlen - p : cap, K = (uint32_t)E.deepK;
 	g_u8p q = c.Q + p;
 	STAT(ST_PROBE);
 	if (qrem <= K) return sa_range_match<1>(E, q, qrem, 0, E.n - 1, 0);
@@ -314,10 +315,11 @@ __device__ __forceinline__ void lane_account(const PairCtx &c, ChainState &st, T
 
 // One trip of the while loop, src/process.c:153-197.
 template <bool EXACT>
-__device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st, Tally &tally, LWin &w) {
+__device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st, Tally &tally, LWin &w, bool &found) {
 	const uint32_t n = (uint32_t)c.E.n;
 	uint32_t curS = 0, curLen = 0;
-	bool found = false, accounted = false;
+	bool accounted = false;
+	found = false;
 	STAT(ST_STEP);
 
 	// lucky_anchor, src/process.c:82-100
@@ -360,6 +362,103 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 	return st;
 }
 
+// ------------------------------------------------------------------ work items
+// One lane = one segment.  Uniform mode: segment w of subject blockIdx.y (decode_item).
+// Adaptive mode: wavefront W of the launch belongs to the pair whose slots contain
+// 64 * W; all its lanes work on that pair.
+struct LaneItem {
+	uint32_t sub, qidx, seg_in_q, start, end;
+	size_t slot;
+	bool valid;
+};
+
+__device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
+	LaneItem it;
+	if (!a.adaptive) {
+		const WorkItem w = decode_item<1>(a);
+		it.sub = w.sub, it.qidx = w.qidx, it.seg_in_q = w.seg_in_q, it.start = w.start, it.end = w.end;
+		it.slot = (size_t)w.sub * a.total_segs + w.w;
+		it.valid = w.valid && !w.is_self;
+		return it;
+	}
+	const uint32_t P = a.nsub * a.nq;
+	const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)));
+	it.valid = false;
+	it.sub = it.qidx = it.seg_in_q = it.start = it.end = 0, it.slot = 0;
+	if (W >= a.pair_wave0[P]) return it;
+	uint32_t lo = 0, hi = P; // the last pair whose first wavefront is <= W (pairs without work share their successor's)
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (a.pair_wave0[mid] <= W) lo = mid; else hi = mid;
+	}
+	const uint32_t pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+	it.sub = pair / a.nq, it.qidx = pair % a.nq;
+	const uint32_t seg = a.seg0 << a.pair_class[pair], qlen = a.qlen[it.qidx];
+	it.seg_in_q = (W - a.pair_wave0[pair]) * 64 + (threadIdx.x & 63u);
+	it.start = it.seg_in_q * seg;
+	it.valid = it.start < qlen;
+	it.end = it.start + seg < qlen ? it.start + seg : qlen;
+	it.slot = (size_t)64 * W + (threadIdx.x & 63u);
+	return it;
+}
+
+// Adaptive mode, step 1: one wavefront per pair samples the longest match at 64 evenly
+// spaced query positions.  Their mean estimates the distance between mismatches, i.e.
+// how long the true and the cold chain of a segment take to meet; the pair's segments
+// are made seg_factor times that (as a power-of-two multiple of seg0, at most 8 seg0).
+// Short segments keep the lanes of a wavefront close together in memory and the work
+// items small; long ones keep the stitching of low-divergence pairs cheap.
+__global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
+	const uint32_t P = a.nsub * a.nq;
+	const uint32_t pair = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+	if (pair >= P) return;
+	const uint32_t sub = pair / a.nq, qidx = pair % a.nq, lane = threadIdx.x & 63u;
+	if (a.self[sub] == (int64_t)qidx) {
+		if (lane == 0) a.pair_class[pair] = 0, a.pair_waves[pair] = 0;
+		return;
+	}
+	PairCtx c = make_ctx(a, sub, qidx);
+	const uint32_t p = (uint32_t)(((uint64_t)(2 * lane + 1) * c.qlen) >> 7);
+	LWin w;
+	w.q0 = EMPTY, w.dg = NO_DIAG;
+	const uint32_t cap = 16 * a.seg0 / (a.seg_factor ? a.seg_factor : 1) + 64; // beyond: the longest class anyway
+	const Probe r = lane_probe(c, p, w, cap);
+	uint32_t sum = r.len < cap ? r.len : cap;
+#pragma unroll
+	for (int d = 32; d; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d);
+	if (lane == 0) {
+		const uint32_t want = (sum >> 6) * a.seg_factor; // mean match length * factor
+		uint32_t cls = 0;
+		while (cls < 3 && (a.seg0 << cls) < want) ++cls;
+		const uint32_t seg = a.seg0 << cls, nseg = (c.qlen + seg - 1) / seg;
+		a.pair_class[pair] = (uint8_t)cls;
+		a.pair_waves[pair] = (nseg + 63) / 64;
+	}
+}
+
+// step 2: exclusive prefix sums of the pairs' wavefront counts (one block)
+__global__ __launch_bounds__(1024) void k_pair_offsets(ScanArgs a) {
+	__shared__ uint32_t s_part[1024];
+	const uint32_t P = a.nsub * a.nq, per = (P + 1023) / 1024;
+	const uint32_t first = threadIdx.x * per, last = first + per < P ? first + per : P;
+	uint32_t sum = 0;
+	for (uint32_t i = first; i < last; ++i) sum += a.pair_waves[i];
+	s_part[threadIdx.x] = sum;
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele, inclusive
+		uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+		__syncthreads();
+		s_part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint32_t run = s_part[threadIdx.x] - sum;
+	for (uint32_t i = first; i < last; ++i) {
+		a.pair_wave0[i] = run;
+		run += a.pair_waves[i];
+	}
+	if (threadIdx.x == 1023) a.pair_wave0[P] = s_part[1023];
+}
+
 // ------------------------------------------------------------------ pass A
 // The lanes of a wavefront take consecutive segments of one query, so they see the
 // same divergence and stay in step.  (Persistent lanes that fetch their next segment
@@ -368,9 +467,9 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 template <bool EXACT, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 	__shared__ uint32_t s_hist[16 * BLOCK];
-	if (a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
-	WorkItem it = decode_item<1>(a);
-	if (!it.valid || it.is_self) return;
+	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
+	const LaneItem it = lane_item(a);
+	if (!it.valid) return;
 	Tally tally;
 	tally_begin<1>(tally, s_hist + threadIdx.x);
 
@@ -378,9 +477,29 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, (uint32_t)c.E.n);
 	LWin w;
 	w.q0 = EMPTY, w.dg = NO_DIAG;
-	while (st.p < it.end) st = lane_step<EXACT>(c, st, tally, w);
+	const size_t slot = it.slot;
+	ColdMark *marks = a.marks + slot * ANDI_COLD_MARKS;
+	uint32_t anchors = 0;
+	while (st.p < it.end) {
+		bool found;
+		st = lane_step<EXACT>(c, st, tally, w, found);
+		if (found && ++anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
+			ColdMark *m = marks + (anchors - 2);
+			ChainState ms = st;
+			ms.pad[0] = 1;
+			m->st = ms;
+			uint32_t v[16];
+#pragma unroll
+			for (int t = 0; t < 16; ++t) v[t] = tally.hist[t * BLOCK];
+			v[0] += tally.quarter + tally.same[0], v[5] += tally.quarter + tally.same[1];
+			v[10] += tally.quarter + tally.same[2], v[15] += tally.quarter + tally.rest + tally.same[3];
+			uint4 *mc = (uint4 *)m->counts;
+#pragma unroll
+			for (int t = 0; t < 4; ++t) mc[t] = make_uint4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
+		}
+	}
+	for (uint32_t k = anchors < 2 ? 0 : anchors - 1; k < ANDI_COLD_MARKS; ++k) marks[k].st.pad[0] = 0; // unused marks
 
-	const size_t slot = (size_t)it.sub * a.total_segs + it.w;
 	a.cold_exit[slot] = st;
 	tally_finish<1>(tally);
 	uint32_t out[16];
@@ -397,10 +516,10 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 template <bool EXACT>
 __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 	__shared__ uint32_t s_hist[2][16 * BLOCK];
-	if (a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
-	WorkItem it = decode_item<1>(a);
-	if (!it.valid || it.is_self) return;
-	const size_t slot = (size_t)it.sub * a.total_segs + it.w;
+	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
+	const LaneItem it = lane_item(a);
+	if (!it.valid) return;
+	const size_t slot = it.slot;
 	const uint32_t *coldCounts = a.cold_counts + slot * 16;
 	uint32_t *owned = a.owned + slot * 16;
 
@@ -417,6 +536,38 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 	tally_begin<1>(tC, s_hist[1] + threadIdx.x);
 	LWin w; // shared by both chains: they run next to each other
 	w.q0 = EMPTY, w.dg = NO_DIAG;
+	bool found;
+
+	// Phase 1: only the true chain runs, until it is in a state the cold chain was in
+	// right after one of its first anchors (pass A's marks).
+	const ColdMark *marks = a.marks + slot * ANDI_COLD_MARKS;
+	ChainState M[ANDI_COLD_MARKS];
+	uint32_t lastMarkP = 0;
+	bool anyMark = false;
+#pragma unroll
+	for (int k = 0; k < ANDI_COLD_MARKS; ++k) {
+		M[k] = marks[k].st;
+		if (M[k].pad[0]) anyMark = true, lastMarkP = M[k].p;
+	}
+	int hit = -1;
+	if (anyMark) {
+		for (;;) {
+#pragma unroll
+			for (int k = 0; k < ANDI_COLD_MARKS; ++k)
+				if (hit < 0 && M[k].pad[0] && same_state(T, M[k])) hit = k;
+			if (hit >= 0 || T.p >= it.end || T.p > lastMarkP) break;
+			T = lane_step<EXACT>(c, T, tT, w, found);
+		}
+	}
+	if (hit >= 0) {
+		tally_finish<1>(tT);
+		const uint32_t *markCounts = marks[hit].counts;
+		for (int t = 0; t < 16; ++t) owned[t] = tT.hist[t * BLOCK] + coldCounts[t] - markCounts[t];
+		a.true_exit[slot] = a.cold_exit[slot];
+		return;
+	}
+
+	// Phase 2 (no mark was hit): both chains, the one that is behind steps, until they meet
 	bool synced = false;
 	for (;;) {
 		if (same_state(T, C)) {
@@ -426,7 +577,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 		if (T.p >= it.end) break;
 		const bool stepT = C.p >= it.end || T.p <= C.p; // one call site keeps the code small
 		Tally tx = stepT ? tT : tC;
-		ChainState nx = lane_step<EXACT>(c, stepT ? T : C, tx, w);
+		ChainState nx = lane_step<EXACT>(c, stepT ? T : C, tx, w, found);
 		if (stepT) {
 			T = nx, tT = tx;
 		} else {
@@ -507,8 +658,22 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	return hipGetLastError();
 }
 
+hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
+	const uint32_t P = a.nsub * a.nq;
+	k_pair_estimate<<<(P + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, BLOCK, 0, st>>>(a);
+	CHECK_LAUNCH();
+	k_pair_offsets<<<1, 1024, 0, st>>>(a);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+static dim3 lane_grid(const ScanArgs &a) {
+	if (a.adaptive) return dim3((a.max_waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 1);
+	return dim3((a.total_segs + BLOCK - 1) / BLOCK, a.nsub);
+}
+
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st) {
-	dim3 grid((a.total_segs + BLOCK - 1) / BLOCK, a.nsub);
+	dim3 grid = lane_grid(a);
 	hipError_t e = a.exact_equal ? lane_cold<true>(a, grid, st) : lane_cold<false>(a, grid, st);
 #ifdef ANDI_LANE_STATS
 	if (e == hipSuccess && getenv("ANDI_LANE_STATS")) {
@@ -527,7 +692,7 @@ hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st) {
 }
 
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st) {
-	dim3 grid((a.total_segs + BLOCK - 1) / BLOCK, a.nsub);
+	dim3 grid = lane_grid(a);
 	if (a.exact_equal)
 		k_lane_stitch<true><<<grid, BLOCK, 0, st>>>(a);
 	else

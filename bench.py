@@ -198,7 +198,7 @@ def main():
                                    "seed %d; rows block-partitioned over %d GPU(s)"
                                    % (G, args.length, args.dlo, args.dhi, args.seed, world),
                        "genomes": G, "length": args.length, "model": "JC", "pairs": pairs_total,
-                       "segment": args.segment or "auto (4096 for this set)"},
+                       "segment": args.segment or "auto (chosen per pair from its sampled match lengths: 2048 ... 16384 for this set)"},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "measured_copy_GBps": copy_gbps,
