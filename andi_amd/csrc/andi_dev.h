@@ -401,39 +401,15 @@ __device__ __forceinline__ Probe sa_range_match(const EsaG &E, g_u8p q, uint32_t
 	}
 }
 
-// The probe of one chain step.  ANDI_MODE_PROBE: the K-mer at q decides most
-// outcomes with one table access; results are those of the true longest match,
-// which is what get_match_cached computes unless flags[0] is set.
-// ANDI_MODE_REFERENCE: the reference's own walk.
+// The probe of one chain step in ANDI_MODE_REFERENCE: the reference's own walk
+// (get_match_cached, src/esa.c:636-656) reduced to what dist_anchor reads of it.
+// (ANDI_MODE_PROBE lives in scan.hip / scan_lane.hip: probe_step, lane_probe.)
 template <int G>
 __device__ __forceinline__ Probe esa_probe(const EsaG &E, g_u8p q, uint32_t qlen) {
 	Probe r;
-	if (E.mode == ANDI_MODE_REFERENCE) {
-		Ival m = esa_match_cached<G>(E, q, qlen);
-		r.len = m.l <= 0 ? 0u : (uint32_t)m.l;
-		r.unique = m.i == m.j;
-		r.pos = (uint32_t)E.SA[m.i];
-		return r;
-	}
-	const int K = E.deepK;
-	uint32_t code;
-	if (qlen > (uint32_t)K && kmer_code(q, K, code)) {
-		uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + code));
-		uint32_t x = (uint32_t)raw, y = (uint32_t)(raw >> 32);
-		uint32_t kind = y & 3u;
-		if (kind == DEEP_FINAL) {
-			r.len = y >> 8, r.unique = (y >> 2) & 1u;
-			r.pos = (r.unique && r.len >= (uint32_t)E.thr) ? (uint32_t)E.SA[x] : 0u;
-			return r;
-		}
-		if (kind == DEEP_SINGLE) {
-			r.pos = x, r.unique = true;
-			r.len = (uint32_t)K + common_prefix<G>(q + K, E.S + x + K, qlen - (uint32_t)K);
-			return r;
-		}
-		if (kind == DEEP_MULTI)
-			return sa_range_match<G>(E, q, qlen, (int32_t)x, (int32_t)(x + (y >> 8)), (uint32_t)K);
-	}
-	// short remainder, separator within the first K characters, or DEEP_SEARCH
-	return sa_range_match<G>(E, q, qlen, 0, E.n - 1, 0);
+	Ival m = esa_match_cached<G>(E, q, qlen);
+	r.len = m.l <= 0 ? 0u : (uint32_t)m.l;
+	r.unique = m.i == m.j;
+	r.pos = (uint32_t)E.SA[m.i];
+	return r;
 }

@@ -288,3 +288,22 @@ def test_bytes_outside_the_alphabet_are_refused(ctx):
     assert andi_amd.scan_rows(ctx, [E], [0], Q, 1, 0).shape == (1, 2, 17)
     for x in (E, Ebad, Q, Qbad):
         x.close()
+
+
+def test_segment_length_per_pair_changes_nothing(ctx, orc, monkeypatch):
+    """segment = 0 lets the engine choose a segment length per pair from sampled match
+    lengths (scan_lane.hip: k_pair_estimate); pairs of very different divergence in one
+    call, every factor, and the uniform layout must all give the oracle's counts."""
+    from andi_amd import synth
+    base = synth.base_codes(120000, 21)
+    seqs = [synth.to_bytes(synth.mutate_codes(base, d, 30 + k)) for k, d in enumerate((0.0, 0.0005, 0.004, 0.03, 0.12))]
+    seqs.append(rand_dna(np.random.default_rng(2), 70000))  # unrelated, and a different length
+    want = orc.dist_matrix(seqs, threads=4)
+    for env in ({}, {"ANDI_SEG_FACTOR": "1"}, {"ANDI_SEG_FACTOR": "200"}, {"ANDI_SEG0": "128"},
+                {"ANDI_UNIFORM_SEGMENTS": "1"}):
+        for k in ("ANDI_SEG_FACTOR", "ANDI_SEG0", "ANDI_UNIFORM_SEGMENTS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, t = _gpu_rows(ctx, seqs)
+        assert (got == want).all(), env
