@@ -421,7 +421,9 @@ __global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
 	const uint32_t p = (uint32_t)(((uint64_t)(2 * lane + 1) * c.qlen) >> 7);
 	LWin w;
 	w.q0 = EMPTY, w.dg = NO_DIAG;
-	const uint32_t cap = 16 * a.seg0 / (a.seg_factor ? a.seg_factor : 1) + 64; // beyond: the longest class anyway
+	// a pair whose mean is seg0 * 8 / factor gets the longest segments anyway: samples are cut at twice
+	// that (a long match is followed 32 symbols per round trip, and the wavefront waits for its longest)
+	const uint32_t cap = 16 * a.seg0 / (a.seg_factor ? a.seg_factor : 1) / 2 + 32;
 	const Probe r = lane_probe(c, p, w, cap);
 	uint32_t sum = r.len < cap ? r.len : cap;
 #pragma unroll
