@@ -730,6 +730,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	p += slots * ANDI_COLD_MARKS * sizeof(ColdMark);
 	a.adaptive = adaptive ? 1 : 0;
 	a.seg0 = seg0, a.max_waves = (uint32_t)max_waves;
+	a.max_class = 0; // long segments must not leave the device short of chains
+	while (a.max_class < 3 && nt / ((uint64_t)seg0 << (a.max_class + 1)) >= (ANDI_TARGET_CHAINS >> 1)) a.max_class++;
 	a.pair_waves = (uint32_t *)p;
 	a.pair_wave0 = a.pair_waves + pairs_all;
 	a.pair_class = (uint8_t *)(a.pair_wave0 + pairs_all + 1);

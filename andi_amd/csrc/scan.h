@@ -59,6 +59,7 @@ struct ScanArgs {
 	int adaptive;
 	uint32_t seg0;
 	uint32_t seg_factor; // a pair's segments are at least this many mean match lengths long
+	uint32_t max_class;  // longest class in use (<= 3): kept small enough that the call still has ~2^19 chains
 	uint8_t *pair_class;
 	uint32_t *pair_waves; // scratch: wavefronts per pair
 	uint32_t *pair_wave0;
