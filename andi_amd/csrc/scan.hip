@@ -417,7 +417,8 @@ __global__ __launch_bounds__(BLOCK, 5) void k_scan_stitch(ScanArgs a) {
 	const uint32_t cell0 = G == 1 ? threadIdx.x : threadIdx.x / G * 16;
 	uint32_t *histT = s_hist[0] + cell0, *histC = s_hist[1] + cell0;
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
-	ChainState T = a.cold_exit[slot - 1]; // assumed entry; verified in pass C
+	// assumed entry; verified in pass C
+	ChainState T = a.cold_exit[slot - it.seg_in_q + entry_source(a, slot - it.seg_in_q, it.seg_in_q, a.seg, c.qlen)];
 	stitch_segment<G, MODE, EXACT>(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
 					  histC);
 	if (lane == 0) a.true_exit[slot] = T;
@@ -457,10 +458,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	}
 	PairCtx c = make_ctx(a, sub, qidx);
 
-	// every segment k >= 1 was stitched assuming it is entered in cold_exit[k-1]
+	// every segment k >= 1 was stitched assuming it is entered in the cold exit of entry_source(k)
 	bool ok = true;
 	for (uint32_t k = 1 + lane; k < nseg; k += 64)
-		ok = ok && same_state(a.true_exit[row + k - 1], a.cold_exit[row + k - 1]);
+		ok = ok && same_state(a.true_exit[row + k - 1], a.cold_exit[row + entry_source(a, row, k, seg, c.qlen)]);
 	ChainState fin;
 	if (__all(ok)) {
 		for (uint32_t k = lane; k < nseg; k += 64) {
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	} else {
 		ChainState st = initial_state();
 		for (uint32_t k = 0; k < nseg; ++k) {
-			ChainState assumed = k == 0 ? initial_state() : a.cold_exit[row + k - 1];
+			ChainState assumed = k == 0 ? initial_state() : a.cold_exit[row + entry_source(a, row, k, seg, c.qlen)];
 			if (same_state(st, assumed)) {
 				if (lane < 16) total[lane] += a.owned[(row + k) * 16 + lane];
 				st = a.true_exit[row + k];

@@ -111,6 +111,28 @@ __device__ __forceinline__ PairCtx make_ctx(const ScanArgs &a, uint32_t sub, uin
 	return c;
 }
 
+// The segment whose cold exit pass B takes as the state in which the true chain enters
+// segment k (k >= 1) of the pair whose segments start at slot `row`.  Normally k - 1.
+// But a chain that leaves a segment at a position beyond the end of the next segment(s)
+// -- a long anchor spans them -- never runs in those: segments that one of the
+// ANDI_SPAN_WINDOW segments before them jumps over are passed over.  (Cold chains that
+// start inside such an anchor end where it ends, so it does not matter whether the
+// jumping segment was itself visited.)  Pass C applies the same rule when it verifies.
+#define ANDI_SPAN_WINDOW 8
+__device__ __forceinline__ uint32_t entry_source(const ScanArgs &a, size_t row, uint32_t k, uint32_t seg,
+												 uint32_t qlen) {
+	uint32_t j = k - 1;
+	while (j >= 1) {
+		const uint32_t e = (j + 1) * seg, end_j = e < qlen ? e : qlen;
+		bool covered = false;
+		for (uint32_t back = 1; back <= ANDI_SPAN_WINDOW && back <= j && !covered; ++back)
+			covered = a.cold_exit[row + j - back].p >= end_j;
+		if (!covered) break;
+		--j;
+	}
+	return j;
+}
+
 // adaptive mode: first slot, segment length and segment count of a pair
 struct PairGeom {
 	size_t slot0;

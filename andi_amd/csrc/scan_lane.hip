@@ -383,7 +383,7 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 // Adaptive mode: wavefront W of the launch belongs to the pair whose slots contain
 // 64 * W; all its lanes work on that pair.
 struct LaneItem {
-	uint32_t sub, qidx, seg_in_q, start, end;
+	uint32_t sub, qidx, seg_in_q, start, end, seg;
 	size_t slot;
 	bool valid;
 };
@@ -393,6 +393,7 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 	if (!a.adaptive) {
 		const WorkItem w = decode_item<1>(a);
 		it.sub = w.sub, it.qidx = w.qidx, it.seg_in_q = w.seg_in_q, it.start = w.start, it.end = w.end;
+		it.seg = a.seg;
 		it.slot = (size_t)w.sub * a.total_segs + w.w;
 		it.valid = w.valid && !w.is_self;
 		return it;
@@ -400,7 +401,7 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 	const uint32_t P = a.nsub * a.nq;
 	const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)));
 	it.valid = false;
-	it.sub = it.qidx = it.seg_in_q = it.start = it.end = 0, it.slot = 0;
+	it.sub = it.qidx = it.seg_in_q = it.start = it.end = it.seg = 0, it.slot = 0;
 	if (W >= a.pair_wave0[P]) return it;
 	uint32_t lo = 0, hi = P; // the last pair whose first wavefront is <= W (pairs without work share their successor's)
 	while (hi - lo > 1) {
@@ -411,6 +412,7 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 	it.sub = pair / a.nq, it.qidx = pair % a.nq;
 	const uint32_t seg = a.seg0 << a.pair_class[pair], qlen = a.qlen[it.qidx];
 	it.seg_in_q = (W - a.pair_wave0[pair]) * 64 + (threadIdx.x & 63u);
+	it.seg = seg;
 	it.start = it.seg_in_q * seg;
 	it.valid = it.start < qlen;
 	it.end = it.start + seg < qlen ? it.start + seg : qlen;
@@ -547,7 +549,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 		return;
 	}
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
-	ChainState T = a.cold_exit[slot - 1]; // assumed entry; verified in pass C
+	// assumed entry; verified in pass C
+	ChainState T = a.cold_exit[slot - it.seg_in_q + entry_source(a, slot - it.seg_in_q, it.seg_in_q, it.seg, c.qlen)];
 	ChainState C = cold_state(it.start, (uint32_t)c.E.n);
 	Tally tT, tC;
 	tally_begin<1>(tT, s_hist[0] + threadIdx.x);
