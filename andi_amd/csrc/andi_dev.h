@@ -4,11 +4,10 @@
 // Layout in HBM per subject (all hipMalloc'ed, see api.hip):
 //   S    uint8[n+1+PAD]  RS, NUL at n, zero padding so wide loads never fault
 //   SA   int32[n]        suffix array (host-built, src/esa.c:294-304)
-// scan index (what the anchor scan uses; built by k_suffix_prefixes + k_probe_table):
+// scan index (what the anchor scan uses; built by k_pack_symbols + k_probe_table):
 //   deep uint2[4^K]      probe table: for every ACGT K-mer the outcome of the
 //                        longest-match search as far as the K-mer alone decides
 //                        it, so most probes cost one random access
-//   rec  uint32[n]       scratch: K-mer code + valid length of every suffix
 //   N0   uint8[n/2+..]   the text as 4-bit symbols (A C G T ! ; # NUL = 0..7), symbol i in
 //                        the low (i even) or high half of byte i/2; N1 the same shifted by
 //                        one symbol (byte b = symbols 2b-1, 2b), so that a 16-byte load can

@@ -64,7 +64,6 @@ struct andi_hip_esa {
 	int4 *tab = nullptr;
 	int32_t *min_scratch = nullptr;
 	uint2 *deep = nullptr;
-	uint32_t *rec = nullptr;
 	uint8_t *Nraw = nullptr;              // 4-bit symbols for the lane scan: N0 and N1 with their padding
 	uint8_t *N0 = nullptr, *N1 = nullptr;
 	int32_t *flags = nullptr;   // device, 4 ints
@@ -190,7 +189,7 @@ int pick_deep_k(size_t n) {
 EsaBuildArgs build_args(const andi_hip_esa *e) {
 	EsaBuildArgs a;
 	a.S = e->S, a.SA = e->SA, a.LCP = e->LCP, a.CLD = e->CLD, a.FVC = e->FVC, a.tab = e->tab;
-	a.deep = e->deep, a.rec = e->rec, a.flags = e->flags, a.deepK = e->deepK;
+	a.deep = e->deep, a.flags = e->flags, a.deepK = e->deepK;
 	a.N0 = e->N0, a.N1 = e->N1;
 	a.min_scratch = e->min_scratch;
 	a.n = e->n;
@@ -307,7 +306,6 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	chk(dmalloc(&e->S, cap + 1 + ANDI_PAD));
 	chk(dmalloc(&e->SA, cap));
 	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
-	chk(dmalloc(&e->rec, cap));
 	// symbols: [16 B front][N0: cap/2 + 1 + back][N1: same], each part 16-byte aligned
 	const size_t nib_part = (cap / 2 + 1 + ANDI_NIB_BACK + 15) & ~(size_t)15;
 	chk(dmalloc(&e->Nraw, 2 * (16 + nib_part)));
@@ -319,7 +317,7 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	// no per-build memset or copy; the host reads them after a stream synchronisation
 	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocMapped));
 	if (err == hipSuccess) chk(hipHostGetDevicePointer((void **)&e->flags, e->h_flags, 0));
-	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 4 * cap + 80 +
+	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 80 +
 			   2 * (16 + nib_part);
 	if (err != hipSuccess) {
 		andi_hip_esa_free(ctx, e);
@@ -456,7 +454,6 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	(void)hipFree(e->FVC);
 	(void)hipFree(e->tab);
 	(void)hipFree(e->deep);
-	(void)hipFree(e->rec);
 	(void)hipFree(e->Nraw);
 	(void)hipFree(e->min_scratch);
 	if (e->h_flags) (void)hipHostFree(e->h_flags);

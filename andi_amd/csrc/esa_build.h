@@ -20,7 +20,6 @@ struct EsaBuildArgs {
 	uint8_t *FVC;       // n       (out)
 	int4 *tab;          // 4^10    (out)
 	uint2 *deep;        // 4^deepK (out)
-	uint32_t *rec;      // n       (scratch)
 	uint8_t *N0, *N1;   // 4-bit symbols of the text, two alignments (out; see andi_dev.h)
 	int32_t *flags;     // 4 ints  (out)
 	int32_t deepK;

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 // bottom-up from the suffix array in two streaming passes; the only random
 // accesses are one 8-byte read of the packed text per suffix.
 //
-// rec[r] describes suffix SA[r]: bits 31..6 the 2-bit code of its first K
+// A suffix's record (made on the fly by suffix_rec, kept in LDS per block) describes suffix SA[r]: bits 31..6 the 2-bit code of its first K
 // characters (first character most significant, garbage past the valid part),
 // bits 5..4 what follows the valid part (0 ACGT/none, 1 '!', 2 ';', 3 other),
 // bits 3..0 v = number of leading ACGT characters, capped at K.
@@ -270,15 +270,12 @@ __global__ __launch_bounds__(256) void k_kmer_table(EsaDev Ed, int4 *__restrict_
 #define REC_SEP(x) (((x) >> 4) & 3u)
 #define REC_CODE(x) ((x) >> 6)
 
-// One thread per suffix: one 8-byte read of the text's 4-bit symbols (N0, see
-// andi_dev.h) at the suffix's position -- the only random access of the build --
-// holds its first 15 symbols: K-mer code, number of leading nucleotides and the
-// separator behind them all come from that word.
-__global__ __launch_bounds__(256) void k_suffix_prefixes(const uint8_t *__restrict__ N0,
-														 const int32_t *__restrict__ SA,
-														 uint32_t *__restrict__ rec, int32_t n, int K) {
-	int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= n) return;
+// rec of suffix r: one 8-byte read of the text's 4-bit symbols (N0, see andi_dev.h) at the
+// suffix's position -- the only random access of the build -- holds its first 15 symbols:
+// K-mer code, number of leading nucleotides and the separator behind them all come from
+// that word.
+__device__ __forceinline__ uint32_t suffix_rec(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
+											   int32_t r, int K) {
 	const uint32_t p = (uint32_t)SA[r];
 	const uint64_t w = ld_u64_unaligned((g_u8p)N0 + (p >> 1)) >> (4 * (p & 1u)); // symbol i at bits 4i..4i+3
 	const uint64_t stop = (w & 0x4444444444444444ull) | (1ull << 62); // not a nucleotide (bit 2); symbol 15 is outside
@@ -299,7 +296,7 @@ __global__ __launch_bounds__(256) void k_suffix_prefixes(const uint8_t *__restri
 	};
 	uint32_t y = __brev(squeeze((uint32_t)w) | (squeeze((uint32_t)(w >> 32)) << 16));
 	y = ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u); // first symbol in the top two bits
-	rec[r] = ((y >> (32 - 2 * K)) << 6) | (sep << 4) | v;
+	return ((y >> (32 - 2 * K)) << 6) | (sep << 4) | v;
 }
 
 // leading characters two suffixes share, counting ACGT only, capped at K
@@ -336,7 +333,7 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 // no divergent per-gap loops); a binary search over the gaps' offsets tells an entry
 // which gap it belongs to.
 #define PT_BLOCK 256
-__global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint32_t *__restrict__ rec,
+__global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restrict__ N0,
 														  const int32_t *__restrict__ SA,
 														  uint2 *__restrict__ deep,
 														  int32_t *__restrict__ flags, int32_t n, int K) {
@@ -346,12 +343,23 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint32_t *__rest
 	__shared__ uint32_t s_L[PT_BLOCK], s_R[PT_BLOCK], s_hh[PT_BLOCK];
 	__shared__ uint2 s_present[PT_BLOCK];    // entry of the K-mer of suffix r, if the gap owns it
 	__shared__ uint32_t s_wave[PT_BLOCK / 64];
+	__shared__ uint32_t s_rec[PT_BLOCK + 3]; // rec of the suffixes r0 - 2 .. r0 + PT_BLOCK
 
-	const int64_t gid = (int64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+	const int64_t r0 = (int64_t)blockIdx.x * PT_BLOCK;
+	const int64_t gid = r0 + threadIdx.x;
+	// the suffixes' records are made here (they used to be a kernel and an array of their own)
+	s_rec[threadIdx.x + 2] = gid < n ? suffix_rec(N0, SA, (int32_t)gid, K) : 0u;
+	if (threadIdx.x < 2) s_rec[threadIdx.x] = r0 + threadIdx.x >= 2 ? suffix_rec(N0, SA, (int32_t)(r0 + threadIdx.x - 2), K) : 0u;
+	if (threadIdx.x == 2) s_rec[PT_BLOCK + 2] = r0 + PT_BLOCK < n ? suffix_rec(N0, SA, (int32_t)(r0 + PT_BLOCK), K) : 0u;
+	__syncthreads();
+	auto rec = [&](int32_t j) { // 0 <= j < n; inside the block's range from LDS
+		const int64_t k = (int64_t)j - r0 + 2;
+		return (k >= 0 && k < PT_BLOCK + 3) ? s_rec[k] : suffix_rec(N0, SA, j, K);
+	};
 	const bool live = gid <= n;
 	const int32_t r = (int32_t)(live ? gid : 0);
 	const bool hasL = live && r > 0, hasR = live && r < n;
-	const uint32_t L = hasL ? rec[r - 1] : 0u, R = hasR ? rec[r] : 0u;
+	const uint32_t L = hasL ? s_rec[threadIdx.x + 1] : 0u, R = hasR ? s_rec[threadIdx.x + 2] : 0u;
 	const uint32_t full = (uint32_t)K;
 	const uint32_t h = (hasL && hasR) ? rec_lcp(L, R, K) : 0u;
 	uint32_t absent = 0, first = 0, owns_present = 0;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint32_t *__rest
 		// (a) present K-mers
 		if (hasR && REC_V(R) == full && !(hasL && REC_V(L) == full && REC_CODE(L) == REC_CODE(R))) {
 			int32_t j = r;
-			while (j + 1 < n && rec[j + 1] == R) ++j;
+			while (j + 1 < n && rec(j + 1) == R) ++j;
 			if (j == r) {
 				present = make_uint2((uint32_t)SA[r], DEEP_SINGLE | (1u << 2) | (full << 8));
 			} else if ((uint32_t)(j - r) < (1u << 24)) {
@@ -379,10 +387,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint32_t *__rest
 			if (k >= 1 && k <= 8 && k < full && (sp == 1 || sp == 2) && (!hasL || h < k)) {
 				int32_t j = r;
 				while (j + 1 < n) {
-					uint32_t X = rec[j + 1];
+					uint32_t X = rec(j + 1);
 					if (REC_V(X) == k && REC_SEP(X) == sp && rec_lcp(R, X, K) == k) ++j; else break;
 				}
-				if (j > r && (j + 1 == n || rec_lcp(R, rec[j + 1], K) < k)) flags[0] = 1; // (pinned host memory: plain idempotent store)
+				if (j > r && (j + 1 == n || rec_lcp(R, rec(j + 1), K) < k)) flags[0] = 1; // (pinned host memory: plain idempotent store)
 			}
 		}
 
@@ -410,8 +418,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint32_t *__rest
 		}
 	}
 	// is the left (right) neighbour the only suffix sharing a given prefix length with it?
-	const uint32_t hLL = (live && r >= 2) ? rec_lcp(rec[r - 2], L, K) : 0u;      // lcp(suffix r-2, suffix r-1)
-	const uint32_t hRR = (live && r + 1 < n) ? rec_lcp(R, rec[r + 1], K) : 0u; // lcp(suffix r, suffix r+1)
+	const uint32_t hLL = (live && r >= 2) ? rec_lcp(s_rec[threadIdx.x], L, K) : 0u;          // lcp(suffix r-2, suffix r-1)
+	const uint32_t hRR = (live && r + 1 < n) ? rec_lcp(R, s_rec[threadIdx.x + 3], K) : 0u; // lcp(suffix r, suffix r+1)
 
 	// block-wide exclusive scan of the entry counts
 	const uint32_t mine = absent + owns_present, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -434,7 +442,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint32_t *__rest
 	if (threadIdx.x == 0) s_off[PT_BLOCK] = total;
 	__syncthreads();
 
-	const int64_t r0 = (int64_t)blockIdx.x * PT_BLOCK;
 	for (uint32_t t = threadIdx.x; t < total; t += PT_BLOCK) {
 		// the gap that owns entry t: the last one whose offset is <= t
 		uint32_t a = 0, b = PT_BLOCK; // invariant: s_off[a] <= t < s_off[b]
@@ -480,15 +487,11 @@ size_t andi_min_tree_entries(int32_t n) {
 
 hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
 	const int32_t n = a.n;
-	const int B = 256;
-	auto blocks = [&](int64_t items) { return (unsigned)((items + B - 1) / B); };
 	hipError_t e;
 	// symbols for the lane scan: the text, its NUL and 64 bytes of the zero padding behind it
 	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 1, st);
 	if (e != hipSuccess) return e;
-	k_suffix_prefixes<<<blocks(n), B, 0, st>>>(a.N0, a.SA, a.rec, n, a.deepK);
-	CHECK_LAUNCH();
-	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_BLOCK - 1) / PT_BLOCK), PT_BLOCK, 0, st>>>(a.rec, a.SA, a.deep, a.flags, n,
+	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_BLOCK - 1) / PT_BLOCK), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.deep, a.flags, n,
 																				  a.deepK);
 	CHECK_LAUNCH();
 	return hipSuccess;
