@@ -33,7 +33,7 @@
 static_assert(sizeof(andi_hip_model) == 68, "struct model must be 17 x u32 (src/model.h:52-57)");
 static_assert(sizeof(andi_hip_interval) == 16, "lcp_inter_t is 4 x int32 (src/esa.h:25-34)");
 static_assert(sizeof(ChainState) == 32, "ChainState is padded to 32 bytes");
-static_assert(sizeof(ColdMark) == 96, "ColdMark is a state and 16 counts");
+static_assert(sizeof(ColdMark) == 112, "ColdMark is a state, 16 counts and the first anchor");
 
 struct EventPair {
 	hipEvent_t a, b;

@@ -25,6 +25,7 @@ struct __attribute__((aligned(16))) ChainState {
 struct __attribute__((aligned(16))) ColdMark {
 	ChainState st; // st.pad[0] != 0: valid
 	uint32_t counts[16];
+	uint32_t first[4]; // the cold chain's 1st anchor: pos_Q, pos_S, length (mark 0 only)
 };
 
 struct ScanArgs {

@@ -503,7 +503,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 	while (st.p < it.end) {
 		bool found;
 		st = lane_step<EXACT>(c, st, tally, w, found);
-		if (found && ++anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
+		if (found && ++anchors == 1) *(uint4 *)marks[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
+		if (found && anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
 			ColdMark *m = marks + (anchors - 2);
 			ChainState ms = st;
 			ms.pad[0] = 1;
@@ -570,6 +571,32 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 		M[k] = marks[k].st;
 		if (M[k].pad[0]) anyMark = true, lastMarkP = M[k].p;
 	}
+	// Shortcut: the true chain enters right behind an anchor that ends where the cold chain's
+	// 1st anchor ends (the same match, found from further left -- the usual case when an
+	// anchor crosses the segment's start).  Both chains then take the same steps up to and
+	// including the cold chain's 2nd anchor, after which their states are equal; they differ
+	// only in what that step counts for the anchor before it (src/process.c:176-186), and
+	// for the models that split an anchor's length evenly that is known without replaying.
+	if constexpr (!EXACT) {
+		if (M[0].pad[0]) {
+			const uint4 f1 = *(const uint4 *)marks[0].first; // pos_Q, pos_S, length
+			if (T.p == f1.x + f1.z + 1 && T.lastQ + T.lastLen == f1.x + f1.z && T.lastS + T.lastLen == f1.y + f1.z &&
+				T.p < it.end) {
+				const bool right = M[0].lwra != 0; // the 2nd anchor was a right anchor (same test for both chains)
+				const uint32_t lenC = (right || f1.z >= 2 * c.thr) ? f1.z : 0u;
+				const uint32_t lenT = (right || T.lwra || T.lastLen >= 2 * c.thr) ? T.lastLen : 0u;
+				const uint32_t dq = (lenT >> 2) - (lenC >> 2), dr = (lenT & 3u) - (lenC & 3u); // model_count_equal's split
+				for (int t = 0; t < 16; ++t) {
+					uint32_t v = coldCounts[t];
+					if (t == 0 || t == 5 || t == 10) v += dq;
+					if (t == 15) v += dq + dr;
+					owned[t] = v;
+				}
+				a.true_exit[slot] = a.cold_exit[slot];
+				return;
+			}
+		}
+	}
 	int hit = -1;
 	if (anyMark) {
 		for (;;) {
@@ -589,6 +616,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 	}
 
 	// Phase 2 (no mark was hit): both chains, the one that is behind steps, until they meet
+	STAT(ST_SEARCH); // (diagnostic builds: segments that reach phase 2)
+	if (M[0].pad[0] && T.p >= M[0].p) { // the cold chain need not be replayed up to its mark
+		C = M[0];
+		for (int t = 0; t < 16; ++t) tC.hist[t * BLOCK] = marks[0].counts[t];
+	}
 	bool synced = false;
 	for (;;) {
 		if (same_state(T, C)) {
