@@ -4,7 +4,9 @@
 #pragma once
 #include "scan.h"
 
+#ifndef WAVES_PER_BLOCK
 #define WAVES_PER_BLOCK 4
+#endif
 #define BLOCK (64 * WAVES_PER_BLOCK)
 #define SCAN_G 4 /* lanes per chain in passes A and B (measured best of 4/8/16 on MI355X) */
 
