@@ -340,7 +340,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 	__shared__ uint32_t s_off[PT_BLOCK + 1]; // exclusive prefix sums of the gaps' entry counts
 	__shared__ uint32_t s_first[PT_BLOCK];   // first code a gap owns
 	__shared__ uint32_t s_absent[PT_BLOCK];  // number of absent codes it owns (they come first)
-	__shared__ uint32_t s_L[PT_BLOCK], s_R[PT_BLOCK], s_hh[PT_BLOCK];
+	__shared__ uint32_t s_h[PT_BLOCK + 2]; // s_h[k + 1]: characters the suffixes r0 + k - 1 and r0 + k share
 	__shared__ uint2 s_present[PT_BLOCK];    // entry of the K-mer of suffix r, if the gap owns it
 	__shared__ uint32_t s_wave[PT_BLOCK / 64];
 	__shared__ uint32_t s_rec[PT_BLOCK + 3]; // rec of the suffixes r0 - 2 .. r0 + PT_BLOCK
@@ -362,6 +362,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 	const uint32_t L = hasL ? s_rec[threadIdx.x + 1] : 0u, R = hasR ? s_rec[threadIdx.x + 2] : 0u;
 	const uint32_t full = (uint32_t)K;
 	const uint32_t h = (hasL && hasR) ? rec_lcp(L, R, K) : 0u;
+	s_h[threadIdx.x + 1] = h;
+	if (threadIdx.x == 0) s_h[0] = r0 >= 2 ? rec_lcp(s_rec[0], s_rec[1], K) : 0u;
+	if (threadIdx.x == 1) s_h[PT_BLOCK + 1] = r0 + PT_BLOCK < n ? rec_lcp(s_rec[PT_BLOCK + 1], s_rec[PT_BLOCK + 2], K) : 0u;
 	uint32_t absent = 0, first = 0, owns_present = 0;
 	uint2 present = make_uint2(0, 0);
 
@@ -395,31 +398,28 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 		}
 
 		// (b) absent K-mers inside this gap
-		int64_t lo, hi;
+		int32_t lo, hi; // codes are below 4^13: 32 bits do
 		if (!hasL) {
 			lo = 0;
 		} else if (REC_V(L) == full) {
-			lo = (int64_t)REC_CODE(L) + 1;
+			lo = (int32_t)REC_CODE(L) + 1;
 		} else { // w <sep> sorts before every K-mer that starts with w
 			uint32_t sh = 2 * (full - REC_V(L));
-			lo = (int64_t)((REC_CODE(L) >> sh) << sh);
+			lo = (int32_t)((REC_CODE(L) >> sh) << sh);
 		}
 		if (!hasR) {
-			hi = ((int64_t)1 << (2 * K)) - 1;
+			hi = (int32_t)((1u << (2 * K)) - 1u);
 		} else if (REC_V(R) == full) {
-			hi = (int64_t)REC_CODE(R) - 1;
+			hi = (int32_t)REC_CODE(R) - 1;
 		} else {
 			uint32_t sh = 2 * (full - REC_V(R));
-			hi = (int64_t)((REC_CODE(R) >> sh) << sh) - 1;
+			hi = (int32_t)((REC_CODE(R) >> sh) << sh) - 1;
 		}
 		if (lo <= hi) {
 			absent = (uint32_t)(hi - lo + 1);
 			first = (uint32_t)lo;
 		}
 	}
-	// is the left (right) neighbour the only suffix sharing a given prefix length with it?
-	const uint32_t hLL = (live && r >= 2) ? rec_lcp(s_rec[threadIdx.x], L, K) : 0u;          // lcp(suffix r-2, suffix r-1)
-	const uint32_t hRR = (live && r + 1 < n) ? rec_lcp(R, s_rec[threadIdx.x + 3], K) : 0u; // lcp(suffix r, suffix r+1)
 
 	// block-wide exclusive scan of the entry counts
 	const uint32_t mine = absent + owns_present, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -431,7 +431,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 	}
 	if (lane == 63) s_wave[wave] = incl;
 	s_first[threadIdx.x] = first, s_absent[threadIdx.x] = absent;
-	s_L[threadIdx.x] = L, s_R[threadIdx.x] = R, s_hh[threadIdx.x] = hLL | (hRR << 8);
 	s_present[threadIdx.x] = present;
 	__syncthreads();
 	uint32_t before = 0;
@@ -456,7 +455,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 		}
 		const int64_t rr = r0 + a;
 		const bool gL = rr > 0, gR = rr < n;
-		const uint32_t gl = s_L[a], gr = s_R[a], hll = s_hh[a] & 0xffu, hrr = s_hh[a] >> 8;
+		// is the left (right) neighbour the only suffix sharing a given prefix length with it?
+		// lcp(suffix rr-2, rr-1) and lcp(suffix rr, rr+1) are the neighbouring gaps' h (0 outside the text)
+		const uint32_t gl = s_rec[a + 1], gr = s_rec[a + 2], hll = s_h[a], hrr = s_h[a + 2];
 		uint32_t lL = gL ? rec_lcp_code(c, gl, K) : 0u;
 		uint32_t lR = gR ? rec_lcp_code(c, gr, K) : 0u;
 		uint32_t l, uniq, idx;
