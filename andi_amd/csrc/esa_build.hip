@@ -333,117 +333,141 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 // no divergent per-gap loops); a binary search over the gaps' offsets tells an entry
 // which gap it belongs to.
 #define PT_BLOCK 256
+#define PT_GAPS 2 /* gaps per thread: two independent gathers in flight per thread */
+#define PT_TILE (PT_BLOCK * PT_GAPS)
 __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restrict__ N0,
 														  const int32_t *__restrict__ SA,
 														  uint2 *__restrict__ deep,
 														  int32_t *__restrict__ flags, int32_t n, int K) {
-	__shared__ uint32_t s_off[PT_BLOCK + 1]; // exclusive prefix sums of the gaps' entry counts
-	__shared__ uint32_t s_first[PT_BLOCK];   // first code a gap owns
-	__shared__ uint32_t s_absent[PT_BLOCK];  // number of absent codes it owns (they come first)
-	__shared__ uint32_t s_h[PT_BLOCK + 2]; // s_h[k + 1]: characters the suffixes r0 + k - 1 and r0 + k share
-	__shared__ uint2 s_present[PT_BLOCK];    // entry of the K-mer of suffix r, if the gap owns it
+	__shared__ uint32_t s_off[PT_TILE + 1]; // exclusive prefix sums of the gaps' entry counts
+	__shared__ uint32_t s_first[PT_TILE];   // first code a gap owns
+	__shared__ uint32_t s_absent[PT_TILE];  // number of absent codes it owns (they come first)
+	__shared__ uint32_t s_h[PT_TILE + 2];   // s_h[k + 1]: characters the suffixes r0 + k - 1 and r0 + k share
+	__shared__ uint2 s_present[PT_TILE];    // entry of the K-mer of suffix r, if the gap owns it
 	__shared__ uint32_t s_wave[PT_BLOCK / 64];
-	__shared__ uint32_t s_rec[PT_BLOCK + 3]; // rec of the suffixes r0 - 2 .. r0 + PT_BLOCK
+	__shared__ uint32_t s_rec[PT_TILE + 3]; // rec of the suffixes r0 - 2 .. r0 + PT_TILE
 
-	const int64_t r0 = (int64_t)blockIdx.x * PT_BLOCK;
-	const int64_t gid = r0 + threadIdx.x;
+	const int64_t r0 = (int64_t)blockIdx.x * PT_TILE;
 	// the suffixes' records are made here (they used to be a kernel and an array of their own)
-	s_rec[threadIdx.x + 2] = gid < n ? suffix_rec(N0, SA, (int32_t)gid, K) : 0u;
+	{
+		uint32_t mine[PT_GAPS];
+#pragma unroll
+		for (int u = 0; u < PT_GAPS; ++u) {
+			const int64_t g = r0 + threadIdx.x + u * PT_BLOCK;
+			mine[u] = g < n ? suffix_rec(N0, SA, (int32_t)g, K) : 0u;
+		}
+#pragma unroll
+		for (int u = 0; u < PT_GAPS; ++u) s_rec[threadIdx.x + u * PT_BLOCK + 2] = mine[u];
+	}
 	if (threadIdx.x < 2) s_rec[threadIdx.x] = r0 + threadIdx.x >= 2 ? suffix_rec(N0, SA, (int32_t)(r0 + threadIdx.x - 2), K) : 0u;
-	if (threadIdx.x == 2) s_rec[PT_BLOCK + 2] = r0 + PT_BLOCK < n ? suffix_rec(N0, SA, (int32_t)(r0 + PT_BLOCK), K) : 0u;
+	if (threadIdx.x == 2) s_rec[PT_TILE + 2] = r0 + PT_TILE < n ? suffix_rec(N0, SA, (int32_t)(r0 + PT_TILE), K) : 0u;
 	__syncthreads();
 	auto rec = [&](int32_t j) { // 0 <= j < n; inside the block's range from LDS
 		const int64_t k = (int64_t)j - r0 + 2;
-		return (k >= 0 && k < PT_BLOCK + 3) ? s_rec[k] : suffix_rec(N0, SA, j, K);
+		return (k >= 0 && k < PT_TILE + 3) ? s_rec[k] : suffix_rec(N0, SA, j, K);
 	};
-	const bool live = gid <= n;
-	const int32_t r = (int32_t)(live ? gid : 0);
-	const bool hasL = live && r > 0, hasR = live && r < n;
-	const uint32_t L = hasL ? s_rec[threadIdx.x + 1] : 0u, R = hasR ? s_rec[threadIdx.x + 2] : 0u;
 	const uint32_t full = (uint32_t)K;
-	const uint32_t h = (hasL && hasR) ? rec_lcp(L, R, K) : 0u;
-	s_h[threadIdx.x + 1] = h;
 	if (threadIdx.x == 0) s_h[0] = r0 >= 2 ? rec_lcp(s_rec[0], s_rec[1], K) : 0u;
-	if (threadIdx.x == 1) s_h[PT_BLOCK + 1] = r0 + PT_BLOCK < n ? rec_lcp(s_rec[PT_BLOCK + 1], s_rec[PT_BLOCK + 2], K) : 0u;
-	uint32_t absent = 0, first = 0, owns_present = 0;
-	uint2 present = make_uint2(0, 0);
+	if (threadIdx.x == 1) s_h[PT_TILE + 1] = r0 + PT_TILE < n ? rec_lcp(s_rec[PT_TILE + 1], s_rec[PT_TILE + 2], K) : 0u;
 
-	if (live) {
-		// (a) present K-mers
-		if (hasR && REC_V(R) == full && !(hasL && REC_V(L) == full && REC_CODE(L) == REC_CODE(R))) {
-			int32_t j = r;
-			while (j + 1 < n && rec(j + 1) == R) ++j;
-			if (j == r) {
-				present = make_uint2((uint32_t)SA[r], DEEP_SINGLE | (1u << 2) | (full << 8));
-			} else if ((uint32_t)(j - r) < (1u << 24)) {
-				present = make_uint2((uint32_t)r, DEEP_MULTI | ((uint32_t)(j - r) << 8));
-			} else {
-				present = make_uint2(0, DEEP_SEARCH);
-			}
-			owns_present = 1;
-			first = REC_CODE(R);
-		}
-
-		// (c) closed run of suffixes "w <sep>" with 1 <= |w| <= 8
-		if (hasR) {
-			uint32_t k = REC_V(R), sp = REC_SEP(R);
-			if (k >= 1 && k <= 8 && k < full && (sp == 1 || sp == 2) && (!hasL || h < k)) {
-				int32_t j = r;
-				while (j + 1 < n) {
-					uint32_t X = rec(j + 1);
-					if (REC_V(X) == k && REC_SEP(X) == sp && rec_lcp(R, X, K) == k) ++j; else break;
-				}
-				if (j > r && (j + 1 == n || rec_lcp(R, rec(j + 1), K) < k)) flags[0] = 1; // (pinned host memory: plain idempotent store)
-			}
-		}
-
-		// (b) absent K-mers inside this gap
-		int32_t lo, hi; // codes are below 4^13: 32 bits do
-		if (!hasL) {
-			lo = 0;
-		} else if (REC_V(L) == full) {
-			lo = (int32_t)REC_CODE(L) + 1;
-		} else { // w <sep> sorts before every K-mer that starts with w
-			uint32_t sh = 2 * (full - REC_V(L));
-			lo = (int32_t)((REC_CODE(L) >> sh) << sh);
-		}
-		if (!hasR) {
-			hi = (int32_t)((1u << (2 * K)) - 1u);
-		} else if (REC_V(R) == full) {
-			hi = (int32_t)REC_CODE(R) - 1;
-		} else {
-			uint32_t sh = 2 * (full - REC_V(R));
-			hi = (int32_t)((REC_CODE(R) >> sh) << sh) - 1;
-		}
-		if (lo <= hi) {
-			absent = (uint32_t)(hi - lo + 1);
-			first = (uint32_t)lo;
-		}
-	}
-
-	// block-wide exclusive scan of the entry counts
-	const uint32_t mine = absent + owns_present, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	uint32_t incl = mine;
+	uint32_t counts[PT_GAPS];
 #pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		uint32_t other = (uint32_t)__shfl_up((int)incl, d);
-		if (lane >= (uint32_t)d) incl += other;
+	for (int u = 0; u < PT_GAPS; ++u) {
+		const uint32_t i = threadIdx.x + u * PT_BLOCK; // gap r0 + i
+		const int64_t gid = r0 + i;
+		const bool live = gid <= n;
+		const int32_t r = (int32_t)(live ? gid : 0);
+		const bool hasL = live && r > 0, hasR = live && r < n;
+		const uint32_t L = hasL ? s_rec[i + 1] : 0u, R = hasR ? s_rec[i + 2] : 0u;
+		const uint32_t h = (hasL && hasR) ? rec_lcp(L, R, K) : 0u;
+		s_h[i + 1] = h;
+		uint32_t absent = 0, first = 0, owns_present = 0;
+		uint2 present = make_uint2(0, 0);
+
+		if (live) {
+			// (a) present K-mers
+			if (hasR && REC_V(R) == full && !(hasL && REC_V(L) == full && REC_CODE(L) == REC_CODE(R))) {
+				int32_t j = r;
+				while (j + 1 < n && rec(j + 1) == R) ++j;
+				if (j == r) {
+					present = make_uint2((uint32_t)SA[r], DEEP_SINGLE | (1u << 2) | (full << 8));
+				} else if ((uint32_t)(j - r) < (1u << 24)) {
+					present = make_uint2((uint32_t)r, DEEP_MULTI | ((uint32_t)(j - r) << 8));
+				} else {
+					present = make_uint2(0, DEEP_SEARCH);
+				}
+				owns_present = 1;
+				first = REC_CODE(R);
+			}
+
+			// (c) closed run of suffixes "w <sep>" with 1 <= |w| <= 8
+			if (hasR) {
+				uint32_t k = REC_V(R), sp = REC_SEP(R);
+				if (k >= 1 && k <= 8 && k < full && (sp == 1 || sp == 2) && (!hasL || h < k)) {
+					int32_t j = r;
+					while (j + 1 < n) {
+						uint32_t X = rec(j + 1);
+						if (REC_V(X) == k && REC_SEP(X) == sp && rec_lcp(R, X, K) == k) ++j; else break;
+					}
+					if (j > r && (j + 1 == n || rec_lcp(R, rec(j + 1), K) < k)) flags[0] = 1; // (pinned host memory: plain idempotent store)
+				}
+			}
+
+			// (b) absent K-mers inside this gap
+			int32_t lo, hi; // codes are below 4^13: 32 bits do
+			if (!hasL) {
+				lo = 0;
+			} else if (REC_V(L) == full) {
+				lo = (int32_t)REC_CODE(L) + 1;
+			} else { // w <sep> sorts before every K-mer that starts with w
+				uint32_t sh = 2 * (full - REC_V(L));
+				lo = (int32_t)((REC_CODE(L) >> sh) << sh);
+			}
+			if (!hasR) {
+				hi = (int32_t)((1u << (2 * K)) - 1u);
+			} else if (REC_V(R) == full) {
+				hi = (int32_t)REC_CODE(R) - 1;
+			} else {
+				uint32_t sh = 2 * (full - REC_V(R));
+				hi = (int32_t)((REC_CODE(R) >> sh) << sh) - 1;
+			}
+			if (lo <= hi) {
+				absent = (uint32_t)(hi - lo + 1);
+				first = (uint32_t)lo;
+			}
+		}
+		s_first[i] = first, s_absent[i] = absent, s_present[i] = present;
+		counts[u] = absent + owns_present;
 	}
-	if (lane == 63) s_wave[wave] = incl;
-	s_first[threadIdx.x] = first, s_absent[threadIdx.x] = absent;
-	s_present[threadIdx.x] = present;
-	__syncthreads();
-	uint32_t before = 0;
-	for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
-	s_off[threadIdx.x] = before + incl - mine;
+
+	// block-wide exclusive scan of the entry counts, gap order = u * PT_BLOCK + thread
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t total = 0;
-	for (uint32_t w = 0; w < PT_BLOCK / 64; ++w) total += s_wave[w];
-	if (threadIdx.x == 0) s_off[PT_BLOCK] = total;
+#pragma unroll
+	for (int u = 0; u < PT_GAPS; ++u) {
+		uint32_t incl = counts[u];
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			uint32_t other = (uint32_t)__shfl_up((int)incl, d);
+			if (lane >= (uint32_t)d) incl += other;
+		}
+		__syncthreads(); // s_wave free again
+		if (lane == 63) s_wave[wave] = incl;
+		__syncthreads();
+		uint32_t before = total, all = 0;
+		for (uint32_t w = 0; w < PT_BLOCK / 64; ++w) {
+			if (w < wave) before += s_wave[w];
+			all += s_wave[w];
+		}
+		s_off[threadIdx.x + u * PT_BLOCK] = before + incl - counts[u];
+		total += all;
+	}
+	if (threadIdx.x == 0) s_off[PT_TILE] = total;
 	__syncthreads();
 
 	for (uint32_t t = threadIdx.x; t < total; t += PT_BLOCK) {
 		// the gap that owns entry t: the last one whose offset is <= t
-		uint32_t a = 0, b = PT_BLOCK; // invariant: s_off[a] <= t < s_off[b]
+		uint32_t a = 0, b = PT_TILE; // invariant: s_off[a] <= t < s_off[b]
 		while (b - a > 1) {
 			uint32_t mid = (a + b) >> 1;
 			if (s_off[mid] <= t) a = mid; else b = mid;
@@ -492,7 +516,7 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
 	// symbols for the lane scan: the text, its NUL and 64 bytes of the zero padding behind it
 	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 1, st);
 	if (e != hipSuccess) return e;
-	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_BLOCK - 1) / PT_BLOCK), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.deep, a.flags, n,
+	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_TILE - 1) / PT_TILE), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.deep, a.flags, n,
 																				  a.deepK);
 	CHECK_LAUNCH();
 	return hipSuccess;
