@@ -17,7 +17,7 @@
 //                          from there on the cold chain's counts are the true
 //                          ones.  This pass assumes the predecessor's cold exit
 //                          state IS the true entry state.
-//   pass C  k_scan_reduce  one wavefront per pair checks that assumption for
+//   pass C  k_scan_reduce  one block per pair checks that assumption for
 //                          every segment (true exit of s-1 == cold exit of
 //                          s-1), sums the per-segment counts, re-stitches the
 //                          rare segments whose assumption failed, and applies
@@ -426,25 +426,26 @@ __global__ __launch_bounds__(BLOCK, 5) void k_scan_stitch(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------ pass C
+// One block per pair: all its wavefronts check the segments and add up their counts; the
+// first wavefront then does what is sequential (fix-ups, epilogue).
 __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
-	__shared__ uint32_t s_hist[WAVES_PER_BLOCK][3][16];
-	uint32_t sub = blockIdx.y;
-	uint32_t qidx = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-	if (qidx >= a.nq) return;
-	uint32_t lane = __lane_id();
+	__shared__ uint32_t s_hist[3][16];
+	const uint32_t sub = blockIdx.y, qidx = blockIdx.x;
+	const uint32_t lane = __lane_id();
 	andi_hip_model *out = a.M + (size_t)sub * a.nq + qidx;
 
 	if (a.self[sub] == (int64_t)qidx) { // src/dist_hack.h:61-64
-		if (lane < 17) {
+		if (threadIdx.x < 17) {
 			uint32_t *o = (uint32_t *)out;
-			o[lane] = (lane == 0 || lane == 16) ? 9u : 0u;
+			o[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 16) ? 9u : 0u;
 		}
 		return;
 	}
 
-	uint32_t *total = s_hist[threadIdx.x >> 6][0];
-	uint32_t *histT = s_hist[threadIdx.x >> 6][1], *histC = s_hist[threadIdx.x >> 6][2];
-	if (lane < 16) total[lane] = 0;
+	uint32_t *total = s_hist[0];
+	uint32_t *histT = s_hist[1], *histC = s_hist[2];
+	if (threadIdx.x < 16) total[threadIdx.x] = 0;
+	__syncthreads();
 
 	uint32_t nseg, seg;
 	size_t row;
@@ -460,16 +461,33 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 
 	// every segment k >= 1 was stitched assuming it is entered in the cold exit of entry_source(k)
 	bool ok = true;
-	for (uint32_t k = 1 + lane; k < nseg; k += 64)
+	for (uint32_t k = 1 + threadIdx.x; k < nseg; k += BLOCK)
 		ok = ok && same_state(a.true_exit[row + k - 1], a.cold_exit[row + entry_source(a, row, k, seg, c.qlen)]);
+	const bool all_ok = __syncthreads_and(ok);
 	ChainState fin;
-	if (__all(ok)) {
-		for (uint32_t k = lane; k < nseg; k += 64) {
-			const uint32_t *o = a.owned + (row + k) * 16;
-			for (int t = 0; t < 16; ++t) atomicAdd(&total[t], o[t]);
+	if (all_ok) {
+		uint32_t sum[16];
+#pragma unroll
+		for (int t = 0; t < 16; ++t) sum[t] = 0;
+		for (uint32_t k = threadIdx.x; k < nseg; k += BLOCK) {
+			const uint4 *o = (const uint4 *)(a.owned + (row + k) * 16);
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const uint4 v = o[t];
+				sum[4 * t] += v.x, sum[4 * t + 1] += v.y, sum[4 * t + 2] += v.z, sum[4 * t + 3] += v.w;
+			}
 		}
+#pragma unroll
+		for (int t = 0; t < 16; ++t) {
+			uint32_t v = sum[t];
+			for (int d = 32; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+			if (lane == 0) atomicAdd(&total[t], v);
+		}
+		__syncthreads();
+		if (threadIdx.x >= 64) return;
 		fin = a.true_exit[row + nseg - 1];
 	} else {
+		if (threadIdx.x >= 64) return; // what follows is sequential: the first wavefront alone
 		ChainState st = initial_state();
 		for (uint32_t k = 0; k < nseg; ++k) {
 			ChainState assumed = k == 0 ? initial_state() : a.cold_exit[row + entry_source(a, row, k, seg, c.qlen)];
@@ -607,7 +625,7 @@ hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
 }
 
 hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st) {
-	dim3 grid((a.nq + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.nsub);
+	dim3 grid(a.nq, a.nsub); // one block per pair
 	k_scan_reduce<<<grid, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	return hipSuccess;
