@@ -696,7 +696,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	const size_t pairs_all = nsub * q->nq;
 	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
-	const size_t need = slots * (2 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark)) +
+	const size_t need = slots * (2 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4) +
 						(adaptive ? pairs_all * 9 + 64 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -725,6 +725,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	p += slots * 16 * sizeof(uint32_t);
 	a.marks = (ColdMark *)p;
 	p += slots * ANDI_COLD_MARKS * sizeof(ColdMark);
+	a.exit_p = (uint32_t *)p;
+	p += slots * sizeof(uint32_t);
 	a.adaptive = adaptive ? 1 : 0;
 	a.seg0 = seg0, a.max_waves = (uint32_t)max_waves;
 	a.max_class = 0; // long segments must not leave the device short of chains

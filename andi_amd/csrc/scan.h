@@ -45,6 +45,7 @@ struct ScanArgs {
 	uint32_t seg; // nucleotides per segment
 	// per (subject, segment) scratch
 	ChainState *cold_exit; // state when the cold chain leaves the segment
+	uint32_t *exit_p;      // its position alone, densely (entry_source reads eight of them per segment)
 	uint32_t *cold_counts; // [..][16] counts the cold chain added inside the segment
 	ColdMark *marks;       // [..][ANDI_COLD_MARKS] (lane scan only)
 	ChainState *true_exit; // state of the true chain when it leaves the segment

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
 	uint32_t lane = Group<G>::sub();
-	if (lane == 0) a.cold_exit[slot] = st;
+	if (lane == 0) a.cold_exit[slot] = st, a.exit_p[slot] = st.p;
 	tally_finish<G>(tally);
 	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = tally.hist[t * tally.hs];
 }

@@ -128,7 +128,7 @@ __device__ __forceinline__ uint32_t entry_source(const ScanArgs &a, size_t row, 
 		const uint32_t e = (j + 1) * seg, end_j = e < qlen ? e : qlen;
 		bool covered = false;
 		for (uint32_t back = 1; back <= ANDI_SPAN_WINDOW && back <= j && !covered; ++back)
-			covered = a.cold_exit[row + j - back].p >= end_j;
+			covered = a.exit_p[row + j - back] >= end_j;
 		if (!covered) break;
 		--j;
 	}

@@ -522,6 +522,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 	for (uint32_t k = anchors < 2 ? 0 : anchors - 1; k < ANDI_COLD_MARKS; ++k) marks[k].st.pad[0] = 0; // unused marks
 
 	a.cold_exit[slot] = st;
+	a.exit_p[slot] = st.p;
 	tally_finish<1>(tally);
 	uint32_t out[16];
 #pragma unroll
