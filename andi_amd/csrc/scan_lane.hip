@@ -704,10 +704,12 @@ static int lane_occupancy() { // waves per SIMD pass A is compiled for (experime
 
 template <bool EXACT>
 static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
+	const char *pe = getenv("ANDI_LANE_LDS_PAD"); // experiments: unused LDS per block, limits the resident wavefronts
+	const size_t pad = pe ? (size_t)atoi(pe) : 0;
 	switch (lane_occupancy()) {
-		case 4: k_lane_cold<EXACT, 4><<<grid, BLOCK, 0, st>>>(a); break;
-		case 6: k_lane_cold<EXACT, 6><<<grid, BLOCK, 0, st>>>(a); break;
-		default: k_lane_cold<EXACT, 8><<<grid, BLOCK, 0, st>>>(a); break;
+		case 4: k_lane_cold<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
+		case 6: k_lane_cold<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break;
+		default: k_lane_cold<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
 	}
 	return hipGetLastError();
 }
