@@ -11,7 +11,7 @@
 //   N0   uint8[n/2+..]   the text as 4-bit symbols (A C G T ! ; # NUL = 0..7), symbol i in
 //                        the low (i even) or high half of byte i/2; N1 the same shifted by
 //                        one symbol (byte b = symbols 2b-1, 2b), so that a 16-byte load can
-//                        start at any symbol.  16 readable bytes in front, 128 behind.
+//                        start at any symbol.  256 readable bytes in front, 384 behind.
 //   flags int32[4]       [0] != 0: some 10-mer table entry may span a separator
 //                        (SURVEY.md appendix C.11): the reference's cached lookup
 //                        is then not the true longest match and the scan follows
@@ -32,7 +32,8 @@
 #define ANDI_CACHE_K 10
 #define ANDI_PAD 2048 /* bytes of zero padding behind every byte pool */
 #define ANDI_MAX_DEEP_K 13
-#define ANDI_NIB_BACK 128 /* readable bytes behind the packed symbols of a text */
+#define ANDI_NIB_BACK 384  /* readable bytes behind the packed symbols of a text */
+#define ANDI_NIB_FRONT 256 /* and in front of them */
 
 struct EsaDev {
 	const uint8_t *S;
@@ -55,7 +56,7 @@ struct EsaDev {
 
 // probe-table entry: x = payload, y = kind | unique << 2 | l << 8
 #define DEEP_FINAL 0u  /* K-mer absent: match length l < K; x = SA index of the one suffix if unique */
-#define DEEP_SINGLE 1u /* K-mer occurs once: x = its position in RS */
+#define DEEP_SINGLE 1u /* K-mer occurs once: x = its position in RS; y >> 2 & 15 = v <= 13 nucleotides follow it, y >> 6 = their 2-bit codes (first in the low bits) */
 #define DEEP_MULTI 2u  /* K-mer occurs more than once: x = first SA index, y >> 8 = run length - 1 */
 #define DEEP_SEARCH 3u /* (run too long to encode) search the whole suffix array */
 

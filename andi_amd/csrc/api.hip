@@ -304,21 +304,22 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	};
 	const size_t deep_entries = (size_t)1 << (2 * pick_deep_k(cap));
 	chk(dmalloc(&e->S, cap + 1 + ANDI_PAD));
-	chk(dmalloc(&e->SA, cap));
+	chk(dmalloc(&e->SA, cap + 8)); // +8: the scan reads the occurrences of a repeated K-mer eight entries at a time
 	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
-	// symbols: [16 B front][N0: cap/2 + 1 + back][N1: same], each part 16-byte aligned
-	const size_t nib_part = (cap / 2 + 1 + ANDI_NIB_BACK + 15) & ~(size_t)15;
-	chk(dmalloc(&e->Nraw, 2 * (16 + nib_part)));
+	// symbols: [front][N0: cap/2 + 1 + back][front][N1: same]; N0 and N1 start on a 256-byte boundary, the
+	// paddings (NUL symbols) let whole lines of the text be fetched around any window the scan may ask for
+	const size_t nib_part = (cap / 2 + 1 + ANDI_NIB_BACK + 255) & ~(size_t)255;
+	chk(dmalloc(&e->Nraw, 2 * (ANDI_NIB_FRONT + nib_part)));
 	if (err == hipSuccess) {
-		e->N0 = e->Nraw + 16, e->N1 = e->Nraw + 16 + nib_part + 16;
-		chk(hipMemsetAsync(e->Nraw, 0x77, 2 * (16 + nib_part), ctx->stream));
+		e->N0 = e->Nraw + ANDI_NIB_FRONT, e->N1 = e->Nraw + ANDI_NIB_FRONT + nib_part + ANDI_NIB_FRONT;
+		chk(hipMemsetAsync(e->Nraw, 0x77, 2 * (ANDI_NIB_FRONT + nib_part), ctx->stream));
 	}
 	// flags: pinned host memory the kernels write directly (rare, idempotent plain stores) --
 	// no per-build memset or copy; the host reads them after a stream synchronisation
 	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocMapped));
 	if (err == hipSuccess) chk(hipHostGetDevicePointer((void **)&e->flags, e->h_flags, 0));
 	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 80 +
-			   2 * (16 + nib_part);
+			   2 * (ANDI_NIB_FRONT + nib_part);
 	if (err != hipSuccess) {
 		andi_hip_esa_free(ctx, e);
 		return fail(ctx, "allocating a subject", err);
@@ -486,7 +487,7 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 		q->off[i] = cursor;
 		q->len[i] = (uint32_t)seqs[i].len;
 		q->total_nt += seqs[i].len;
-		cursor += (seqs[i].len + 1 + 15) & ~(uint64_t)15; // NUL + 16-byte aligned starts
+		cursor += (seqs[i].len + 1 + 255) & ~(uint64_t)255; // NUL; starts on 256-byte boundaries (128 of the packed pool: a cache line)
 	}
 	const size_t pool_bytes = cursor + ANDI_PAD;
 	hipError_t err = hipSuccess;
@@ -742,6 +743,12 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.fixups = ctx->d_fixups;
 	a.any_reference = any_reference;
 	a.group = andi_scan_group();
+	{
+		const char *mp = getenv("ANDI_ROUNDS_PASSES");
+		a.max_passes = mp && atoi(mp) > 0 ? (uint32_t)atoi(mp) : 3u;
+		const char *kn = getenv("ANDI_KNOCK");
+		a.knock = kn ? (uint32_t)atoi(kn) : 0u;
+	}
 	a.lanes = a.group == 0;
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 

@@ -338,7 +338,7 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restrict__ N0,
 														  const int32_t *__restrict__ SA,
 														  uint2 *__restrict__ deep,
-														  int32_t *__restrict__ flags, int32_t n, int K) {
+														  int32_t *__restrict__ flags, int32_t n, int K, int single_ext) {
 	__shared__ uint32_t s_off[PT_TILE + 1]; // exclusive prefix sums of the gaps' entry counts
 	__shared__ uint32_t s_first[PT_TILE];   // first code a gap owns
 	__shared__ uint32_t s_absent[PT_TILE];  // number of absent codes it owns (they come first)
@@ -390,7 +390,25 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 				int32_t j = r;
 				while (j + 1 < n && rec(j + 1) == R) ++j;
 				if (j == r) {
-					present = make_uint2((uint32_t)SA[r], DEEP_SINGLE | (1u << 2) | (full << 8));
+					// the K-mer occurs once.  For the scan in rounds (scan_rounds.hip) its entry also carries the
+					// (up to 13) nucleotides that follow it in the text, so that a chance match is settled
+					// without touching the text (costs the build a second gather: +11 %)
+					const uint32_t pos = (uint32_t)SA[r], e0 = pos + full;
+					if (!single_ext) {
+						present = make_uint2(pos, DEEP_SINGLE | (1u << 2) | (full << 8));
+					} else {
+					const uint64_t w = ld_u64_unaligned((g_u8p)N0 + (e0 >> 1)) >> (4 * (e0 & 1u)); // 15 symbols from e0 on
+					uint32_t nval = (uint32_t)__builtin_ctzll((w & 0x4444444444444444ull) | (1ull << 52)) >> 2; // <= 13
+					auto squeeze = [](uint32_t x) { // 8 nibbles -> 8 x 2 bits, first symbol in the low bits
+						x &= 0x33333333u;
+						x = (x | (x >> 2)) & 0x0f0f0f0fu;
+						x = (x | (x >> 4)) & 0x00ff00ffu;
+						x = (x | (x >> 8)) & 0x0000ffffu;
+						return x;
+					};
+					const uint32_t ext = (squeeze((uint32_t)w) | (squeeze((uint32_t)(w >> 32)) << 16)) & ((1u << (2 * nval)) - 1u);
+					present = make_uint2(pos, DEEP_SINGLE | (nval << 2) | (ext << 6));
+					}
 				} else if ((uint32_t)(j - r) < (1u << 24)) {
 					present = make_uint2((uint32_t)r, DEEP_MULTI | ((uint32_t)(j - r) << 8));
 				} else {
@@ -517,7 +535,7 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
 	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 1, st);
 	if (e != hipSuccess) return e;
 	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_TILE - 1) / PT_TILE), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.deep, a.flags, n,
-																				  a.deepK);
+																				  a.deepK, andi_rounds_lines() != 0);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }

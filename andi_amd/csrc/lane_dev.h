@@ -1,0 +1,158 @@
+// lane_dev.h -- device helpers shared by the kernels that run ONE LANE PER CHAIN on the 4-bit
+// symbols (scan_lane.hip: passes A and B with direct loads; scan_rounds.hip: pass A in rounds
+// with line buffers): windows of 32 symbols, their comparison, K-mer codes, work items.
+#pragma once
+#include "scan_dev.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+// -DANDI_LANE_STATS: count the memory accesses of pass A by kind (diagnostic builds only)
+#ifdef ANDI_LANE_STATS
+static __device__ unsigned long long g_lane_stats[16];
+#define STAT(k) atomicAdd(&g_lane_stats[k], 1ull)
+#else
+#define STAT(k) ((void)0)
+#endif
+// -DANDI_KNOCKOUT: parts of pass A can be switched off at run time (ANDI_KNOCK=bits) to time them; results are then wrong
+#ifdef ANDI_KNOCKOUT
+#define KNOCK(c, bit) (((c).knock >> (bit)) & 1u)
+#else
+#define KNOCK(c, bit) false
+#endif
+enum { ST_STEP, ST_LCP_RELOAD, ST_LCP_SLIDE, ST_PROBE, ST_PROBE_RELOAD, ST_TABLE, ST_FINAL_SA, ST_SINGLE, ST_EXT_LOOP,
+	   ST_MULTI, ST_MULTI_CAND, ST_SEARCH, ST_GAP_RELOAD, ST_GAP_WORDS, ST_SUBST, ST_LUCKY_TRY };
+
+constexpr uint32_t WNT = 32; // symbols per window
+constexpr uint32_t EMPTY = ~0u;
+constexpr int32_t NO_DIAG = INT32_MIN;
+constexpr uint32_t ONES = 0x11111111u;
+constexpr uint32_t MULTI_MAX = 8; // occurrences a lane extends along one by one; more: binary search
+
+// 32 symbols of the query from q0 (even) and, if dg != NO_DIAG, of the subject from q0 + dg
+struct LWin {
+	uint32_t q0;
+	int32_t dg;
+	uint4 q, s;
+	uint4 d; // bit 4k of word j: symbols 8j + k differ
+};
+
+__device__ __forceinline__ uint32_t pick(const uint4 &v, uint32_t j) {
+	return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : j == 3 ? v.w : 0u;
+}
+
+__device__ __forceinline__ uint32_t neq8(uint32_t a, uint32_t b) { // one bit per differing nibble
+	uint32_t x = a ^ b;
+	x |= x >> 1;
+	x |= x >> 2;
+	return x & ONES;
+}
+
+__device__ __forceinline__ uint4 neq32(const uint4 &a, const uint4 &b) {
+	return make_uint4(neq8(a.x, b.x), neq8(a.y, b.y), neq8(a.z, b.z), neq8(a.w, b.w));
+}
+
+// index (0..31) of the first marked symbol at or after symbol o, 32 if none
+__device__ __forceinline__ uint32_t first_from(const uint4 &d, uint32_t o) {
+	uint64_t lo = d.x | ((uint64_t)d.y << 32), hi = d.z | ((uint64_t)d.w << 32);
+	const uint32_t sh = 4 * o;
+	if (sh < 64) {
+		lo = (lo >> sh) << sh;
+	} else {
+		lo = 0;
+		hi = sh < 128 ? (hi >> (sh - 64)) << (sh - 64) : 0;
+	}
+	if (lo) return (uint32_t)__builtin_ctzll(lo) >> 2;
+	if (hi) return 16 + ((uint32_t)__builtin_ctzll(hi) >> 2);
+	return WNT;
+}
+
+// bits 4a, 4a+4, ... 4b-4 (0 <= a < b <= 8)
+__device__ __forceinline__ uint32_t symbol_range(uint32_t a, uint32_t b) {
+	return (0xffffffffu >> (32 - 4 * b)) & ~((1u << (4 * a)) - 1u) & ONES;
+}
+
+__device__ __forceinline__ uint4 ld_query(const PairCtx &c, uint32_t qa) { // qa even
+	return ld_u128_unaligned(c.Qn + (qa >> 1));
+}
+
+__device__ __forceinline__ uint4 ld_subject(const PairCtx &c, int32_t sa) { // sa >= -32
+	const int32_t odd = sa & 1;
+	g_u8p base = odd ? c.E.N1 : c.E.N0;
+	return ld_u128_unaligned(base + ((sa + odd) >> 1));
+}
+
+// 2-bit code (first symbol most significant) of the K symbols at offset o of the
+// window (o + K <= 32); false if one of them is not a nucleotide.
+__device__ __forceinline__ bool lane_kmer(const LWin &w, uint32_t o, uint32_t K, uint32_t &code) {
+	const uint32_t j = o >> 3, r = (o & 7u) * 4u;
+	const uint32_t a = pick(w.q, j), b = pick(w.q, j + 1), e = pick(w.q, j + 2);
+	const uint32_t lo = __builtin_amdgcn_alignbit(b, a, r), hi = __builtin_amdgcn_alignbit(e, b, r);
+	const uint64_t v = lo | ((uint64_t)hi << 32);
+	const uint64_t inside = ~0ull >> (64 - 4 * K);
+	auto squeeze = [](uint32_t x) { // 8 nibbles -> 8 x 2 bits, first symbol in the low bits
+		x &= 0x33333333u;
+		x = (x | (x >> 2)) & 0x0f0f0f0fu;
+		x = (x | (x >> 4)) & 0x00ff00ffu;
+		x = (x | (x >> 8)) & 0x0000ffffu;
+		return x;
+	};
+	uint32_t y = __brev(squeeze(lo) | (squeeze(hi) << 16)); // first symbol on top, bits of a pair swapped
+	y = ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
+	code = y >> (32 - 2 * K);
+	return (v & inside & 0x4444444444444444ull) == 0;
+}
+
+// ------------------------------------------------------------------ work items
+// One lane = one segment.  Uniform mode: segment w of subject blockIdx.y (decode_item).
+// Adaptive mode: wavefront W of the launch belongs to the pair whose slots contain
+// 64 * W; all its lanes work on that pair.
+struct LaneItem {
+	uint32_t sub, qidx, seg_in_q, start, end, seg;
+	size_t slot;
+	bool valid;
+};
+
+template <int NT = BLOCK> // threads per block
+__device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
+	LaneItem it;
+	if (!a.adaptive) {
+		it.sub = blockIdx.y;
+		const uint32_t w = blockIdx.x * NT + threadIdx.x;
+		it.valid = w < a.total_segs;
+		it.qidx = it.seg_in_q = it.start = it.end = 0;
+		it.seg = a.seg;
+		it.slot = (size_t)it.sub * a.total_segs + w;
+		if (it.valid) {
+			it.qidx = a.seg2query[w];
+			it.seg_in_q = w - a.qseg_start[it.qidx];
+			const uint32_t qlen = a.qlen[it.qidx];
+			it.start = it.seg_in_q * a.seg;
+			it.end = it.start + a.seg < qlen ? it.start + a.seg : qlen;
+			it.valid = a.self[it.sub] != (int64_t)it.qidx;
+		}
+		return it;
+	}
+	const uint32_t P = a.nsub * a.nq;
+	const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NT / 64) + (threadIdx.x >> 6)));
+	it.valid = false;
+	it.sub = it.qidx = it.seg_in_q = it.start = it.end = it.seg = 0, it.slot = 0;
+	if (W >= a.pair_wave0[P]) return it;
+	uint32_t lo = 0, hi = P; // the last pair whose first wavefront is <= W (pairs without work share their successor's)
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (a.pair_wave0[mid] <= W) lo = mid; else hi = mid;
+	}
+	const uint32_t pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+	it.sub = pair / a.nq, it.qidx = pair % a.nq;
+	const uint32_t seg = a.seg0 << a.pair_class[pair], qlen = a.qlen[it.qidx];
+	it.seg_in_q = (W - a.pair_wave0[pair]) * 64 + (threadIdx.x & 63u);
+	it.seg = seg;
+	it.start = it.seg_in_q * seg;
+	it.valid = it.start < qlen;
+	it.end = it.start + seg < qlen ? it.start + seg : qlen;
+	it.slot = (size_t)64 * W + (threadIdx.x & 63u);
+	return it;
+}
+

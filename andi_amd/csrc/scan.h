@@ -67,6 +67,8 @@ struct ScanArgs {
 	uint32_t *pair_wave0;
 	uint32_t max_waves;   // upper bound (every pair in class 0): the grid
 	int group;         // otherwise: lanes per chain of scan.hip's kernels (2, 4, 8)
+	uint32_t max_passes; // scan_rounds.hip: trips of the compute loop per round
+	uint32_t knock;      // diagnostic builds (-DANDI_LANE_STATS): parts of pass A switched off to time them (results are then wrong)
 };
 
 // 4-bit symbols of `bytes` source bytes (a NUL-padded pool or text) into N0 and, if not
@@ -81,6 +83,9 @@ int andi_scan_group(void);
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
+// pass A in rounds with line buffers (scan_rounds.hip); andi_rounds_lines() != 0: in use
+int andi_rounds_lines(void);
+hipError_t andi_launch_rounds_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st);

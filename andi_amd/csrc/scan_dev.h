@@ -24,6 +24,7 @@ struct PairCtx {
 	uint32_t thr;
 	uint32_t border; // n / 2, src/process.c:149
 	bool exact;      // LogDet/ANI: equal runs are counted per nucleotide (src/model.c:256-278)
+	uint32_t knock;  // diagnostic builds only
 };
 
 __device__ __forceinline__ bool same_state(const ChainState &a, const ChainState &b) {
@@ -110,6 +111,7 @@ __device__ __forceinline__ PairCtx make_ctx(const ScanArgs &a, uint32_t sub, uin
 	c.thr = (uint32_t)c.E.thr;
 	c.border = (uint32_t)c.E.n / 2;
 	c.exact = a.exact_equal != 0;
+	c.knock = a.knock;
 	return c;
 }
 

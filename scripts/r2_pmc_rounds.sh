@@ -1,0 +1,20 @@
+#!/bin/bash
+# counters of pass A in rounds (one rocprofv3 --pmc pass per counter set)
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" || exit 1
+tag=$1; shift
+out=gpurun_out/pmc_$tag
+mkdir -p $out
+i=0
+while read -r set; do
+  [ -z "$set" ] && continue
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -o p$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/p$i.log 2>&1
+done <<'SETS'
+SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES
+SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+GRBM_GUI_ACTIVE
+SETS
+python3 scripts/pmc_summary.py $out > $out/summary.txt
+grep -A30 "k_rounds_cold\|k_lane_cold" $out/summary.txt | head -70

@@ -307,3 +307,25 @@ def test_segment_length_per_pair_changes_nothing(ctx, orc, monkeypatch):
             monkeypatch.setenv(k, v)
         got, t = _gpu_rows(ctx, seqs)
         assert (got == want).all(), env
+
+
+@pytest.mark.parametrize("lines", ["2,2", "4,4", "8,4", "8,8"])
+def test_pass_a_in_rounds_agrees(ctx, orc, monkeypatch, lines):
+    """ANDI_ROUNDS=QP,SP runs pass A as scan_rounds.hip does it: chains as state machines, all loads of a
+    wavefront in one place, the streams through line buffers in LDS, probe-table entries that carry the
+    symbols behind a K-mer that occurs once.  Same counts, whatever the buffers' sizes and however often
+    the wavefront goes to memory."""
+    from andi_amd import synth
+    monkeypatch.setenv("ANDI_ROUNDS", lines)
+    rng = np.random.default_rng(6)
+    base = synth.base_codes(90000, 13)
+    a = synth.to_bytes(base)
+    seqs = [a] + [synth.to_bytes(synth.mutate_codes(base, d, 40 + k)) for k, d in enumerate((0.0007, 0.01, 0.05, 0.15))]
+    unit = rand_dna(rng, 2500)
+    rep = rand_dna(rng, 20000) + unit + rand_dna(rng, 9000) + unit + rand_dna(rng, 7000) + unit[::-1].translate(
+        bytes.maketrans(b"ACGT", b"TGCA"))  # a repeat on both strands: K-mers with several occurrences
+    joined = a[:30000] + b"!" + rand_dna(rng, 700) + b"!" + seqs[2][30000:70000]
+    seqs += [rep, rep[:25000] + a[5000:30000], joined, rand_dna(rng, 3000, b"AC"), rand_dna(rng, 50)]
+    for passes in ("1", "3", "50"):
+        monkeypatch.setenv("ANDI_ROUNDS_PASSES", passes)
+        _check_set(ctx, orc, seqs, segments=(0, 1500, 64))
