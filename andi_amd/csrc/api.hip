@@ -26,9 +26,11 @@
 // several hundred thousand chains, long enough that stitching stays a few per cent
 #define ANDI_MIN_SEGMENT 4096u
 #define ANDI_MAX_SEGMENT 65536u
-#define ANDI_TARGET_CHAINS (1u << 20)
-// per-pair segment lengths: classes seg/2, seg, 2 seg, 4 seg of the call's length; one block lays them out
-#define ANDI_ADAPTIVE_MAX_PAIRS 16384u
+#define ANDI_TARGET_CHAINS (1u << 22) /* at most about this many chains per call (308 bytes of scratch each) */
+#define ANDI_MIN_CHAINS (1u << 19)    /* and long segments only while the call keeps this many */
+// per-pair segment lengths: classes seg/2, seg, 2 seg, 4 seg of the call's length, as long as the scratch they
+// need (whole wavefronts per pair) stays a fraction of the device's memory
+#define ANDI_ADAPTIVE_MAX_PAIRS (1u << 22)
 
 static_assert(sizeof(andi_hip_model) == 68, "struct model must be 17 x u32 (src/model.h:52-57)");
 static_assert(sizeof(andi_hip_interval) == 16, "lcp_inter_t is 4 x int32 (src/esa.h:25-34)");
@@ -678,7 +680,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	HIP_TRY(ctx, hipEventRecord(ctx->desc_done, ctx->stream));
 
 	// scratch: per (subject, segment) two states and two count vectors
-	const bool adaptive = want_adaptive && !any_reference;
+	bool adaptive = want_adaptive && !any_reference;
 	uint32_t seg0 = segment / 2; // classes: 1/2, 1, 2, 4 times the call's segment length
 	if (const char *e0 = getenv("ANDI_SEG0")) { // experiments: shortest segment of the adaptive classes
 		if (atoi(e0) >= 64) seg0 = (uint32_t)atoi(e0);
@@ -690,15 +692,20 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 				if (h_self[s] == (int64_t)i) continue;
 				max_waves += ((q->len[i] + (uint64_t)seg0 - 1) / seg0 + 63) / 64;
 			}
-		if (max_waves >= (1u << 26)) {
-			ctx->err = "too many scan segments; raise opts.segment";
-			return 1;
-		}
+		// a pair occupies whole wavefronts: with queries of a few segments most lanes would idle, and the
+		// scratch must stay a fraction of the device's memory -- one segment length for the call then
+		uint64_t used = 0;
+		for (size_t i = 0; i < q->nq; ++i) used += (q->len[i] + (uint64_t)seg0 - 1) / seg0;
+		used *= nsub;
+		size_t free_b = 0, total_b = 0;
+		const bool fits = max_waves < (1u << 26) &&
+						  (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)64 * max_waves * 308 < free_b / 2 + ctx->scratch_bytes);
+		if (!fits || (10 * used < 7 * 64 * max_waves && !getenv("ANDI_FORCE_ADAPTIVE"))) adaptive = false, max_waves = 0;
 	}
 	const size_t pairs_all = nsub * q->nq;
 	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
 	const size_t need = slots * (2 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4) +
-						(adaptive ? pairs_all * 9 + 64 : 0);
+						(adaptive ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -731,10 +738,11 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.adaptive = adaptive ? 1 : 0;
 	a.seg0 = seg0, a.max_waves = (uint32_t)max_waves;
 	a.max_class = 0; // long segments must not leave the device short of chains
-	while (a.max_class < 3 && nt / ((uint64_t)seg0 << (a.max_class + 1)) >= (ANDI_TARGET_CHAINS >> 1)) a.max_class++;
+	while (a.max_class < 3 && nt / ((uint64_t)seg0 << (a.max_class + 1)) >= ANDI_MIN_CHAINS) a.max_class++;
 	a.pair_waves = (uint32_t *)p;
 	a.pair_wave0 = a.pair_waves + pairs_all;
-	a.pair_class = (uint8_t *)(a.pair_wave0 + pairs_all + 1);
+	a.pair_bsum = a.pair_wave0 + pairs_all + 1;
+	a.pair_class = (uint8_t *)(a.pair_bsum + pairs_all / 1024 + 2);
 	{
 		const char *f = getenv("ANDI_SEG_FACTOR");
 		a.seg_factor = f && atoi(f) > 0 ? (uint32_t)atoi(f) : 16u; // measured best of 8/16/32 with seg0 = 2048
@@ -771,6 +779,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		t.stop();
 		if (e != hipSuccess) return fail(ctx, "scan passes B/C", e);
 	}
+	(adaptive ? ctx->acc.adaptive_calls : ctx->acc.uniform_calls)++;
 	ctx->acc.scan_pairs += pairs;
 	ctx->acc.scan_query_nt += nt;
 	return 0;

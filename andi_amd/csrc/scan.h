@@ -65,6 +65,7 @@ struct ScanArgs {
 	uint8_t *pair_class;
 	uint32_t *pair_waves; // scratch: wavefronts per pair
 	uint32_t *pair_wave0;
+	uint32_t *pair_bsum;  // scratch: sums / offsets of 1024 pairs each
 	uint32_t max_waves;   // upper bound (every pair in class 0): the grid
 	int group;         // otherwise: lanes per chain of scan.hip's kernels (2, 4, 8)
 	uint32_t max_passes; // scan_rounds.hip: trips of the compute loop per round

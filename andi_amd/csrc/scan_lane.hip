@@ -335,27 +335,48 @@ __global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
 	}
 }
 
-// step 2: exclusive prefix sums of the pairs' wavefront counts (one block)
+// step 2: exclusive prefix sums of the pairs' wavefront counts, any number of pairs: sums of
+// 1024 pairs per block, a scan of those sums by one block, the scan inside every block
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *s_part) { // inclusive, 1024 threads
+	s_part[threadIdx.x] = v;
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele
+		const uint32_t o = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+		__syncthreads();
+		s_part[threadIdx.x] += o;
+		__syncthreads();
+	}
+	return s_part[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void k_pair_block_sums(ScanArgs a) {
+	__shared__ uint32_t s_part[1024];
+	const uint32_t P = a.nsub * a.nq, i = blockIdx.x * 1024 + threadIdx.x;
+	const uint32_t incl = block_scan_1024(i < P ? a.pair_waves[i] : 0u, s_part);
+	if (threadIdx.x == 1023) a.pair_bsum[blockIdx.x] = incl;
+}
+
+__global__ __launch_bounds__(1024) void k_pair_block_offsets(ScanArgs a) { // one block: exclusive scan of the block sums, in place
+	__shared__ uint32_t s_part[1024];
+	const uint32_t P = a.nsub * a.nq, nb = (P + 1023) / 1024, per = (nb + 1023) / 1024;
+	const uint32_t first = threadIdx.x * per, last = first + per < nb ? first + per : nb;
+	uint32_t sum = 0;
+	for (uint32_t i = first; i < last; ++i) sum += a.pair_bsum[i];
+	uint32_t run = block_scan_1024(sum, s_part) - sum;
+	for (uint32_t i = first; i < last; ++i) {
+		const uint32_t v = a.pair_bsum[i];
+		a.pair_bsum[i] = run;
+		run += v;
+	}
+	if (threadIdx.x == 1023) a.pair_wave0[P] = s_part[1023]; // wavefronts in use
+}
+
 __global__ __launch_bounds__(1024) void k_pair_offsets(ScanArgs a) {
 	__shared__ uint32_t s_part[1024];
-	const uint32_t P = a.nsub * a.nq, per = (P + 1023) / 1024;
-	const uint32_t first = threadIdx.x * per, last = first + per < P ? first + per : P;
-	uint32_t sum = 0;
-	for (uint32_t i = first; i < last; ++i) sum += a.pair_waves[i];
-	s_part[threadIdx.x] = sum;
-	__syncthreads();
-	for (uint32_t d = 1; d < 1024; d <<= 1) { // Hillis-Steele, inclusive
-		uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
-		__syncthreads();
-		s_part[threadIdx.x] += v;
-		__syncthreads();
-	}
-	uint32_t run = s_part[threadIdx.x] - sum;
-	for (uint32_t i = first; i < last; ++i) {
-		a.pair_wave0[i] = run;
-		run += a.pair_waves[i];
-	}
-	if (threadIdx.x == 1023) a.pair_wave0[P] = s_part[1023];
+	const uint32_t P = a.nsub * a.nq, i = blockIdx.x * 1024 + threadIdx.x;
+	const uint32_t v = i < P ? a.pair_waves[i] : 0u;
+	const uint32_t incl = block_scan_1024(v, s_part);
+	if (i < P) a.pair_wave0[i] = a.pair_bsum[blockIdx.x] + incl - v;
 }
 
 // ------------------------------------------------------------------ pass A
@@ -597,7 +618,12 @@ hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
 	const uint32_t P = a.nsub * a.nq;
 	k_pair_estimate<<<(P + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
-	k_pair_offsets<<<1, 1024, 0, st>>>(a);
+	const unsigned nb = (P + 1023) / 1024;
+	k_pair_block_sums<<<nb, 1024, 0, st>>>(a);
+	CHECK_LAUNCH();
+	k_pair_block_offsets<<<1, 1024, 0, st>>>(a);
+	CHECK_LAUNCH();
+	k_pair_offsets<<<nb, 1024, 0, st>>>(a);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }

@@ -60,6 +60,8 @@ class Timings(C.Structure):
         ("scan_pairs", C.c_uint64),
         ("fixups", C.c_uint64),
         ("reference_subjects", C.c_uint64),
+        ("adaptive_calls", C.c_uint64),
+        ("uniform_calls", C.c_uint64),
     ]
 
 

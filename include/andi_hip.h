@@ -178,7 +178,7 @@ int andi_hip_copy_to_host(andi_hip_ctx *ctx, void *dst_host, const void *src_dev
 /* Kernel timing, measured with HIP events on the stream the kernels run on.
  * Accumulates since the last reset; read after andi_hip_sync(). */
 typedef struct {
-	double build_ms;      /* K1-K4 */
+	double build_ms;      /* index builds: the scan index (andi_hip_esa_build_index), the reference arrays K1-K4 (andi_hip_esa_build) */
 	uint64_t build_launches;
 	double scan_ms;       /* anchor scan pass A (the dominant kernel) */
 	uint64_t scan_launches;
@@ -188,6 +188,8 @@ typedef struct {
 	uint64_t scan_pairs;
 	uint64_t fixups;      /* segments whose speculative entry state was wrong */
 	uint64_t reference_subjects; /* subjects scanned with the reference walk */
+	uint64_t adaptive_calls; /* scan calls that chose the segment length per pair */
+	uint64_t uniform_calls;  /* ... one segment length for the call */
 } andi_hip_timings;
 int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t);
 void andi_hip_timings_reset(andi_hip_ctx *ctx);

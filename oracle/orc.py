@@ -212,6 +212,18 @@ def dist_matrix(seqs, p_value=0.025, model=M_JC, threads=0, times=False):
     return (M, (t[0], t[1])) if times else M
 
 
+def scan_row(esa, seqs, self_idx=-1, model=M_JC, threads=0):
+    """dist_anchor of every sequence against one prepared subject (row of the matrix): (n, 17) uint32."""
+    L = lib()
+    n = len(seqs)
+    arr = (C.c_char_p * n)(*seqs)
+    lens = (C.c_size_t * n)(*[len(s) for s in seqs])
+    row = np.zeros((n, 17), dtype=np.uint32)
+    L.orc_scan_row(row.ctypes.data, C.byref(esa.esa), esa.threshold, arr, lens, n,
+                   n if self_idx < 0 else self_idx, model, threads)
+    return row
+
+
 def estimate(counts17, model=M_JC):
     m = Model()
     for k in range(16):

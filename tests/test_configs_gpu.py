@@ -1,0 +1,173 @@
+"""BASELINE.json's configs 2-4 (C3, C4, C5 of SURVEY.md §8) on the device: the shapes that make them
+different from the bench set -- many pairs per scan call, Kimura, full genome lengths, a 10^8-character
+index, 99 bootstrap replicates of a 256 x 256 matrix -- each against the oracle where the oracle finishes
+in seconds, and through size-independent properties at full size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _star_set(n, length, d_lo, d_hi, seed, ragged=0.0):
+    """n genomes from one base (andi_amd/synth.py); with ragged > 0 their lengths differ by up to that fraction."""
+    from andi_amd import synth
+    base = synth.base_codes(length, seed)
+    rng = np.random.default_rng(seed ^ 0xC4)
+    ds = rng.uniform(d_lo, d_hi, n)
+    out = []
+    for k in range(n):
+        codes = synth.mutate_codes(base, float(ds[k]), seed + 1 + k)
+        if ragged:
+            cut = int(length * (1.0 - ragged * rng.random()))
+            codes = codes[:cut]
+        out.append(synth.to_bytes(codes))
+    return out
+
+
+# ------------------------------------------------------------------ C4: 3085 genomes, ~2 Mbp
+def test_c4_shape_3085_queries_per_row(ctx, orc, monkeypatch):
+    """A scan call of the C4 shape: 8 subject rows x 3085 queries = 24 680 pairs (more than one block of the
+    pair layout handles), short genomes so that the oracle finishes: uniform and per-pair segment lengths."""
+    import andi_amd
+    seqs = _star_set(3085, 20000, 0.001, 0.015, seed=3085, ragged=0.3)
+    subjects = [0, 1, 700, 1542, 1543, 2900, 3083, 3084]
+    want = np.stack([orc.scan_row(orc.OracleEsa(seqs[i]), seqs, i, orc.M_JC, threads=0) for i in subjects])
+    Q = andi_amd.Queries(ctx, seqs)
+    esas = [andi_amd.Esa(ctx, seqs[i]) for i in subjects]
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("ANDI_FORCE_ADAPTIVE", "1")  # whole wavefronts per pair although the queries are short
+        ctx.timings_reset()
+        got = andi_amd.scan_rows(ctx, esas, subjects, Q)
+        t = ctx.timings()
+        assert (t["adaptive_calls"], t["uniform_calls"]) == ((1, 0) if force else (0, 1))
+        assert t["scan_pairs"] == 8 * 3084
+        bad = np.argwhere((got != want).any(axis=2))
+        assert len(bad) == 0, (force, bad[:5])
+    for e in esas:
+        e.close()
+    Q.close()
+
+
+def test_c4_full_length_rows_choose_segments_per_pair(ctx, orc):
+    """Full C4 genome length (2.1 Mbp): rows of 40 queries -- the layout with per-pair segment lengths is in
+    use -- against the oracle for a sample of the pairs, and the one-call seam on three of the genomes."""
+    import andi_amd
+    n = 2_100_000
+    seqs = _star_set(40, n, 0.001, 0.015, seed=404)
+    subjects = [0, 17, 39]
+    Q = andi_amd.Queries(ctx, seqs)
+    esas = [andi_amd.Esa(ctx, seqs[i]) for i in subjects]
+    ctx.timings_reset()
+    got = andi_amd.scan_rows(ctx, esas, subjects, Q)
+    t = ctx.timings()
+    assert t["adaptive_calls"] == 1 and t["fixups"] == 0
+    assert (got[:, :, 16][got[:, :, 16] != 9] == n).all()
+    cov = got[:, :, :16].sum(axis=2) / n
+    assert (cov[got[:, :, 16] == n] > 0.9).all() and (cov <= 1.0).all()
+    O = orc.OracleEsa(seqs[17], sa=esas[1].SA)  # the oracle's own arrays on the product's suffix array
+    for j in (0, 5, 16, 18, 39):
+        assert (got[1, j] == O.dist_anchor(seqs[j])).all(), j
+    assert got[1, 17, 0] == 9 and got[1, 17, 16] == 9
+    for e in esas:
+        e.close()
+    Q.close()
+    three = [seqs[0], seqs[17], seqs[39]]
+    M = andi_amd.dist_matrix(three, host_threads=3)
+    assert (M[1, 0] == got[1, 0]).all() and (M[1, 2] == got[1, 39]).all() and (M[0, 1] == got[0, 17]).all()
+
+
+# ------------------------------------------------------------------ C3: 109 genomes, Kimura
+def test_c3_kimura_109_genomes_one_call(orc):
+    """109 genomes (short), Kimura, through the seam andi_hip_dist_matrix (14 batches of subject slots):
+    counts bit-exact, Kimura distances equal to the oracle's within 1e-9 (they come from the same integers)."""
+    import andi_amd
+    seqs = _star_set(109, 30000, 1e-4, 5e-3, seed=109)
+    M = andi_amd.dist_matrix(seqs, model=andi_amd.M_KIMURA, host_threads=8)
+    want = orc.dist_matrix(seqs, model=orc.M_KIMURA, threads=0)
+    assert (M == want).all()
+    for i, j in ((0, 1), (5, 77), (108, 3), (54, 55)):
+        pair = M[i, j].astype(np.uint64) + M[j, i]
+        pair = np.minimum(pair, 0xFFFFFFFF).astype(np.uint32)
+        d_gpu, d_cpu = andi_amd.estimate(pair, andi_amd.M_KIMURA), orc.estimate(pair, orc.M_KIMURA)
+        assert abs(d_gpu - d_cpu) <= 1e-9 and 0 < d_gpu < 0.02
+
+
+def test_c3_full_length_pair_kimura(ctx, orc):
+    """One ordered pair at C3's genome length (5.1 Mbp), Kimura: equal to the sequential oracle."""
+    import andi_amd
+    from andi_amd import synth
+    n = 5_100_000
+    base = synth.base_codes(n, 131)
+    a = synth.to_bytes(synth.mutate_codes(base, 0.0004, 1))
+    b = synth.to_bytes(synth.mutate_codes(base, 0.004, 2))
+    Q = andi_amd.Queries(ctx, [a, b])
+    E = andi_amd.Esa(ctx, a)
+    got = andi_amd.scan_rows(ctx, [E], [0], Q, andi_amd.M_KIMURA)
+    O = orc.OracleEsa(a, sa=E.SA)
+    assert (got[0, 1] == O.dist_anchor(b, model=orc.M_KIMURA)).all()
+    d = andi_amd.estimate(got[0, 1], andi_amd.M_KIMURA)
+    assert abs(d - 0.0044) < 0.0004
+    E.close()
+    Q.close()
+
+
+# ------------------------------------------------------------------ C5: 50 Mbp genomes, bootstrap
+def test_c5_index_of_1e8_characters(ctx, orc):
+    """A 50 Mbp subject: n = 10^8 + 1 characters, the probe table's depth clamps at 13 (4^13 < n), 1.1 GB of
+    scan index.  One ordered pair against the oracle (which reuses the product's suffix array) and the
+    independence of the segmentation."""
+    import andi_amd
+    from andi_amd import synth
+    L = 50_000_000
+    base = synth.base_codes(L, 11)
+    a = synth.to_bytes(synth.mutate_codes(base, 0.002, 1))
+    b = synth.to_bytes(synth.mutate_codes(base, 0.03, 2))
+    del base
+    Q = andi_amd.Queries(ctx, [a, b])
+    E = andi_amd.Esa(ctx, a)
+    assert E.n == 2 * L + 1 and E.nbytes() > 1.1e9  # text, suffix array, 4^13 table entries, packed text twice
+    got = andi_amd.scan_rows(ctx, [E], [0], Q)
+    got2 = andi_amd.scan_rows(ctx, [E], [0], Q, segment=1 << 16)
+    assert (got == got2).all()
+    O = orc.OracleEsa(a, sa=E.SA)
+    assert O.threshold == E.threshold
+    want = O.dist_anchor(b)
+    assert (got[0, 1] == want).all()
+    assert got[0, 1, 16] == L and abs(andi_amd.estimate(got[0, 1]) - 0.032) < 0.002
+    E.close()
+    Q.close()
+
+
+def test_c5_bootstrap_99_replicates_of_256(ctx):
+    """andi_hip_bootstrap at C5's size: 99 replicates of a 256 x 256 matrix in one launch.  The reference seeds
+    GSL from the clock (src/andi.c:272-279), so the draws cannot be compared: totals are preserved
+    (src/model.c:222-232), matrices are mirrored with the {1, .., 1} diagonal (src/process.c:289-321), the
+    draws are deterministic in the seed and centred on the point estimate."""
+    import andi_amd
+    n, reps = 256, 99
+    rng = np.random.default_rng(256)
+    M = np.zeros((n, n, 17), np.uint32)
+    total = rng.integers(200_000, 2_000_000, (n, n))
+    dist = rng.uniform(0.001, 0.05, (n, n))
+    for t in range(16):
+        same = t % 5 == 0
+        M[:, :, t] = (total * ((1 - dist) / 4 if same else dist / 12)).astype(np.uint32)
+    M[:, :, 16] = (total * 1.1).astype(np.uint32)
+    B = andi_amd.bootstrap(ctx, M, reps, seed=1729)
+    assert B.shape == (reps, n, n, 17)
+    iu = np.triu_indices(n, 1)
+    pair = M[iu[0], iu[1], :16].astype(np.uint64) + M[iu[1], iu[0], :16]
+    for r in (0, 49, 98):
+        up = B[r, iu[0], iu[1]]
+        assert (up == B[r, iu[1], iu[0]]).all()  # mirrored
+        assert (up[:, :16].sum(axis=1) == pair.sum(axis=1)).all()  # the multinomial keeps the total
+        d = np.arange(n)
+        assert (B[r, d, d, 0] == 1).all() and (B[r, d, d, 16] == 1).all()
+    # centred on the point estimate: substitutions of all replicates of a pair
+    sub = lambda c: c.sum(axis=-1) - c[..., 0] - c[..., 5] - c[..., 10] - c[..., 15]
+    mean = sub(B[:, iu[0], iu[1], :16].astype(np.float64)).mean(axis=0)
+    exp = sub(pair.astype(np.float64))
+    assert np.abs(mean / exp - 1).max() < 0.05
+    assert (B == andi_amd.bootstrap(ctx, M, reps, seed=1729)).all()
+    assert (B[0] != andi_amd.bootstrap(ctx, M, 1, seed=1730)[0]).any()
