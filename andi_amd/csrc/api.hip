@@ -2,6 +2,8 @@
 // staging, kernel orchestration and the one-call replacement of
 // distMatrix/distMatrixLM (src/dist_hack.h:34-96).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types only: librccl is loaded on demand (dlopen), see rccl() below
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -215,6 +217,13 @@ void andi_hip_default_opts(andi_hip_opts *o) {
 	o->host_threads = 0;
 	o->low_memory = 0;
 	o->segment = 0;
+	o->num_gpus = 1;
+	o->devices = NULL;
+}
+
+int andi_hip_device_count(void) {
+	int count = 0;
+	return hipGetDeviceCount(&count) == hipSuccess && count > 0 ? count : 0;
 }
 
 int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errlen) {
@@ -828,11 +837,22 @@ void andi_hip_timings_reset(andi_hip_ctx *ctx) {
 	ctx->acc = andi_hip_timings{};
 }
 
+} // extern "C"
+
 // ------------------------------------------------------------------ the seam
 // distMatrix / distMatrixLM, src/dist_hack.h:34-96: for every subject build the
-// index and compare every other sequence against it.  Host threads prepare RS
-// and the suffix array (seq_subject_init + esa_init_SA); the calling thread
-// feeds the device in subject order.
+// index and compare every other sequence against it.
+//
+// The rows of the matrix (one subject against every query) are independent given
+// the subject's index.  Every device of the call owns a contiguous block of rows
+// (block sizes differ by at most one) and is driven by one host thread with its own
+// context: all queries staged once, a set of subject slots reused batch after batch,
+// its rows kept in HBM.  A pool of host threads shared by all devices prepares RS and
+// the suffix array (seq_subject_init + esa_init_SA) in the order the devices will
+// ask for them.  The one exchange of the job is the gather of the row blocks on the
+// first device -- RCCL send/recv over xGMI, every peer on its own link -- followed by
+// one copy of the matrix to the host.  (One device, several contexts on one device,
+// or no usable RCCL: every block is copied to the host matrix directly.)
 namespace {
 struct Prepared {
 	size_t idx = 0;
@@ -841,7 +861,55 @@ struct Prepared {
 	std::vector<int32_t> SA;
 	int rc = 0;
 };
+
+// librccl is loaded when a call first spans several devices: single-device users (and processes
+// that carry another copy of RCCL, like PyTorch's) never touch it
+struct Rccl {
+	void *lib = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+	bool ok = false;
+};
+
+Rccl &rccl() {
+	static Rccl r;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+		for (const char *nm : names)
+			if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!r.lib) return;
+		r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+		r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+		r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+		r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+		r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
+		r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
+		r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+		r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.GetErrorString;
+	});
+	return r;
+}
+
+char g_last_gather[200] = "none"; // how the last andi_hip_dist_matrix call collected its rows (diagnostic)
+
+void row_block(size_t total, size_t parts, size_t k, size_t &first, size_t &last) { // as andi_amd/shard.py: row_block
+	const size_t base = total / parts, extra = total % parts;
+	first = k * base + std::min(k, extra);
+	last = first + base + (k < extra ? 1 : 0);
+}
 } // namespace
+
+extern "C" {
+
+const char *andi_hip_last_gather(void) {
+	return g_last_gather;
+}
 
 int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 						 const andi_hip_opts *opts_in, char *errbuf, size_t errlen) {
@@ -867,70 +935,112 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		}
 	}
 
-	andi_hip_ctx *ctx = nullptr;
-	if (andi_hip_ctx_create(&ctx, o.device, errbuf, errlen)) return 1;
-	andi_hip_queries *Q = nullptr;
-	andi_hip_model *d_rows = nullptr;
-	int rc = 0;
-	auto bail = [&](const char *what) {
-		set_err(errbuf, errlen, "%s: %s", what, andi_hip_last_error(ctx));
-		rc = 1;
-	};
+	// ---- the devices of the call
+	std::vector<int> devs;
+	{
+		int visible = 0;
+		hipError_t e = hipGetDeviceCount(&visible);
+		if (e != hipSuccess || visible <= 0) {
+			set_err(errbuf, errlen, "no HIP device available (%s); the anchor-distance engine has no CPU path",
+					e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+			return 1;
+		}
+		if (o.devices && o.num_gpus > 0) {
+			devs.assign(o.devices, o.devices + o.num_gpus);
+		} else {
+			const int want = o.num_gpus < 0 ? visible - o.device : (o.num_gpus == 0 ? 1 : o.num_gpus);
+			for (int k = 0; k < want; ++k) devs.push_back(o.device + k);
+		}
+		for (int d : devs)
+			if (d < 0 || d >= visible) {
+				set_err(errbuf, errlen, "HIP device %d out of range (have %d)", d, visible);
+				return 1;
+			}
+		if (devs.empty()) {
+			set_err(errbuf, errlen, "andi_hip_dist_matrix: no device selected");
+			return 1;
+		}
+		if (devs.size() > n) devs.resize(n); // at least one row each
+	}
+	const size_t ndev = devs.size();
+	bool distinct = true;
+	for (size_t a = 0; a < ndev; ++a)
+		for (size_t b = a + 1; b < ndev; ++b) distinct = distinct && devs[a] != devs[b];
+	const char *gather_env = getenv("ANDI_GATHER");
+	// RCCL gather: several distinct devices (or forced, to exercise the path on one device), and the matrix fits next to the rest
+	bool use_rccl = (ndev > 1 && distinct && !(gather_env && !strcmp(gather_env, "direct"))) ||
+					(distinct && gather_env && !strcmp(gather_env, "rccl"));
+	if (use_rccl && n * n * sizeof(andi_hip_model) > ((size_t)32 << 30)) use_rccl = false;
+	if (use_rccl && !rccl().ok) use_rccl = false;
 
-	// Subject slots: device buffers sized for the longest genome, reused batch
-	// after batch (no allocation inside the loop).  Several subjects per scan call
-	// keep the GPU filled; low_memory keeps one index resident at a time, which is
-	// what distMatrixLM trades (src/dist_hack.h:14-16).
+	// ---- shared host pool: subject preparation + suffix sorting (the role of the OpenMP
+	// subject loop, src/dist_hack.h:46-52), in the order the devices consume, bounded look-ahead
 	size_t longest = 0;
 	for (size_t i = 0; i < n; ++i) longest = std::max(longest, seqs[i].len);
 	const size_t rs_cap = 2 * longest + 1;
-	size_t batch = o.low_memory ? 1 : 8;
-	{
-		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-			const size_t per_slot = 10 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap))) + (1 << 20);
-			while (batch > 1 && batch * per_slot > free_b / 2) batch /= 2;
-		}
+	std::vector<size_t> first(ndev), last(ndev);
+	size_t max_rows = 0;
+	for (size_t d = 0; d < ndev; ++d) {
+		row_block(n, ndev, d, first[d], last[d]);
+		max_rows = std::max(max_rows, last[d] - first[d]);
 	}
-	if (batch > n) batch = n;
-	std::vector<andi_hip_esa *> slots(batch, nullptr);
+	std::vector<size_t> order; // subjects in the order they are needed
+	order.reserve(n);
+	for (size_t k = 0; k < max_rows; ++k)
+		for (size_t d = 0; d < ndev; ++d)
+			if (first[d] + k < last[d]) order.push_back(first[d] + k);
 
-	if (andi_hip_queries_stage(ctx, seqs, n, &Q)) bail("staging queries");
-	for (size_t b = 0; b < batch && !rc; ++b)
-		if (esa_reserve(ctx, rs_cap, &slots[b])) bail("allocating subject slots");
-	if (!rc && andi_hip_dev_alloc(ctx, batch * n * sizeof(andi_hip_model), (void **)&d_rows)) bail("row buffer");
-
-	// host pool: subject preparation + suffix sorting (the role of the OpenMP
-	// subject loop, src/dist_hack.h:46-52), bounded look-ahead
 	int threads = o.host_threads > 0 ? o.host_threads : (int)std::thread::hardware_concurrency();
 	if (threads < 1) threads = 1;
 	if ((size_t)threads > n) threads = (int)n;
-	const size_t window = (size_t)threads + batch + 1;
+	const size_t batch_max = o.low_memory ? 1 : 8;
+	const size_t window = (size_t)threads + ndev * batch_max + 1;
 
 	std::mutex mu;
 	std::condition_variable cv;
 	std::deque<Prepared *> ready; // any order
 	std::atomic<size_t> next{0};
-	size_t consumed = 0; // guarded by mu
+	size_t consumed = 0; // subjects taken by the devices, guarded by mu
 	bool abort_flag = false;
+	std::string first_error;
+	size_t rows_done = 0; // guarded by mu (progress)
+
+	auto fail_all = [&](const std::string &msg) {
+		std::lock_guard<std::mutex> lk(mu);
+		if (!abort_flag) first_error = msg;
+		abort_flag = true;
+		cv.notify_all();
+	};
 
 	auto worker = [&]() {
 		for (;;) {
-			size_t i = next.fetch_add(1);
-			if (i >= n) return;
+			const size_t pos = next.fetch_add(1);
+			if (pos >= n) return;
 			{
 				std::unique_lock<std::mutex> lk(mu);
-				cv.wait(lk, [&] { return abort_flag || i < consumed + window; });
+				cv.wait(lk, [&] { return abort_flag || pos < consumed + window; });
 				if (abort_flag) return;
 			}
-			auto *p = new Prepared;
-			p->idx = i;
-			double gc;
-			p->rc = andi_hip_subject_prepare(seqs[i].seq, seqs[i].len, o.p_value, &p->RS, &p->n, &gc,
-											 &p->thr);
-			if (!p->rc) {
-				p->SA.resize(p->n);
-				p->rc = andi_hip_suffix_array((const unsigned char *)p->RS, p->SA.data(), (int32_t)p->n);
+			const size_t i = order[pos];
+			Prepared *p = nullptr;
+			try {
+				p = new Prepared;
+				p->idx = i;
+				double gc;
+				p->rc = andi_hip_subject_prepare(seqs[i].seq, seqs[i].len, o.p_value, &p->RS, &p->n, &gc, &p->thr);
+				if (!p->rc) {
+					p->SA.resize(p->n);
+					p->rc = andi_hip_suffix_array((const unsigned char *)p->RS, p->SA.data(), (int32_t)p->n);
+				}
+			} catch (...) { // out of memory: report it as the reference does (src/dist_hack.h:53)
+				if (p) {
+					andi_hip_free(p->RS);
+					delete p;
+				}
+				char msg[96];
+				snprintf(msg, sizeof msg, "Failed to create index for sequence %zu.", i);
+				fail_all(msg);
+				return;
 			}
 			{
 				std::lock_guard<std::mutex> lk(mu);
@@ -939,18 +1049,17 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			cv.notify_all();
 		}
 	};
-	std::vector<std::thread> pool;
-	if (!rc)
-		for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
 
-	auto take = [&](size_t i) { // blocks until subject i is prepared
-		Prepared *p = nullptr;
+	auto take = [&](size_t i) -> Prepared * { // blocks until subject i is prepared; null if the call was aborted
 		std::unique_lock<std::mutex> lk(mu);
+		Prepared *p = nullptr;
 		cv.wait(lk, [&] {
+			if (abort_flag) return true;
 			for (auto *c : ready)
 				if (c->idx == i) return true;
 			return false;
 		});
+		if (abort_flag) return nullptr;
 		for (auto it = ready.begin(); it != ready.end(); ++it)
 			if ((*it)->idx == i) {
 				p = *it;
@@ -960,34 +1069,92 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		return p;
 	};
 
-	std::vector<int64_t> self(batch);
-	for (size_t i0 = 0; i0 < n && !rc; i0 += batch) {
-		const size_t nb = std::min(batch, n - i0);
-		for (size_t b = 0; b < nb && !rc; ++b) {
-			Prepared *p = take(i0 + b);
-			if (p->rc) {
-				set_err(errbuf, errlen, "Failed to create index for sequence %zu.", i0 + b); // src/dist_hack.h:53
-				rc = 1;
+	// ---- one driver per device
+	struct Dev {
+		andi_hip_ctx *ctx = nullptr;
+		andi_hip_queries *Q = nullptr;
+		andi_hip_model *d_rows = nullptr; // rccl: the whole row block; direct: one batch of rows
+		std::vector<andi_hip_esa *> slots;
+	};
+	std::vector<Dev> dv(ndev);
+
+	auto drive = [&](size_t d) {
+		Dev &D = dv[d];
+		char eb[256] = "";
+		auto bail = [&](const char *what) {
+			char msg[512];
+			snprintf(msg, sizeof msg, "%s (device %d): %s", what, devs[d], D.ctx ? andi_hip_last_error(D.ctx) : eb);
+			fail_all(msg);
+		};
+		if (andi_hip_ctx_create(&D.ctx, devs[d], eb, sizeof eb)) return bail("creating a context");
+		const size_t rows = last[d] - first[d];
+		// Subject slots: device buffers sized for the longest genome, reused batch after batch (no
+		// allocation inside the loop).  Several subjects per scan call keep the GPU filled; low_memory
+		// keeps one index resident at a time, which is what distMatrixLM trades (src/dist_hack.h:14-16).
+		size_t batch = batch_max;
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+				const size_t per_slot = 10 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap))) + (1 << 20);
+				while (batch > 1 && batch * per_slot > free_b / (2 * ndev)) batch /= 2;
 			}
-			if (!rc && esa_upload(ctx, slots[b], p->RS, p->SA.data(), p->n, p->thr)) bail("staging subject");
-			if (!rc && andi_hip_esa_build_index(ctx, slots[b])) bail("index build");
-			self[b] = (int64_t)(i0 + b);
-			andi_hip_free(p->RS);
-			delete p;
-			{
-				std::lock_guard<std::mutex> lk(mu);
-				consumed = i0 + b + 1;
-			}
-			cv.notify_all();
 		}
-		if (!rc && andi_hip_scan_rows(ctx, slots.data(), self.data(), nb, Q, o.model, o.segment, d_rows)) bail("scan");
-		if (!rc && andi_hip_copy_to_host(ctx, M + i0 * n, d_rows, nb * n * sizeof(andi_hip_model))) bail("row copy");
-		if (!rc && o.progress) o.progress((i0 + nb) * (n - 1), n * n - n, o.ud);
+		if (batch > rows) batch = rows;
+		D.slots.assign(batch, nullptr);
+		if (andi_hip_queries_stage(D.ctx, seqs, n, &D.Q)) return bail("staging queries");
+		for (size_t b = 0; b < batch; ++b)
+			if (esa_reserve(D.ctx, rs_cap, &D.slots[b])) return bail("allocating subject slots");
+		if (andi_hip_dev_alloc(D.ctx, (use_rccl ? rows : batch) * n * sizeof(andi_hip_model), (void **)&D.d_rows)) return bail("row buffer");
+
+		std::vector<int64_t> self(batch);
+		for (size_t i0 = first[d]; i0 < last[d]; i0 += batch) {
+			const size_t nb = std::min(batch, last[d] - i0);
+			for (size_t b = 0; b < nb; ++b) {
+				Prepared *p = take(i0 + b);
+				if (!p) return;
+				bool ok = true;
+				if (p->rc) {
+					char msg[96];
+					snprintf(msg, sizeof msg, "Failed to create index for sequence %zu.", i0 + b); // src/dist_hack.h:53
+					fail_all(msg);
+					ok = false;
+				}
+				if (ok && esa_upload(D.ctx, D.slots[b], p->RS, p->SA.data(), p->n, p->thr)) bail("staging subject"), ok = false;
+				if (ok && andi_hip_esa_build_index(D.ctx, D.slots[b])) bail("index build"), ok = false;
+				self[b] = (int64_t)(i0 + b);
+				andi_hip_free(p->RS);
+				delete p;
+				{
+					std::lock_guard<std::mutex> lk(mu);
+					++consumed;
+				}
+				cv.notify_all();
+				if (!ok) return;
+			}
+			andi_hip_model *dst = use_rccl ? D.d_rows + (i0 - first[d]) * n : D.d_rows;
+			if (andi_hip_scan_rows(D.ctx, D.slots.data(), self.data(), nb, D.Q, o.model, o.segment, dst)) return bail("scan");
+			if (!use_rccl && andi_hip_copy_to_host(D.ctx, M + i0 * n, dst, nb * n * sizeof(andi_hip_model))) return bail("row copy");
+			if (use_rccl && andi_hip_sync(D.ctx)) return bail("scan"); // the slots are reused by the next batch
+			if (o.progress) {
+				std::lock_guard<std::mutex> lk(mu);
+				rows_done += nb;
+				o.progress(rows_done * (n - 1), n * n - n, o.ud);
+			}
+		}
+	};
+
+	std::vector<std::thread> pool, drivers;
+	for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+	if (ndev == 1) {
+		drive(0); // the calling thread, as before
+	} else {
+		for (size_t d = 0; d < ndev; ++d) drivers.emplace_back(drive, d);
+		for (auto &t : drivers) t.join();
 	}
 	{
 		std::lock_guard<std::mutex> lk(mu);
-		abort_flag = abort_flag || rc;
 		consumed = n; // release any waiting worker
+		if (abort_flag) next.store(n);
 	}
 	cv.notify_all();
 	for (auto &t : pool) t.join();
@@ -995,11 +1162,73 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		andi_hip_free(p->RS);
 		delete p;
 	}
-	for (auto *e : slots)
-		if (e) andi_hip_esa_free(ctx, e);
-	if (d_rows) andi_hip_dev_free(ctx, d_rows);
-	if (Q) andi_hip_queries_free(ctx, Q);
-	andi_hip_ctx_destroy(ctx);
+	int rc = abort_flag ? 1 : 0;
+
+	// ---- the gather: row blocks to the first device over RCCL, one copy to the host
+	snprintf(g_last_gather, sizeof g_last_gather, "%s", use_rccl ? "rccl" : "direct");
+	if (!rc && use_rccl) {
+		Rccl &R = rccl();
+		std::vector<ncclComm_t> comms(ndev, nullptr);
+		andi_hip_model *d_full = nullptr;
+		std::string err;
+		auto nccl_ok = [&](ncclResult_t r, const char *what) {
+			if (r == ncclSuccess) return true;
+			if (err.empty()) err = std::string(what) + ": " + R.GetErrorString(r);
+			return false;
+		};
+		// one process, one node: the communicators bootstrap over the loopback interface unless the caller chose one
+		setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+		bool ok = nccl_ok(R.CommInitAll(comms.data(), (int)ndev, devs.data()), "ncclCommInitAll");
+		if (ok && hipSetDevice(devs[0]) != hipSuccess) ok = false, err = "hipSetDevice";
+		if (ok && hipMalloc((void **)&d_full, n * n * sizeof(andi_hip_model)) != hipSuccess) ok = false, err = "allocating the gathered matrix";
+		if (ok) {
+			ok = nccl_ok(R.GroupStart(), "ncclGroupStart");
+			for (size_t d = 1; d < ndev && ok; ++d) {
+				const size_t bytes = (last[d] - first[d]) * n * sizeof(andi_hip_model);
+				ok = nccl_ok(R.Send(dv[d].d_rows, bytes, ncclUint8, 0, comms[d], dv[d].ctx->stream), "ncclSend") &&
+					 nccl_ok(R.Recv(d_full + first[d] * n, bytes, ncclUint8, (int)d, comms[0], dv[0].ctx->stream), "ncclRecv");
+			}
+			if (!nccl_ok(R.GroupEnd(), "ncclGroupEnd")) ok = false;
+		}
+		if (ok) { // the first device's own block, then everything to the host
+			hipError_t e = hipSetDevice(devs[0]);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(d_full + first[0] * n, dv[0].d_rows, (last[0] - first[0]) * n * sizeof(andi_hip_model),
+								   hipMemcpyDeviceToDevice, dv[0].ctx->stream);
+			for (size_t d = 1; d < ndev && e == hipSuccess; ++d) {
+				e = hipSetDevice(devs[d]);
+				if (e == hipSuccess) e = hipStreamSynchronize(dv[d].ctx->stream);
+			}
+			if (e == hipSuccess) e = hipSetDevice(devs[0]);
+			if (e == hipSuccess) e = hipStreamSynchronize(dv[0].ctx->stream);
+			if (e == hipSuccess) e = hipMemcpy(M, d_full, n * n * sizeof(andi_hip_model), hipMemcpyDeviceToHost);
+			if (e != hipSuccess) ok = false, err = std::string("gathering the matrix: ") + hipGetErrorString(e);
+		}
+		for (auto cm : comms)
+			if (cm) (void)R.CommDestroy(cm);
+		if (d_full) {
+			(void)hipSetDevice(devs[0]);
+			(void)hipFree(d_full);
+		}
+		if (!ok) { // RCCL unusable on this box: the rows are still in HBM -- copy every block to the host directly
+			snprintf(g_last_gather, sizeof g_last_gather, "direct (rccl: %.160s)", err.c_str());
+			for (size_t d = 0; d < ndev && !rc; ++d)
+				if (andi_hip_copy_to_host(dv[d].ctx, M + first[d] * n, dv[d].d_rows, (last[d] - first[d]) * n * sizeof(andi_hip_model))) {
+					first_error = std::string("row copy: ") + andi_hip_last_error(dv[d].ctx);
+					rc = 1;
+				}
+		}
+	}
+	if (rc) set_err(errbuf, errlen, "%s", first_error.empty() ? "andi_hip_dist_matrix failed" : first_error.c_str());
+
+	for (auto &D : dv) {
+		if (!D.ctx) continue;
+		for (auto *e : D.slots)
+			if (e) andi_hip_esa_free(D.ctx, e);
+		if (D.d_rows) andi_hip_dev_free(D.ctx, D.d_rows);
+		if (D.Q) andi_hip_queries_free(D.ctx, D.Q);
+		andi_hip_ctx_destroy(D.ctx);
+	}
 	return rc;
 }
 

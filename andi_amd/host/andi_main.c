@@ -256,7 +256,13 @@ static void print_matrix(const andi_hip_model *M, const genome *g, size_t n, int
 	size_t cap = 64 + n * (300 + 16 * n), wcap = 4096 + n * n * 512;
 	char *out = xmalloc(cap), *wbuf = xmalloc(wcap);
 	int flags = 0;
-	andi_hip_format_distances(M, names, n, model, vv, truncate, warnings, out, cap, wbuf, wcap, &flags);
+	size_t need = andi_hip_format_distances(M, names, n, model, vv, truncate, warnings, out, cap, wbuf, wcap, &flags);
+	if (need >= cap) { /* long names: the call says how much it needs */
+		free(out);
+		cap = need + 1;
+		out = xmalloc(cap);
+		andi_hip_format_distances(M, names, n, model, vv, truncate, warnings, out, cap, wbuf, wcap, &flags);
+	}
 	for (char *line = strtok(wbuf, "\n"); line; line = strtok(NULL, "\n")) soft_warnx("%s", line);
 	fputs(out, stdout);
 	free(out);
@@ -281,6 +287,9 @@ int main(int argc, char *argv[]) {
 	andi_hip_default_opts(&opts);
 	long procs = sysconf(_SC_NPROCESSORS_ONLN);
 	opts.host_threads = procs > 0 ? (int)procs : 1;
+	/* the rows of the matrix are tiled over all visible GPUs (ANDI_HIP_GPUS=k: the first k) */
+	opts.num_gpus = -1;
+	if (getenv("ANDI_HIP_GPUS") && atoi(getenv("ANDI_HIP_GPUS")) > 0) opts.num_gpus = atoi(getenv("ANDI_HIP_GPUS"));
 	int verbose = 0, join = 0, truncate = 0;
 	unsigned long bootstrap = 0;
 	enum { P_AUTO, P_NEVER, P_ALWAYS } progress = P_AUTO;

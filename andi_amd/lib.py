@@ -45,6 +45,8 @@ class Opts(C.Structure):
         ("segment", C.c_uint32),
         ("progress", PROGRESS_FN),
         ("ud", C.c_void_p),
+        ("num_gpus", C.c_int),
+        ("devices", C.POINTER(C.c_int)),
     ]
 
 
@@ -71,6 +73,7 @@ SYMBOLS = {
     "andi_hip_default_opts": (None, [C.POINTER(Opts)]),
     "andi_hip_abi_version": (C.c_int, []),
     "andi_hip_dist_matrix": (C.c_int, [_P, C.POINTER(Seq), C.c_size_t, C.POINTER(Opts), C.c_char_p, C.c_size_t]),
+    "andi_hip_last_gather": (C.c_char_p, []),
     "andi_hip_subject_prepare": (C.c_int, [C.c_char_p, C.c_size_t, C.c_double, C.POINTER(_P),
                                             C.POINTER(C.c_size_t), C.POINTER(C.c_double),
                                             C.POINTER(C.c_size_t)]),
@@ -84,6 +87,7 @@ SYMBOLS = {
     "andi_hip_format_distances": (C.c_size_t, [_P, C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_int,
                                                C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_size_t,
                                                C.POINTER(C.c_int)]),
+    "andi_hip_device_count": (C.c_int, []),
     "andi_hip_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_size_t]),
     "andi_hip_ctx_destroy": (None, [_P]),
     "andi_hip_last_error": (C.c_char_p, [_P]),
@@ -192,12 +196,16 @@ def format_distances(M, names, model=M_JC, extra_verbose=False, truncate_names=F
     assert M.shape == (n, n, 17)
     cnames = (C.c_char_p * n)(*[s.encode() if isinstance(s, str) else s for s in names])
     cap = 64 + n * (64 + 16 * n)
-    out = C.create_string_buffer(cap)
     warn = C.create_string_buffer(1 << 20)
     flags = C.c_int()
-    L.andi_hip_format_distances(M.ctypes.data, cnames, n, model, int(extra_verbose), int(truncate_names),
-                                int(warnings), C.cast(out, _P), cap, C.cast(warn, _P), len(warn),
-                                C.byref(flags))
+    for _ in range(2):  # the call returns the bytes it needs: long names get a second, exact buffer
+        out = C.create_string_buffer(cap)
+        need = L.andi_hip_format_distances(M.ctypes.data, cnames, n, model, int(extra_verbose), int(truncate_names),
+                                           int(warnings), C.cast(out, _P), cap, C.cast(warn, _P), len(warn),
+                                           C.byref(flags))
+        if need < cap:
+            break
+        cap = need + 1
     return out.value.decode(), warn.value.decode(), flags.value
 
 
@@ -374,6 +382,14 @@ def scan_rows(ctx: Context, esas, selfs, queries: Queries, model=M_JC, segment=0
     return out
 
 
+def device_count():
+    return load().andi_hip_device_count()
+
+
+def last_gather():
+    return load().andi_hip_last_gather().decode()
+
+
 def bootstrap(ctx: Context, M, replicates, seed=0):
     """calculate_bootstrap (src/process.c:289): (replicates, n, n, 17) uint32."""
     M = np.ascontiguousarray(M, dtype=np.uint32)
@@ -384,8 +400,10 @@ def bootstrap(ctx: Context, M, replicates, seed=0):
     return B
 
 
-def dist_matrix(seqs, p_value=0.025, model=M_JC, device=0, host_threads=0, segment=0):
-    """distMatrix (src/dist_hack.h:34): n*n*17 uint32, row = subject."""
+def dist_matrix(seqs, p_value=0.025, model=M_JC, device=0, host_threads=0, segment=0, num_gpus=1, devices=None,
+                low_memory=False):
+    """distMatrix (src/dist_hack.h:34): n*n*17 uint32, row = subject.  num_gpus / devices: the rows are
+    tiled over several devices (or several contexts on one) behind the same call."""
     L = load()
     seqs = [bytes(s) for s in seqs]
     n = len(seqs)
@@ -393,6 +411,11 @@ def dist_matrix(seqs, p_value=0.025, model=M_JC, device=0, host_threads=0, segme
     o = Opts()
     L.andi_hip_default_opts(C.byref(o))
     o.p_value, o.model, o.device, o.host_threads, o.segment = p_value, model, device, host_threads, segment
+    o.low_memory = int(low_memory)
+    o.num_gpus = num_gpus
+    if devices is not None:
+        dl = (C.c_int * len(devices))(*devices)
+        o.devices, o.num_gpus = dl, len(devices)
     M = np.zeros((n, n, 17), np.uint32)
     err = C.create_string_buffer(512)
     if L.andi_hip_dist_matrix(M.ctypes.data, arr, n, C.byref(o), err, len(err)):

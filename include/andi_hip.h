@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ANDI_HIP_ABI_VERSION 1
+#define ANDI_HIP_ABI_VERSION 2
 
 /* enum in src/global.h:50 */
 enum { ANDI_M_RAW = 0, ANDI_M_JC = 1, ANDI_M_KIMURA = 2, ANDI_M_LOGDET = 3, ANDI_M_ANI = 4 };
@@ -56,12 +56,19 @@ typedef struct {
 typedef struct {
 	double p_value;
 	int model;
-	int device;        /* HIP device ordinal */
-	int host_threads;  /* <=0: all cores (suffix sorting pool) */
+	int device;        /* first HIP device ordinal */
+	int host_threads;  /* <=0: all cores (suffix sorting pool, shared by the devices) */
 	int low_memory;    /* bound the number of resident subject indexes */
 	uint32_t segment;  /* query nucleotides per scan work item; 0 = default */
-	void (*progress)(size_t done, size_t total, void *ud);
+	void (*progress)(size_t done, size_t total, void *ud); /* serialised; called from the devices' driver threads */
 	void *ud;
+	/* The N x N loop is tiled over the GPUs of the node by rows (the parallel loop of
+	 * src/dist_hack.h:46-47): num_gpus devices device, device + 1, ...; 0 or 1 = one device; < 0 = all
+	 * visible devices from `device` on.  Every device owns a contiguous block of subject rows; the row
+	 * blocks are gathered on the first device with RCCL (send/recv over xGMI) and copied to M once. */
+	int num_gpus;
+	const int *devices; /* optional: exactly these num_gpus ordinals (an ordinal may repeat: several contexts
+	                     * on one device, rows then go to M directly) */
 } andi_hip_opts;
 
 void andi_hip_default_opts(andi_hip_opts *o);
@@ -75,6 +82,8 @@ int andi_hip_abi_version(void);
 /* ------------------------------------------------------------------ */
 int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 						 const andi_hip_opts *opts, char *errbuf, size_t errlen);
+/* how the last call collected its rows: "rccl", "direct" (diagnostic; not thread-safe) */
+const char *andi_hip_last_gather(void);
 
 /* ------------------------------------------------------------------ */
 /* Host pieces of the path (stay on the host, same libm)               */
@@ -110,6 +119,7 @@ typedef struct andi_hip_ctx andi_hip_ctx;         /* device + streams + scratch 
 typedef struct andi_hip_esa andi_hip_esa;         /* one subject's esa_s (src/esa.h:42-59) in HBM */
 typedef struct andi_hip_queries andi_hip_queries; /* all query sequences in HBM */
 
+int andi_hip_device_count(void); /* visible HIP devices; 0 if none (or no usable runtime) */
 int andi_hip_ctx_create(andi_hip_ctx **ctx, int device, char *errbuf, size_t errlen);
 void andi_hip_ctx_destroy(andi_hip_ctx *ctx);
 const char *andi_hip_last_error(const andi_hip_ctx *ctx);

@@ -1,0 +1,75 @@
+"""The N x N loop tiled over several devices BEHIND the C-ABI (andi_hip_dist_matrix with opts.num_gpus /
+opts.devices; src/dist_hack.h:46-47 is the loop that is being tiled).  A box with one GPU can still run every
+piece of it: several driver threads and contexts on device 0 (rows go to the host matrix directly), and the
+RCCL gather forced for one device (communicator, grouped exchange, the copy of the gathered matrix)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _set():
+    from andi_amd import synth
+    base = synth.base_codes(60000, 77)
+    seqs = [synth.to_bytes(synth.mutate_codes(base, d, 90 + k)) for k, d in
+            enumerate((0.0, 0.001, 0.004, 0.01, 0.02, 0.03, 0.05, 0.08, 0.1, 0.002, 0.015))]
+    seqs.append(synth.unrelated(20000, 5))
+    return seqs
+
+
+def test_row_blocks_on_several_contexts_equal_one_call(orc):
+    import andi_amd
+    seqs = _set()
+    want = orc.dist_matrix(seqs, threads=0)
+    one = andi_amd.dist_matrix(seqs, host_threads=4)
+    assert (one == want).all() and andi_amd.lib.last_gather() == "direct"
+    for devices in ([0, 0], [0, 0, 0], [0] * 5, [0] * 12, [0] * 40):  # up to one row per context; more contexts than rows
+        got = andi_amd.dist_matrix(seqs, host_threads=4, devices=devices)
+        assert (got == want).all(), devices
+        assert andi_amd.lib.last_gather() == "direct"
+    got = andi_amd.dist_matrix(seqs, host_threads=2, devices=[0, 0, 0], low_memory=True, model=andi_amd.M_KIMURA)
+    assert (got == orc.dist_matrix(seqs, model=orc.M_KIMURA, threads=0)).all()
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import andi_amd
+from oracle import orc
+from test_multi_gpu import _set
+seqs = _set()
+want = orc.dist_matrix(seqs, threads=0)
+os.environ["ANDI_GATHER"] = "rccl"
+got = andi_amd.dist_matrix(seqs, host_threads=4, num_gpus=-1)
+assert (got == want).all()
+assert andi_amd.lib.last_gather() == "rccl", andi_amd.lib.last_gather()
+del os.environ["ANDI_GATHER"]
+if andi_amd.lib.device_count() > 1:  # several GPUs visible: the same call spans all of them
+    got = andi_amd.dist_matrix(seqs, host_threads=4, num_gpus=-1)
+    assert (got == want).all() and andi_amd.lib.last_gather() == "rccl", andi_amd.lib.last_gather()
+print("rccl gather ok on", andi_amd.lib.device_count(), "device(s)")
+"""
+
+
+def test_rccl_gather_path_on_one_device():
+    """ANDI_GATHER=rccl takes the multi-device route with the devices there are: rows stay in HBM, librccl is
+    loaded, a communicator per device is created, the (here empty) grouped send/recv runs, the gathered matrix is
+    copied once.  With several GPUs visible the same call spans all of them.  In a process of its own: the
+    library loads ROCm's librccl, which must not meet the copy of the ROCm runtime that PyTorch carries."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl gather ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_errors_come_back_through_errbuf():
+    import andi_amd
+    seqs = _set()[:3]
+    with pytest.raises(andi_amd.AndiHipError, match="out of range"):
+        andi_amd.dist_matrix(seqs, devices=[0, 99])
+    with pytest.raises(andi_amd.AndiHipError):
+        andi_amd.dist_matrix(seqs[:2] + [b""], devices=[0, 0])
