@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +23,7 @@
 #include "andi_hip.h"
 #include "bootstrap.h"
 #include "esa_build.h"
+#include "sa_device.h"
 #include "scan.h"
 
 // segment length when the caller passes 0: short enough that one scan launch has
@@ -57,6 +59,10 @@ struct andi_hip_ctx {
 	size_t desc_bytes = 0;
 	hipEvent_t desc_done = nullptr;
 	unsigned long long *d_fixups = nullptr;
+	// device suffix sorter: workspace, two pinned ints
+	void *sa_ws = nullptr;
+	size_t sa_ws_bytes = 0;
+	int32_t *sa_pinned = nullptr;
 	std::vector<EventPair> pending;
 	andi_hip_timings acc{};
 };
@@ -217,6 +223,7 @@ void andi_hip_default_opts(andi_hip_opts *o) {
 	o->host_threads = 0;
 	o->low_memory = 0;
 	o->segment = 0;
+	o->sa_on_host = 0;
 	o->num_gpus = 1;
 	o->devices = NULL;
 }
@@ -269,6 +276,8 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
 	if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
 	if (ctx->d_fixups) (void)hipFree(ctx->d_fixups);
+	if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
+	if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
 	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -356,10 +365,58 @@ static int esa_upload(andi_hip_ctx *ctx, andi_hip_esa *e, const char *RS, const 
 	memset(e->h_flags, 0, 4 * sizeof(int32_t));
 	if (err == hipSuccess) err = hipMemsetAsync(e->S + n, 0, 1 + ANDI_PAD, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(e->S, RS, n, hipMemcpyHostToDevice, ctx->stream);
-	if (err == hipSuccess)
+	if (err == hipSuccess && SA)
 		err = hipMemcpyAsync(e->SA, SA, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "uploading a subject", err);
+	return 0;
+}
+
+// esa_init_SA (src/esa.c:294-304) on the device: the text is in the slot, the suffix array is built there
+static int esa_sort_suffixes(andi_hip_ctx *ctx, andi_hip_esa *e) {
+	const size_t need = andi_sa_device_workspace(e->n);
+	if (ctx->sa_ws_bytes < need) {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
+		ctx->sa_ws = nullptr, ctx->sa_ws_bytes = 0;
+		HIP_TRY(ctx, hipMalloc(&ctx->sa_ws, need));
+		ctx->sa_ws_bytes = need;
+	}
+	if (!ctx->sa_pinned) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->sa_pinned, 2 * sizeof(int32_t), hipHostMallocDefault));
+	const auto t0 = std::chrono::steady_clock::now();
+	int rounds = 0;
+	hipError_t err = andi_sa_device(e->S, e->n, e->SA, ctx->sa_ws, ctx->sa_ws_bytes, ctx->sa_pinned, ctx->stream, &rounds);
+	if (err == hipErrorInvalidSymbol) {
+		ctx->err = "a subject holds a byte outside {A,C,G,T,!,;,#}";
+		return 1;
+	}
+	if (err != hipSuccess) return fail(ctx, "building the suffix array", err);
+	ctx->acc.sa_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	ctx->acc.sa_builds++;
+	ctx->acc.sa_rounds += (uint64_t)rounds;
+	return 0;
+}
+
+int andi_hip_esa_stage_text(andi_hip_ctx *ctx, const char *RS, size_t n, size_t threshold, andi_hip_esa **out) {
+	if (!ctx || !RS || !out || n == 0 || n >= (size_t)INT32_MAX) {
+		if (ctx) ctx->err = "andi_hip_esa_stage_text: bad arguments";
+		return 1;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	andi_hip_esa *e = nullptr;
+	if (esa_reserve(ctx, n, &e)) return 1;
+	if (esa_upload(ctx, e, RS, nullptr, n, threshold) || esa_sort_suffixes(ctx, e)) {
+		andi_hip_esa_free(ctx, e);
+		return 1;
+	}
+	*out = e;
+	return 0;
+}
+
+int andi_hip_esa_download_sa(andi_hip_ctx *ctx, const andi_hip_esa *e, int32_t *SA) {
+	if (!ctx || !e || !SA) return 1;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	HIP_TRY(ctx, hipMemcpy(SA, e->SA, (size_t)e->n * sizeof(int32_t), hipMemcpyDeviceToHost));
 	return 0;
 }
 
@@ -1028,7 +1085,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 				p->idx = i;
 				double gc;
 				p->rc = andi_hip_subject_prepare(seqs[i].seq, seqs[i].len, o.p_value, &p->RS, &p->n, &gc, &p->thr);
-				if (!p->rc) {
+				if (!p->rc && o.sa_on_host) {
 					p->SA.resize(p->n);
 					p->rc = andi_hip_suffix_array((const unsigned char *)p->RS, p->SA.data(), (int32_t)p->n);
 				}
@@ -1119,7 +1176,8 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 					fail_all(msg);
 					ok = false;
 				}
-				if (ok && esa_upload(D.ctx, D.slots[b], p->RS, p->SA.data(), p->n, p->thr)) bail("staging subject"), ok = false;
+				if (ok && esa_upload(D.ctx, D.slots[b], p->RS, o.sa_on_host ? p->SA.data() : nullptr, p->n, p->thr)) bail("staging subject"), ok = false;
+				if (ok && !o.sa_on_host && esa_sort_suffixes(D.ctx, D.slots[b])) bail("suffix array"), ok = false;
 				if (ok && andi_hip_esa_build_index(D.ctx, D.slots[b])) bail("index build"), ok = false;
 				self[b] = (int64_t)(i0 + b);
 				andi_hip_free(p->RS);

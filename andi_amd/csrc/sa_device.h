@@ -1,0 +1,13 @@
+// sa_device.h — suffix array construction on the device (sa_device.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// bytes of device workspace andi_sa_device needs for a text of n characters
+size_t andi_sa_device_workspace(int32_t n);
+// SA[0..n) of the text S[0..n) (device pointers; S readable 32 bytes past n, zeros there), bytes in unsigned
+// order -- what divsufsort() computes at src/esa.c:303.  h_pinned2: two ints of pinned host memory.  Synchronises
+// the stream once per round.  hipErrorInvalidSymbol: the text holds a byte outside {A C G T ! ; #}.
+hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *workspace, size_t workspace_bytes,
+						  int32_t *h_pinned2, hipStream_t st, int *rounds_out);

@@ -45,6 +45,7 @@ class Opts(C.Structure):
         ("segment", C.c_uint32),
         ("progress", PROGRESS_FN),
         ("ud", C.c_void_p),
+        ("sa_on_host", C.c_int),
         ("num_gpus", C.c_int),
         ("devices", C.POINTER(C.c_int)),
     ]
@@ -62,6 +63,9 @@ class Timings(C.Structure):
         ("scan_pairs", C.c_uint64),
         ("fixups", C.c_uint64),
         ("reference_subjects", C.c_uint64),
+        ("sa_ms", C.c_double),
+        ("sa_builds", C.c_uint64),
+        ("sa_rounds", C.c_uint64),
         ("adaptive_calls", C.c_uint64),
         ("uniform_calls", C.c_uint64),
     ]
@@ -93,6 +97,8 @@ SYMBOLS = {
     "andi_hip_last_error": (C.c_char_p, [_P]),
     "andi_hip_sync": (C.c_int, [_P]),
     "andi_hip_esa_stage": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
+    "andi_hip_esa_stage_text": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
+    "andi_hip_esa_download_sa": (C.c_int, [_P, _P, _P]),
     "andi_hip_esa_build": (C.c_int, [_P, _P]),
     "andi_hip_esa_build_index": (C.c_int, [_P, _P]),
     "andi_hip_esa_flags": (C.c_int, [_P, _P, _P]),
@@ -260,22 +266,36 @@ class Esa:
     arrays LCP, CLD, FVC, 10-mer table (build="reference")."""
 
     def __init__(self, ctx: Context, seq: bytes, p_value=0.025, sa=None, build="index", prepared=None):
+        """sa: None = suffix array by the host sorter; an int32 array = given; "device" = built on the device."""
         self.ctx = ctx
         if prepared is not None:  # (RS, gc, threshold, SA) from prepare_host(), e.g. made in a thread pool
             self.RS, self.gc, self.threshold, sa = prepared
         else:
             self.RS, self.gc, self.threshold = subject_prepare(seq, p_value)
         self.n = len(self.RS)
-        self.SA = suffix_array(self.RS) if sa is None else np.ascontiguousarray(sa, dtype=np.int32)
         self._h = _P()
         L = load()
-        ctx._check(L.andi_hip_esa_stage(ctx._h, self.RS, self.SA.ctypes.data, self.n, self.threshold,
-                                        C.byref(self._h)), "esa_stage")
+        if isinstance(sa, str) and sa == "device":
+            self._SA = None
+            ctx._check(L.andi_hip_esa_stage_text(ctx._h, self.RS, self.n, self.threshold, C.byref(self._h)),
+                       "esa_stage_text")
+        else:
+            self._SA = suffix_array(self.RS) if sa is None else np.ascontiguousarray(sa, dtype=np.int32)
+            ctx._check(L.andi_hip_esa_stage(ctx._h, self.RS, self._SA.ctypes.data, self.n, self.threshold,
+                                            C.byref(self._h)), "esa_stage")
         self.reference_built = False
         if build in ("index", "both", True):
             self.build()
         if build in ("reference", "both"):
             self.build_reference()
+
+    @property
+    def SA(self):
+        if self._SA is None:  # built on the device: fetch it
+            sa = np.empty(self.n, np.int32)
+            self.ctx._check(load().andi_hip_esa_download_sa(self.ctx._h, self._h, sa.ctypes.data), "esa_download_sa")
+            self._SA = sa
+        return self._SA
 
     def build(self):
         """scan index (probe table)"""
@@ -401,7 +421,7 @@ def bootstrap(ctx: Context, M, replicates, seed=0):
 
 
 def dist_matrix(seqs, p_value=0.025, model=M_JC, device=0, host_threads=0, segment=0, num_gpus=1, devices=None,
-                low_memory=False):
+                low_memory=False, sa_on_host=False):
     """distMatrix (src/dist_hack.h:34): n*n*17 uint32, row = subject.  num_gpus / devices: the rows are
     tiled over several devices (or several contexts on one) behind the same call."""
     L = load()
@@ -412,6 +432,7 @@ def dist_matrix(seqs, p_value=0.025, model=M_JC, device=0, host_threads=0, segme
     L.andi_hip_default_opts(C.byref(o))
     o.p_value, o.model, o.device, o.host_threads, o.segment = p_value, model, device, host_threads, segment
     o.low_memory = int(low_memory)
+    o.sa_on_host = int(sa_on_host)
     o.num_gpus = num_gpus
     if devices is not None:
         dl = (C.c_int * len(devices))(*devices)

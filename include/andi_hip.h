@@ -66,6 +66,8 @@ typedef struct {
 	 * src/dist_hack.h:46-47): num_gpus devices device, device + 1, ...; 0 or 1 = one device; < 0 = all
 	 * visible devices from `device` on.  Every device owns a contiguous block of subject rows; the row
 	 * blocks are gathered on the first device with RCCL (send/recv over xGMI) and copied to M once. */
+	int sa_on_host;    /* 0: suffix arrays are built on the device (sa_device.hip); 1: by the host pool
+	                    * (andi_hip_suffix_array), as the reference does with libdivsufsort (src/esa.c:303) */
 	int num_gpus;
 	const int *devices; /* optional: exactly these num_gpus ordinals (an ordinal may repeat: several contexts
 	                     * on one device, rows then go to M directly) */
@@ -129,6 +131,11 @@ int andi_hip_sync(andi_hip_ctx *ctx);
  * src/esa.c:294-304).  Host→device copies only. */
 int andi_hip_esa_stage(andi_hip_ctx *ctx, const char *RS, const int32_t *SA, size_t n,
 					   size_t threshold, andi_hip_esa **out);
+/* The same with the suffix array built on the device (esa_init_SA, src/esa.c:294-304, without the host:
+ * prefix doubling on radix sorts): only RS is uploaded.  Synchronous. */
+int andi_hip_esa_stage_text(andi_hip_ctx *ctx, const char *RS, size_t n, size_t threshold, andi_hip_esa **out);
+/* Test hook: the suffix array as the device holds it, n entries. */
+int andi_hip_esa_download_sa(andi_hip_ctx *ctx, const andi_hip_esa *esa, int32_t *SA);
 /* esa_init_LCP, _CLD, _FVC, _cache (src/esa.c:373-426, 312-363, 229-245,
  * 73-215) as HIP kernels on the context's stream (asynchronous): the
  * reference's own arrays, bit for bit. */
@@ -198,6 +205,9 @@ typedef struct {
 	uint64_t scan_pairs;
 	uint64_t fixups;      /* segments whose speculative entry state was wrong */
 	uint64_t reference_subjects; /* subjects scanned with the reference walk */
+	double sa_ms;            /* suffix arrays built on the device (wall time of the calls: they synchronise per round) */
+	uint64_t sa_builds;
+	uint64_t sa_rounds;      /* sorting rounds of those builds */
 	uint64_t adaptive_calls; /* scan calls that chose the segment length per pair */
 	uint64_t uniform_calls;  /* ... one segment length for the call */
 } andi_hip_timings;

@@ -118,3 +118,54 @@ def test_match_positions_joined_and_unrelated(ctx, orc):
         np.frombuffer(g.translate(bytes.maketrans(b"ACGT", bytes(range(4)))), np.uint8), 0.02, 3)), 5, seed=2)
     _match_all_positions(ctx, orc, a, b)
     _match_all_positions(ctx, orc, rand_dna(rng, 50000), rand_dna(rng, 20000))
+
+
+def _sa_texts():
+    from andi_amd import synth
+    rng = np.random.default_rng(303)
+    yield from _subjects()
+    yield "homopolymer-100k", b"A" * 100000  # every round keeps every suffix: 13 rounds of doubling
+    yield "period-3", b"ACG" * 30000
+    yield "repeat-5k-x7", b"".join(rand_dna(rng, 30000) + u for u in [rand_dna(rng, 5000)] * 7)  # rRNA-operon-like
+    yield "two-copies", (lambda s: s + b"!" + s)(rand_dna(rng, 60000))
+    yield "length-21", rand_dna(rng, 21)
+    yield "length-22", rand_dna(rng, 22)
+    yield "random-2M", synth.to_bytes(synth.base_codes(2_000_000, 9))
+
+
+@pytest.mark.parametrize("name,seq", list(_sa_texts()), ids=[n for n, _ in _sa_texts()])
+def test_device_suffix_array_equals_host(ctx, name, seq):
+    """esa_init_SA (src/esa.c:294-304) on the device: the suffix array of RS is unique, so the device sorter
+    (sa_device.hip) must reproduce the host sorter's (host_sais.cpp, itself pinned to the oracle's independent
+    sorter in tests/test_host.py) entry for entry."""
+    import andi_amd
+    ctx.timings_reset()
+    E = andi_amd.Esa(ctx, seq, sa="device", build=False)
+    t = ctx.timings()
+    assert t["sa_builds"] == 1 and t["sa_rounds"] >= 1
+    want = andi_amd.suffix_array(E.RS)
+    got = E.SA
+    assert got.shape == want.shape and (got == want).all(), (name, np.argwhere(got != want)[:5].ravel())
+    E.close()
+
+
+def test_scan_on_device_built_suffix_arrays(ctx, orc):
+    """The whole device path of a subject: text up, suffix array, scan index, scan -- and the one-call seam with
+    the suffix arrays on the device (the default) and on the host."""
+    import andi_amd
+    from andi_amd import synth
+    base = synth.base_codes(150000, 31)
+    seqs = [synth.to_bytes(synth.mutate_codes(base, d, 60 + k)) for k, d in enumerate((0.0, 0.003, 0.03, 0.1))]
+    seqs.append(synth.join_contigs(seqs[1], 7, seed=2))
+    want = orc.dist_matrix(seqs, threads=0)
+    Q = andi_amd.Queries(ctx, seqs)
+    esas = [andi_amd.Esa(ctx, s, sa="device") for s in seqs]
+    got = andi_amd.scan_rows(ctx, esas, list(range(len(seqs))), Q)
+    assert (got == want).all()
+    for e in esas:
+        e.close()
+    Q.close()
+    assert (andi_amd.dist_matrix(seqs, host_threads=2) == want).all()
+    assert (andi_amd.dist_matrix(seqs, host_threads=2, sa_on_host=True) == want).all()
+    with pytest.raises(andi_amd.AndiHipError, match="outside"):
+        andi_amd.Esa(ctx, seqs[0][:500] + b"N" + seqs[0][500:1000], sa="device")
