@@ -765,12 +765,12 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		used *= nsub;
 		size_t free_b = 0, total_b = 0;
 		const bool fits = max_waves < (1u << 26) &&
-						  (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)64 * max_waves * 308 < free_b / 2 + ctx->scratch_bytes);
+						  (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)64 * max_waves * 348 < free_b / 2 + ctx->scratch_bytes);
 		if (!fits || (10 * used < 7 * 64 * max_waves && !getenv("ANDI_FORCE_ADAPTIVE"))) adaptive = false, max_waves = 0;
 	}
 	const size_t pairs_all = nsub * q->nq;
 	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
-	const size_t need = slots * (2 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4) +
+	const size_t need = slots * (3 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4 + 8) + 128 +
 						(adaptive ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -793,6 +793,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	p += slots * sizeof(ChainState);
 	a.true_exit = (ChainState *)p;
 	p += slots * sizeof(ChainState);
+	a.used_entry = (ChainState *)p;
+	p += slots * sizeof(ChainState);
 	a.cold_counts = (uint32_t *)p;
 	p += slots * 16 * sizeof(uint32_t);
 	a.owned = (uint32_t *)p;
@@ -801,6 +803,13 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	p += slots * ANDI_COLD_MARKS * sizeof(ColdMark);
 	a.exit_p = (uint32_t *)p;
 	p += slots * sizeof(uint32_t);
+	p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+	a.restitch_count = (uint32_t *)p;
+	a.restitch_round = 0;
+	a.defer_count = a.restitch_count + 8;
+	p += 64;
+	a.defer_list = (unsigned long long *)p;
+	p += slots * sizeof(unsigned long long);
 	a.adaptive = adaptive ? 1 : 0;
 	a.seg0 = seg0, a.max_waves = (uint32_t)max_waves;
 	a.max_class = 0; // long segments must not leave the device short of chains
@@ -844,6 +853,13 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		if (e == hipSuccess) e = andi_launch_scan_reduce(a, ctx->stream);
 		t.stop();
 		if (e != hipSuccess) return fail(ctx, "scan passes B/C", e);
+	}
+	if (getenv("ANDI_DEBUG_STITCH")) { // diagnostics: segments stitched again per round, length of the last stage's list
+		uint32_t h[16];
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipMemcpy(h, a.restitch_count, sizeof h, hipMemcpyDeviceToHost);
+		fprintf(stderr, "stitch: %zu slots; true chains that left on their own %u; stitched again in rounds: %u %u %u; last list %u\n", slots,
+				h[ANDI_RESTITCH_ROUNDS], h[0], h[1], h[2], h[8]);
 	}
 	(adaptive ? ctx->acc.adaptive_calls : ctx->acc.uniform_calls)++;
 	ctx->acc.scan_pairs += pairs;

@@ -28,7 +28,8 @@ constexpr uint32_t WNT = 32; // symbols per window
 constexpr uint32_t EMPTY = ~0u;
 constexpr int32_t NO_DIAG = INT32_MIN;
 constexpr uint32_t ONES = 0x11111111u;
-constexpr uint32_t MULTI_MAX = 8; // occurrences a lane extends along one by one; more: binary search
+constexpr uint32_t MULTI_MAX = 32; // occurrences a lane extends along one by one; more: binary search
+constexpr uint32_t ROUNDS_MULTI_MAX = 8; // (scan_rounds.hip keeps the positions in registers)
 
 // 32 symbols of the query from q0 (even) and, if dg != NO_DIAG, of the subject from q0 + dg
 struct LWin {
@@ -114,6 +115,9 @@ struct LaneItem {
 	bool valid;
 };
 
+// the work item of a slot (see lane_item for the layouts)
+__device__ __forceinline__ LaneItem lane_item_of_slot(const ScanArgs &a, unsigned long long slot);
+
 template <int NT = BLOCK> // threads per block
 __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 	LaneItem it;
@@ -156,3 +160,33 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 	return it;
 }
 
+
+__device__ __forceinline__ LaneItem lane_item_of_slot(const ScanArgs &a, unsigned long long slot) {
+	LaneItem it;
+	it.slot = (size_t)slot;
+	it.valid = true;
+	if (!a.adaptive) {
+		it.sub = (uint32_t)(slot / a.total_segs);
+		const uint32_t w = (uint32_t)(slot % a.total_segs);
+		it.qidx = a.seg2query[w];
+		it.seg_in_q = w - a.qseg_start[it.qidx];
+		it.seg = a.seg;
+		const uint32_t qlen = a.qlen[it.qidx];
+		it.start = it.seg_in_q * a.seg;
+		it.end = it.start + a.seg < qlen ? it.start + a.seg : qlen;
+		return it;
+	}
+	const uint32_t P = a.nsub * a.nq, W = (uint32_t)(slot >> 6);
+	uint32_t lo = 0, hi = P; // the last pair whose first wavefront is <= W
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (a.pair_wave0[mid] <= W) lo = mid; else hi = mid;
+	}
+	it.sub = lo / a.nq, it.qidx = lo % a.nq;
+	it.seg = a.seg0 << a.pair_class[lo];
+	const uint32_t qlen = a.qlen[it.qidx];
+	it.seg_in_q = (W - a.pair_wave0[lo]) * 64 + (uint32_t)(slot & 63u);
+	it.start = it.seg_in_q * it.seg;
+	it.end = it.start + it.seg < qlen ? it.start + it.seg : qlen;
+	return it;
+}

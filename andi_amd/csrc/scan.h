@@ -14,8 +14,10 @@ struct __attribute__((aligned(16))) ChainState {
 	uint32_t lastQ;   // last_match.pos_Q
 	uint32_t lastLen; // last_match.length
 	uint32_t lwra;    // last_was_right_anchor
-	uint32_t pad[3];
+	uint32_t pad[3];  // [0]: a mark is valid (ColdMark); [1] in a cold exit: anchors the cold chain found in its
+					  // segment (capped at 255; ANDI_ANCHORS_UNKNOWN: not recorded)
 };
+#define ANDI_ANCHORS_UNKNOWN 0xffffffffu
 
 // What pass A of the lane scan remembers of a cold chain besides its exit: the state and
 // the counts right after its 2nd (.. ANDI_COLD_MARKS + 1 th) anchor.  The true chain
@@ -49,6 +51,15 @@ struct ScanArgs {
 	uint32_t *cold_counts; // [..][16] counts the cold chain added inside the segment
 	ColdMark *marks;       // [..][ANDI_COLD_MARKS] (lane scan only)
 	ChainState *true_exit; // state of the true chain when it leaves the segment
+	ChainState *used_entry; // the state pass B let the true chain enter the segment in (pass C verifies it)
+	uint32_t *restitch_count; // [r]: segments stitched again in round r (lane scan); [ANDI_RESTITCH_ROUNDS]: true chains that left their segment on their own
+	uint32_t restitch_round;
+	// Segments whose stitching takes more than ANDI_STITCH_BUDGET chain steps are put on a list and
+	// stitched by a second launch, 64 of them per wavefront: one long replay (through a repeat, along the
+	// edge of an island) would otherwise hold up the 63 settled segments of its wavefront.
+	unsigned long long *defer_list; // slots
+	uint32_t *defer_count;
+	uint32_t defer_base; // first list entry of this launch
 	uint32_t *owned;       // [..][16] counts the true chain adds inside the segment
 	andi_hip_model *M;     // [nsub][nq]
 	unsigned long long *fixups;
@@ -84,6 +95,14 @@ int andi_scan_group(void);
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
+// Pass B again for the segments whose predecessor's true exit turned out not to be the assumed entry (a true
+// chain that runs on lucky anchors through a repeat in which cold chains find nothing unique): each round
+// settles one more segment of every such stretch, all stretches at once.  Rounds after one without any
+// re-stitched segment return at once.
+#define ANDI_RESTITCH_ROUNDS 3
+#define ANDI_STITCH_BUDGET 48
+#define ANDI_LISTED_LANES 2
+#define ANDI_STITCH_TOGETHER 40 /* steps of pass B's phase 2 in which the cold chain is replayed beside the true one */
 // pass A in rounds with line buffers (scan_rounds.hip); andi_rounds_lines() != 0: in use
 int andi_rounds_lines(void);
 hipError_t andi_launch_rounds_cold(const ScanArgs &a, hipStream_t st);

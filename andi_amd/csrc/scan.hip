@@ -356,6 +356,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_scan_cold(ScanArgs a) {
 
 	size_t slot = (size_t)it.sub * a.total_segs + it.w;
 	uint32_t lane = Group<G>::sub();
+	st.pad[1] = ANDI_ANCHORS_UNKNOWN; // (this kernel does not count its anchors: no memory is inherited through its segments)
 	if (lane == 0) a.cold_exit[slot] = st, a.exit_p[slot] = st.p;
 	tally_finish<G>(tally);
 	for (uint32_t t = lane; t < 16; t += G) a.cold_counts[slot * 16 + t] = tally.hist[t * tally.hs];
@@ -418,7 +419,8 @@ __global__ __launch_bounds__(BLOCK, 5) void k_scan_stitch(ScanArgs a) {
 	uint32_t *histT = s_hist[0] + cell0, *histC = s_hist[1] + cell0;
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
 	// assumed entry; verified in pass C
-	ChainState T = a.cold_exit[slot - it.seg_in_q + entry_source(a, slot - it.seg_in_q, it.seg_in_q, a.seg, c.qlen)];
+	ChainState T = assumed_entry(a, slot - it.seg_in_q, it.seg_in_q, a.seg, c.qlen);
+	if (lane == 0) a.used_entry[slot] = T;
 	stitch_segment<G, MODE, EXACT>(c, T, it.start, it.end, a.cold_exit[slot], a.cold_counts + slot * 16, histT,
 					  histC);
 	if (lane == 0) a.true_exit[slot] = T;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	// every segment k >= 1 was stitched assuming it is entered in the cold exit of entry_source(k)
 	bool ok = true;
 	for (uint32_t k = 1 + threadIdx.x; k < nseg; k += BLOCK)
-		ok = ok && same_state(a.true_exit[row + k - 1], a.cold_exit[row + entry_source(a, row, k, seg, c.qlen)]);
+		ok = ok && same_state(a.true_exit[row + k - 1], a.used_entry[row + k]);
 	const bool all_ok = __syncthreads_and(ok);
 	ChainState fin;
 	if (all_ok) {
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 		if (threadIdx.x >= 64) return; // what follows is sequential: the first wavefront alone
 		ChainState st = initial_state();
 		for (uint32_t k = 0; k < nseg; ++k) {
-			ChainState assumed = k == 0 ? initial_state() : a.cold_exit[row + entry_source(a, row, k, seg, c.qlen)];
+			ChainState assumed = k == 0 ? initial_state() : a.used_entry[row + k];
 			if (same_state(st, assumed)) {
 				if (lane < 16) total[lane] += a.owned[(row + k) * 16 + lane];
 				st = a.true_exit[row + k];

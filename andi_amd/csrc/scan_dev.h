@@ -137,6 +137,36 @@ __device__ __forceinline__ uint32_t entry_source(const ScanArgs &a, size_t row, 
 	return j;
 }
 
+// The state in which pass B assumes the true chain enters segment k (k >= 1), verified by pass C.
+// Its position is where the cold chain of the segment before it (entry_source) left.  What it
+// remembers -- its last anchor and last_was_right_anchor -- is what that cold chain left with,
+// unless that chain found no anchor at all: the true chain then passes through such a segment
+// with the memory it came with (in a stretch without homology -- a genomic island, an unrelated
+// contig -- no chain finds anything for many segments), so the memory is taken from the nearest
+// segment before it whose cold chain did find one.
+#define ANDI_MEMORY_WINDOW 4096
+__device__ __forceinline__ ChainState assumed_entry(const ScanArgs &a, size_t row, uint32_t k, uint32_t seg, uint32_t qlen) {
+	uint32_t j = entry_source(a, row, k, seg, qlen);
+	ChainState T = a.cold_exit[row + j];
+	if (T.pad[1] != 0 || j == 0) return T;
+	for (uint32_t hops = 0; hops < ANDI_MEMORY_WINDOW; ++hops) {
+		j = entry_source(a, row, j, seg, qlen); // the segment the chain was in before j
+		const ChainState m = a.cold_exit[row + j];
+		if (m.pad[1] != 0 || j == 0) {
+			T.lastS = m.lastS, T.lastQ = m.lastQ, T.lastLen = m.lastLen, T.lwra = m.lwra;
+			break;
+		}
+	}
+	return T; // (window exhausted: the assumption fails pass C's check and the pair is fixed up sequentially)
+}
+
+// lucky_anchor's precondition (src/process.c:86-92): while it does not hold and no anchor is found, a
+// chain's next position depends on its position alone
+__device__ __forceinline__ bool lucky_applies(const ChainState &s, uint32_t n, uint32_t thr) {
+	const uint32_t advance = s.p - s.lastQ;
+	return s.lastS + advance < n && advance - s.lastLen <= thr;
+}
+
 // adaptive mode: first slot, segment length and segment count of a pair
 struct PairGeom {
 	size_t slot0;

@@ -17,6 +17,8 @@
 // stitch, reduce) are those of scan.hip; the results are bit-identical.
 #include "lane_dev.h"
 
+#include <algorithm>
+
 namespace {
 
 __device__ __forceinline__ void win_load(LWin &w, const PairCtx &c, uint32_t qa, int32_t dg) {
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 	}
 	for (uint32_t k = anchors < 2 ? 0 : anchors - 1; k < ANDI_COLD_MARKS; ++k) marks[k].st.pad[0] = 0; // unused marks
 
+	st.pad[1] = anchors < 255 ? anchors : 255;
 	a.cold_exit[slot] = st;
 	a.exit_p[slot] = st.p;
 	tally_finish<1>(tally);
@@ -435,24 +438,39 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 // ------------------------------------------------------------------ pass B
 // as stitch_segment in scan.hip: the true chain (entering in state T) is replayed next
 // to the segment's cold chain until both are in the same state
-template <bool EXACT>
-__global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
-	__shared__ uint32_t s_hist[2][16 * BLOCK];
-	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
-	const LaneItem it = lane_item(a);
-	if (!it.valid) return;
+// LISTED: the segments an earlier launch put on the list
+template <bool EXACT, bool AGAIN, bool LISTED>
+__device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &it, uint32_t (*s_hist)[16 * BLOCK]) {
 	const size_t slot = it.slot;
+	uint32_t steps = 0; // chain steps replayed so far
+	auto over_budget = [&]() { // (not LISTED) too long for this launch: leave it to the listed one
+		if (++steps <= ANDI_STITCH_BUDGET || LISTED) return false;
+		a.defer_list[atomicAdd(a.defer_count, 1u)] = (unsigned long long)slot;
+		return true;
+	};
 	const uint32_t *coldCounts = a.cold_counts + slot * 16;
 	uint32_t *owned = a.owned + slot * 16;
 
 	if (it.seg_in_q == 0) { // the first segment's "cold" chain is the true chain
+		if (AGAIN) return;
 		a.true_exit[slot] = a.cold_exit[slot];
 		for (int t = 0; t < 16; ++t) owned[t] = coldCounts[t];
 		return;
 	}
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
-	// assumed entry; verified in pass C
-	ChainState T = a.cold_exit[slot - it.seg_in_q + entry_source(a, slot - it.seg_in_q, it.seg_in_q, it.seg, c.qlen)];
+	ChainState T;
+	if constexpr (AGAIN) { // where the true chain of the segment before really left, as far as that is known by now
+		const size_t row = slot - it.seg_in_q;
+		T = a.true_exit[row + entry_source(a, row, it.seg_in_q, it.seg, c.qlen)];
+		T.pad[0] = T.pad[1] = T.pad[2] = 0;
+		if (!LISTED) {
+			if (same_state(T, a.used_entry[slot])) return;
+			atomicAdd(&a.restitch_count[a.restitch_round], 1u);
+		}
+	} else { // assumed entry
+		T = assumed_entry(a, slot - it.seg_in_q, it.seg_in_q, it.seg, c.qlen);
+	}
+	a.used_entry[slot] = T; // verified in pass C
 	ChainState C = cold_state(it.start, (uint32_t)c.E.n);
 	Tally tT, tC;
 	tally_begin<1>(tT, s_hist[0] + threadIdx.x);
@@ -498,6 +516,40 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 			}
 		}
 	}
+	// Phase 0: the cold chain's first anchor lies far ahead -- the segment starts in a stretch without homology
+	// (an island, an unrelated contig).  Until a chain finds an anchor, and once lucky_anchor's precondition is
+	// gone, its positions depend on its position alone: both chains step (the one behind) until they stand at the
+	// same position; from there the true chain's steps are the cold chain's, so it arrives at the cold chain's
+	// first anchor just as that did and is put there, with its own memory, instead of being replayed through
+	// the stretch.
+	uint32_t foundC = 0; // anchors the replayed cold chain has behind it
+	const ChainState coldExit = a.cold_exit[slot];
+	const uint32_t totalC = coldExit.pad[1], nS = (uint32_t)c.E.n;
+	if (totalC >= 1 && totalC != ANDI_ANCHORS_UNKNOWN) {
+		const uint4 f1 = *(const uint4 *)marks[0].first; // the cold chain's 1st anchor: pos_Q, pos_S, length
+		if (f1.x > T.p + 4 * WNT && !lucky_applies(T, nS, c.thr)) { // (a true chain that comes from an anchor nearby falls in with the marks at once)
+			while (T.p < f1.x && C.p < f1.x) {
+				if (T.p == C.p && !lucky_applies(T, nS, c.thr)) {
+					T.p = f1.x;
+					lane_account<EXACT>(c, T, tT, w, f1.y);
+					T.lastS = f1.y, T.lastQ = f1.x, T.lastLen = f1.z;
+					T.p += f1.z + 1;
+					break;
+				}
+				if (over_budget()) return;
+				const bool stepT = T.p <= C.p;
+				Tally tx = stepT ? tT : tC;
+				ChainState nx = lane_step<EXACT>(c, stepT ? T : C, tx, w, found);
+				if (stepT) {
+					T = nx, tT = tx;
+				} else {
+					C = nx, tC = tx;
+					if (found) ++foundC;
+				}
+				if (found) break; // the true chain found an anchor of its own, or the cold chain its first: go on as usual
+			}
+		}
+	}
 	int hit = -1;
 	if (anyMark) {
 		for (;;) {
@@ -505,6 +557,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 			for (int k = 0; k < ANDI_COLD_MARKS; ++k)
 				if (hit < 0 && M[k].pad[0] && same_state(T, M[k])) hit = k;
 			if (hit >= 0 || T.p >= it.end || T.p > lastMarkP) break;
+			if (over_budget()) return;
 			T = lane_step<EXACT>(c, T, tT, w, found);
 		}
 	}
@@ -520,22 +573,46 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 	STAT(ST_SEARCH); // (diagnostic builds: segments that reach phase 2)
 	if (M[0].pad[0] && T.p >= M[0].p) { // the cold chain need not be replayed up to its mark
 		C = M[0];
+		foundC = 2;
 		for (int t = 0; t < 16; ++t) tC.hist[t * BLOCK] = marks[0].counts[t];
 	}
-	bool synced = false;
-	for (;;) {
+	// Without an anchor ahead of it a chain's positions depend on its position alone (once lucky_anchor's
+	// precondition is gone): when the two chains stand at the same position and the cold chain has found all
+	// the anchors it finds in this segment, the true chain's remaining steps are the cold chain's -- whatever
+	// the two remember.  That settles the segments of a stretch without homology after a few steps.
+	// Chains that have not met after ANDI_STITCH_TOGETHER steps are in a stretch in which they will not soon
+	// (without homology the step lengths hardly vary and the two keep leapfrogging; chance anchors of one are
+	// not the other's): the true chain then runs alone to the segment's end -- half the steps of replaying both.
+	bool synced = false, psynced = false;
+	for (uint32_t together = 0;; ++together) {
 		if (same_state(T, C)) {
 			synced = true;
 			break;
 		}
+		if (together >= ANDI_STITCH_TOGETHER) {
+			while (T.p < it.end) {
+				if (over_budget()) return;
+				T = lane_step<EXACT>(c, T, tT, w, found);
+			}
+			break;
+		}
+		if (T.p == C.p && totalC < 255 && foundC == totalC && !lucky_applies(T, nS, c.thr) && !lucky_applies(C, nS, c.thr)) {
+			psynced = true;
+			break;
+		}
 		if (T.p >= it.end) break;
-		const bool stepT = C.p >= it.end || T.p <= C.p; // one call site keeps the code small
+		if (over_budget()) return;
+		// the one that is behind steps -- but a cold chain with no anchor left to find is only needed to learn
+		// where the true chain falls in with it, and that cannot happen while the true chain runs on lucky
+		// anchors (through a repeat, where the cold chain would crawl from probe to probe)
+		const bool stepT = C.p >= it.end || T.p <= C.p || (totalC < 255 && foundC == totalC && lucky_applies(T, nS, c.thr));
 		Tally tx = stepT ? tT : tC;
 		ChainState nx = lane_step<EXACT>(c, stepT ? T : C, tx, w, found);
 		if (stepT) {
 			T = nx, tT = tx;
 		} else {
 			C = nx, tC = tx;
+			if (found) ++foundC;
 		}
 	}
 	tally_finish<1>(tT);
@@ -543,10 +620,36 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) {
 	// from the meeting point on, the cold chain's trajectory is the true one
 	for (int t = 0; t < 16; ++t) {
 		uint32_t v = tT.hist[t * BLOCK];
-		if (synced) v += coldCounts[t] - tC.hist[t * BLOCK];
+		if (synced || psynced) v += coldCounts[t] - tC.hist[t * BLOCK];
 		owned[t] = v;
 	}
-	a.true_exit[slot] = synced ? a.cold_exit[slot] : T;
+	if (psynced) T.p = coldExit.p; // same steps from here on, the true chain's own memory
+	a.true_exit[slot] = synced ? coldExit : T;
+	if (!synced && !psynced) atomicAdd(&a.restitch_count[ANDI_RESTITCH_ROUNDS], 1u); // its successor's assumed entry is at stake
+}
+
+template <bool EXACT, bool AGAIN, bool LISTED>
+__global__ __launch_bounds__(BLOCK, 3) void k_lane_stitch(ScanArgs a) {
+	__shared__ uint32_t s_hist[2][16 * BLOCK];
+	// stitching again is for the successors of segments whose true chain never fell in with the cold one, and then
+	// for the successors of those that were stitched again
+	if (AGAIN && a.restitch_count[a.restitch_round > 0 ? a.restitch_round - 1 : ANDI_RESTITCH_ROUNDS] == 0) return;
+	if constexpr (LISTED) {
+		// As few segments per wavefront as the list's length allows (at least ANDI_LISTED_LANES): their replays
+		// are long and all different, a full wavefront of them would take its 64 lanes' paths one after the
+		// other at every step, and the device is nearly empty while this launch runs
+		const uint32_t count = *a.defer_count, waves = gridDim.x * WAVES_PER_BLOCK;
+		uint32_t lanes = (count + waves - 1) / waves;
+		lanes = lanes < ANDI_LISTED_LANES ? ANDI_LISTED_LANES : lanes > 64 ? 64 : lanes;
+		if ((threadIdx.x & 63u) >= lanes) return;
+		const uint32_t stride = waves * lanes;
+		for (uint32_t idx = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * lanes + (threadIdx.x & 63u); idx < count; idx += stride)
+			stitch_item<EXACT, AGAIN, true>(a, lane_item_of_slot(a, a.defer_list[idx]), s_hist);
+	} else {
+		if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
+		const LaneItem it = lane_item(a);
+		if (it.valid) stitch_item<EXACT, AGAIN, false>(a, it, s_hist);
+	}
 }
 
 // ------------------------------------------------------------------ packing
@@ -652,11 +755,33 @@ hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st) {
 	return e;
 }
 
-hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st) {
-	dim3 grid = lane_grid(a);
+hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
+	dim3 grid = lane_grid(a0);
+	ScanArgs a = a0;
+	hipError_t e = hipMemsetAsync(a.restitch_count, 0, 16 * sizeof(uint32_t), st);
+	if (e != hipSuccess) return e;
+	// every stage: the launch over all segments, then the segments it put on the list (a grid for half of all
+	// segments at most: blocks beyond the list's length return at once; the list cannot be longer than the
+	// segments that have a predecessor)
+	const size_t slots = a.adaptive ? (size_t)64 * a.max_waves : (size_t)a.nsub * a.total_segs;
+	const uint32_t per_block = WAVES_PER_BLOCK * ANDI_LISTED_LANES;
+	const unsigned lblocks = (unsigned)std::min<size_t>((slots + per_block - 1) / per_block, 4096); // (strides over the list)
+	auto stage = [&](auto main_kernel, auto listed_kernel) {
+		(void)hipMemsetAsync(a.defer_count, 0, sizeof(uint32_t), st);
+		main_kernel<<<grid, BLOCK, 0, st>>>(a);
+		listed_kernel<<<lblocks, BLOCK, 0, st>>>(a);
+	};
 	if (a.exact_equal)
-		k_lane_stitch<true><<<grid, BLOCK, 0, st>>>(a);
+		stage(k_lane_stitch<true, false, false>, k_lane_stitch<true, false, true>);
 	else
-		k_lane_stitch<false><<<grid, BLOCK, 0, st>>>(a);
+		stage(k_lane_stitch<false, false, false>, k_lane_stitch<false, false, true>);
+	static const bool again = !getenv("ANDI_NO_RESTITCH");
+	for (uint32_t r = 0; again && r < ANDI_RESTITCH_ROUNDS; ++r) {
+		a.restitch_round = r;
+		if (a.exact_equal)
+			stage(k_lane_stitch<true, true, false>, k_lane_stitch<true, true, true>);
+		else
+			stage(k_lane_stitch<false, true, false>, k_lane_stitch<false, true, true>);
+	}
 	return hipGetLastError();
 }

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void k_rounds_cold(ScanArgs a) {
 				} else if (kind == DEEP_MULTI) {
 					cnt = (ty >> 8) + 1;
 					STAT(ST_MULTI);
-					if (cnt > MULTI_MAX) {
+					if (cnt > ROUNDS_MULTI_MAX) {
 						STAT(ST_SEARCH);
 						const Probe pr = sa_range_match<1>(E, c.Q + st.p, qrem, (int32_t)tx, (int32_t)(tx + cnt - 1), K);
 						curS = pr.pos, curLen = pr.len, found = pr.unique && pr.len >= thr, pc = PC_DONE_PROBE;
@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64) void k_rounds_cold(ScanArgs a) {
 
 	if (!it.valid) return;
 	for (uint32_t k = anchors < 2 ? 0 : anchors - 1; k < ANDI_COLD_MARKS; ++k) marks[k].st.pad[0] = 0; // unused marks
+	st.pad[1] = anchors < 255 ? anchors : 255;
 	a.cold_exit[slot] = st;
 	a.exit_p[slot] = st.p;
 	tally_finish<1>(tally);

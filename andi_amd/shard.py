@@ -32,20 +32,22 @@ def weak_scaling_set_size(n_gpus, base=29):
     return n_gpus * max(1, round(base / math.sqrt(n_gpus)))
 
 
-def gather_matrix(block, total, dist=None, world=1, rank=0, force=False):
+def gather_matrix(block, total, dist=None, world=1, rank=0, force=False, rows=None):
     """All ranks call with their padded row block, a (max_rows, total, 17) int32
-    tensor; returns the full (total, total, 17) uint32 matrix on rank 0 and None
-    elsewhere.  force=True goes through the collective even with one rank."""
+    tensor; returns the full (rows, total, 17) uint32 matrix on rank 0 and None
+    elsewhere (rows = number of subject rows of the job, default: total).
+    force=True goes through the collective even with one rank."""
     import torch
+    rows = total if rows is None else rows
     if world == 1 and not (force and dist is not None):
-        a, b = row_block(total, 1, 0)
+        a, b = row_block(rows, 1, 0)
         return block[: b - a].cpu().numpy().view(np.uint32)
     parts = [torch.empty_like(block) for _ in range(world)]
     dist.all_gather(parts, block)
     if rank != 0:
         return None
-    rows = []
+    out = []
     for r in range(world):
-        a, b = row_block(total, world, r)
-        rows.append(parts[r][: b - a].cpu().numpy().view(np.uint32))
-    return np.concatenate(rows, axis=0)
+        a, b = row_block(rows, world, r)
+        out.append(parts[r][: b - a].cpu().numpy().view(np.uint32))
+    return np.concatenate(out, axis=0)

@@ -64,3 +64,84 @@ def join_contigs(seq: bytes, n_contigs, seed=7):
         parts.append(seq[last:c])
         last = c
     return b"!".join(parts)
+
+
+# ---------------------------------------------------------------- realistic structure
+def _revcomp_codes(c):
+    return (3 - c)[::-1]
+
+
+def realistic_base(length, seed, families=((1300, 10), (5000, 7), (300, 25))):
+    """A base genome with multi-copy repeats on both strands: per family (unit length, copies) one random unit is
+    pasted at random places, every other copy reverse-complemented and every copy lightly mutated (IS elements,
+    rRNA operons, REP-like short repeats).  andi's manual lists exactly these as what real data sets have and the
+    test generator has not (docs/manual/andi-manual.tex:303-320)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    g = rng.integers(0, 4, size=length, dtype=np.uint8)
+    for unit_len, copies in families:
+        if unit_len * copies * 2 > length:
+            continue
+        unit = rng.integers(0, 4, size=unit_len, dtype=np.uint8)
+        for k in range(copies):
+            u = unit.copy()
+            m = rng.random(unit_len) < 0.004 * k  # older copies have drifted
+            u[m] = (u[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+            if k & 1:
+                u = _revcomp_codes(u)
+            at = int(rng.integers(0, length - unit_len))
+            g[at:at + unit_len] = u
+    return g
+
+
+def evolve_codes(base, d, seed, indel_rate=0.1, inversions=2, novel_fraction=0.1):
+    """A descendant of `base`: substitutions at divergence d (as mutate_codes), indels (indel_rate per substitution,
+    lengths geometric with mean 6, a few up to 1 kbp), `inversions` inverted segments of 5-60 kbp (reverse
+    complement in place) and about novel_fraction of the genome replaced by islands of unrelated sequence
+    (5-40 kbp): the non-homologous stretches in which the scan probes at every step."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    g = mutate_codes(base, d, seed + 7)
+    L = len(g)
+    for _ in range(inversions):
+        ln = int(rng.integers(5000, max(5001, min(60000, L // 4))))
+        at = int(rng.integers(0, L - ln))
+        g[at:at + ln] = _revcomp_codes(g[at:at + ln])
+    # islands of novel sequence, then indels, applied left to right
+    edits = []  # (position, deleted length, inserted codes)
+    target, covered = int(novel_fraction * L), 0
+    while covered < target:
+        ln = int(rng.integers(5000, max(5001, min(40000, L // 5))))
+        edits.append((int(rng.integers(0, L - ln)), ln, rng.integers(0, 4, size=int(ln * rng.uniform(0.5, 1.5)), dtype=np.uint8)))
+        covered += ln
+    p = d if d < 0.75 else 0.7
+    n_indel = int(indel_rate * p * L)
+    for _ in range(n_indel):
+        ln = min(int(rng.geometric(1 / 6.0)), 1000) if rng.random() > 0.01 else int(rng.integers(50, 1000))
+        at = int(rng.integers(0, L - ln))
+        if rng.random() < 0.5:
+            edits.append((at, ln, np.empty(0, np.uint8)))
+        else:
+            edits.append((at, 0, rng.integers(0, 4, size=ln, dtype=np.uint8)))
+    edits.sort(key=lambda e: e[0])
+    parts, cursor = [], 0
+    for at, dele, ins in edits:
+        if at < cursor:
+            continue  # overlaps the previous edit
+        parts.append(g[cursor:at])
+        parts.append(ins)
+        cursor = at + dele
+    parts.append(g[cursor:])
+    return np.concatenate(parts)
+
+
+def realistic_set(n, length, d_lo, d_hi, seed=1729, contigs=0, **kw):
+    """n genomes descending from one repeat-carrying base, each with substitutions, indels, inversions and novel
+    islands of its own (star phylogeny); contigs > 0 cuts every genome into that many contigs joined by '!'
+    (andi --join, src/sequence.c:78-125).  Returns (list of bytes, list of d_k)."""
+    base = realistic_base(length, seed)
+    drng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+    ds = drng.uniform(d_lo, d_hi, size=n)
+    out = []
+    for k in range(n):
+        s = to_bytes(evolve_codes(base, float(ds[k]), seed + 100 + k, **kw))
+        out.append(join_contigs(s, contigs, seed=seed + k) if contigs > 1 else s)
+    return out, [float(x) for x in ds]

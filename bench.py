@@ -12,9 +12,11 @@ d_k ~ U[0.0004, 0.03], JC model.  One step = one pass of the device path over
 the whole set: per subject the device index build (the scan index: packed text and
 K-mer probe table, from the resident RS + suffix array), then the anchor scan of
 every query against every subject (passes A/B of scan_lane.hip, pass C of
-scan.hip), then (N > 1) the RCCL gather of the row blocks.  Suffix arrays are built on the host and uploaded before the
-timed region (north_star: "SA ... on host"); their cost is reported under
-"end_to_end", never in "value".
+scan.hip), then (N > 1) the RCCL gather of the row blocks.  The texts and their
+suffix arrays are staged before the timed region (the suffix arrays are built on
+the device, sa_device.hip; the host sorter's time is reported beside it); the whole
+job through the one-call seam andi_hip_dist_matrix -- everything included, cold -- is
+reported under "end_to_end", never in "value".
 
 N > 1 (one process per GPU, launched by torch.distributed.run): one G x G
 matrix with G ~ 29*sqrt(N) genomes, rows block-partitioned over the ranks, so
@@ -40,19 +42,25 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genomes", type=int, default=0, help="genomes in the set (default: 29 at 1 GPU)")
+    ap.add_argument("--subjects", type=int, default=0,
+                    help="scan only the first S genomes as subjects (S rows x all genomes; default: all rows)")
     ap.add_argument("--length", type=int, default=4_900_000)
     ap.add_argument("--dlo", type=float, default=0.0004)
     ap.add_argument("--dhi", type=float, default=0.03)
     ap.add_argument("--segment", type=int, default=0)
+    ap.add_argument("--set", choices=("star", "realistic"), default="star",
+                    help="star: substitutions only (the reference's generator, test/test_fasta.cxx); realistic: repeats on "
+                         "both strands, indels, inversions, unrelated islands (andi_amd/synth.py: realistic_set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1729)
     return ap.parse_args()
 
 
 def cpu_baseline(seqs, p_value, model):
-    """The oracle (a port of the reference's OpenMP path, subject-parallel like
-    distMatrix) on this box's host cores, whole workload.  Checker code: timed
-    as a baseline only, never part of the product path."""
+    """The oracle (a port of the reference's OpenMP path) on this box's host cores.  Checker code: timed as a
+    baseline only, never part of the product path.  Both of the reference's loops: subject-parallel (distMatrix,
+    src/dist_hack.h:46-47; whole workload) and query-parallel (distMatrixLM, src/dist_hack.h:59-60; all host
+    cores on the queries of one subject at a time; a sample of the subjects)."""
     from oracle import orc
     cores = os.cpu_count() or 1
     threads = min(cores, len(seqs))
@@ -60,6 +68,20 @@ def cpu_baseline(seqs, p_value, model):
     M, (t_build, t_scan) = orc.dist_matrix(seqs, p_value=p_value, model=model, threads=threads, times=True)
     wall = time.time() - t0
     n = len(seqs)
+    # query-parallel flavour on a bounded sample: 3 subjects, every query, all cores
+    sample = min(3, n)
+    t_lm_build = t_lm_scan = 0.0
+    lm_ok = True
+    for i in range(sample):
+        t1 = time.time()
+        O = orc.OracleEsa(seqs[i], p_value)
+        t2 = time.time()
+        row = orc.scan_row(O, seqs, i, model, threads=cores)
+        t3 = time.time()
+        O.close()
+        t_lm_build += t2 - t1
+        t_lm_scan += t3 - t2
+        lm_ok = lm_ok and bool((row == M[i]).all())
     return M, {
         "value": (n * n - n) / wall, "unit": "pairs/s", "cores": threads, "kind": "port",
         "sample": "whole workload: %d genomes, %d ordered pairs, index build (own suffix sorter, not "
@@ -67,6 +89,13 @@ def cpu_baseline(seqs, p_value, model):
         "host_cores_available": cores,
         "index_build_core_s": t_build, "scan_core_s": t_scan,
         "scan_only_pairs_per_s_per_core": (n * n - n) / t_scan if t_scan > 0 else None,
+        "query_parallel": {
+            "note": "distMatrixLM-style (src/dist_hack.h:59-60): one subject at a time, its index built by one core, "
+                    "its queries scanned by all %d host cores; sample = first %d subjects x %d queries" % (cores, sample, n - 1),
+            "value": sample * (n - 1) / (t_lm_build + t_lm_scan), "unit": "pairs/s", "cores": cores,
+            "scan_only_pairs_per_s": sample * (n - 1) / t_lm_scan if t_lm_scan > 0 else None,
+            "index_build_s_per_subject": t_lm_build / sample, "equal_to_subject_parallel": lm_ok,
+        },
     }
 
 
@@ -75,9 +104,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = max(args.gpus, 1)
-    if world != n_gpus and world > 1:
-        n_gpus = world
+    if max(args.gpus, 1) != world:
+        raise SystemExit("bench.py --gpus %d needs %d ranks: launch it as `python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...` (one process per GPU); "
+                         "WORLD_SIZE is %d" % (args.gpus, args.gpus, args.gpus, args.gpus, world))
 
     import numpy as np
     import torch
@@ -99,24 +129,31 @@ def main():
     model = andi_amd.M_JC
     p_value = 0.025
     t_gen = time.time()
-    seqs, ds = synth.genome_set(G, args.length, args.dlo, args.dhi, seed=args.seed)
+    if args.set == "realistic":
+        seqs, ds = synth.realistic_set(G, args.length, args.dlo, args.dhi, seed=args.seed)
+    else:
+        seqs, ds = synth.genome_set(G, args.length, args.dlo, args.dhi, seed=args.seed)
     t_gen = time.time() - t_gen
 
-    r0, r1 = shard.row_block(G, world, rank)
+    S = args.subjects if 0 < args.subjects <= G else G  # subject rows of the job
+    r0, r1 = shard.row_block(S, world, rank)
     ctx = andi_amd.Context(local_rank)
-    # ---- untimed staging: queries, and for the owned rows RS + host suffix array
+    # ---- untimed staging: queries, and for the owned rows RS (host: seq_subject_init) and its suffix array (device)
     t_stage = time.time()
     Q = andi_amd.Queries(ctx, seqs)
     from concurrent.futures import ThreadPoolExecutor
     host_threads = max(1, min((os.cpu_count() or 1) // max(world, 1), r1 - r0))
-    with ThreadPoolExecutor(host_threads) as pool:  # suffix arrays on the host cores, in parallel
-        prepared = list(pool.map(lambda i: lib.prepare_host(seqs[i], p_value), range(r0, r1)))
-    esas = [andi_amd.Esa(ctx, seqs[i], p_value, build=False, prepared=prepared[i - r0]) for i in range(r0, r1)]
+    with ThreadPoolExecutor(host_threads) as pool:  # RS = revcomp(S) # S, gc, threshold on the host cores
+        prepared = list(pool.map(lambda i: lib.subject_prepare(seqs[i], p_value), range(r0, r1)))
+    ctx.timings_reset()
+    esas = [andi_amd.Esa(ctx, seqs[i], p_value, build=False, prepared=prepared[i - r0] + ("device",)) for i in range(r0, r1)]
     del prepared
     ctx.sync()
     t_stage = time.time() - t_stage
+    sa_ms = ctx.timings()["sa_ms"]
     nsub = r1 - r0
-    block = torch.zeros((shard.max_rows(G, world), G, 17), dtype=torch.int32, device="cuda")
+    block = torch.zeros((shard.max_rows(S, world), G, 17), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # the engine writes the block from its own stream: the fill must have landed
     gathered = [None]
     selfs = list(range(r0, r1))
     dptr = andi_amd.lib._P(block.data_ptr())
@@ -127,7 +164,7 @@ def main():
         lib.scan_rows_dev(ctx, esas, selfs, Q, model, args.segment, dptr)  # anchor scan
         ctx.sync()  # the engine's stream is not torch's: finish before the collective
         if use_dist:  # RCCL over xGMI: the one exchange of the job, 68 B per ordered pair
-            gathered[0] = shard.gather_matrix(block, G, dist, world, rank, force=True)
+            gathered[0] = shard.gather_matrix(block, G, dist, world, rank, force=True, rows=S)
 
     def fence():
         if use_dist:
@@ -149,7 +186,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    pairs_total = G * G - G
+    pairs_total = S * (G - 1)
     ms_per_step = 1e3 * elapsed / args.steps
     value = pairs_total / (elapsed / args.steps)
 
@@ -157,7 +194,7 @@ def main():
     # the engine's own stream: algorithmic bytes = 2 * query length per pair
     launches = max(int(tm["scan_launches"]), 1)
     scan_ms = tm["scan_ms"] / launches
-    alg_bytes = 2.0 * tm["scan_query_nt"] / launches
+    alg_bytes = 2.0 * tm["scan_query_nt"] / launches  # (query lengths differ in the realistic sets: the sum over the scanned pairs)
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
     prof = os.path.join(ROOT, "profiles", "traffic.json")
@@ -187,17 +224,19 @@ def main():
     scan_kernel = "k_lane_cold" if os.environ.get("ANDI_SCAN_G", "0") == "0" else "k_scan_cold"
     out = None
     if rank == 0:
-        full = gathered[0] if use_dist else shard.gather_matrix(block, G)
-        dmat = [andi_amd.estimate(full[0, j].astype(np.uint64) + full[j, 0], model) for j in range(1, min(G, 4))]
+        full = gathered[0] if use_dist else shard.gather_matrix(block, G, rows=S)
+        dmat = [andi_amd.estimate(full[0, j].astype(np.uint64) + full[j, 0], model) for j in range(1, min(S, 4))]
         out = {
             "metric": "genome-pairs/sec (ordered pairs, n^2-n) over the N x N anchor-distance loop",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C2-synth: %d genomes x %d nt, d~U[%g,%g] from a common base, JC, "
-                                   "seed %d; rows block-partitioned over %d GPU(s)"
-                                   % (G, args.length, args.dlo, args.dhi, args.seed, world),
-                       "genomes": G, "length": args.length, "model": "JC", "pairs": pairs_total,
+            "config": {"workload": "C2-%s: %d genomes x %d nt, d~U[%g,%g] from a common base, JC, "
+                                   "seed %d; %s rows block-partitioned over %d GPU(s)"
+                                   % ("synth" if args.set == "star" else "realistic (repeats, indels, inversions, 10 %% unrelated)",
+                                      G, args.length, args.dlo, args.dhi, args.seed,
+                                      "all" if S == G else "the first %d subject" % S, world),
+                       "genomes": G, "subjects": S, "length": args.length, "model": "JC", "pairs": pairs_total,
                        "segment": args.segment or "auto (chosen per pair from its sampled match lengths: 2048 ... 16384 for this set)"},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -207,16 +246,19 @@ def main():
             "breakdown_ms_per_step": {"index_build": tm["build_ms"] / args.steps,
                                       "scan_cold_pass": tm["scan_ms"] / args.steps,
                                       "scan_stitch_reduce": tm["stitch_ms"] / args.steps,
-                                      "fixups": int(tm["fixups"])},
-            "end_to_end": {"note": "rank 0, untimed staging: host RS + suffix arrays (SA-IS, %d host threads) + H2D" % host_threads,
-                           "staging_s": t_stage, "generate_s": t_gen,
+                                      "fixups": int(tm["fixups"]),
+                                      "scan_calls_with_per_pair_segments": int(tm["adaptive_calls"]),
+                                      "scan_calls_with_one_segment_length": int(tm["uniform_calls"])},
+            "end_to_end": {"note": "rank 0, untimed staging of its rows: RS on %d host threads, H2D of RS, suffix arrays "
+                                   "on the device (sa_device.hip)" % host_threads,
+                           "staging_s": t_stage, "device_suffix_sort_s": sa_ms * 1e-3, "generate_s": t_gen,
                            "pairs_per_s_incl_staging": (nsub * (G - 1)) / (t_stage + elapsed / args.steps)},
             "sample_distances": dmat,
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         Mcpu, base = cpu_baseline(seqs, p_value, model)
         out["cpu_baseline"] = base
-        out["parity_vs_cpu_baseline"] = bool((Mcpu == full).all())
+        out["parity_vs_cpu_baseline"] = bool((Mcpu[:S] == full).all())
     elif rank == 0:
         out["cpu_baseline"] = None
 
@@ -224,6 +266,18 @@ def main():
         e.close()
     Q.close()
     ctx.close()
+    if rank == 0 and world == 1 and S == G and not args.no_cpu_baseline:
+        # the whole job through the one-call seam (context, staging, suffix arrays, index builds, scans, D2H), cold
+        t0 = time.time()
+        M1 = andi_amd.dist_matrix(seqs, p_value=p_value, model=model)
+        e2e = time.time() - t0
+        t0 = time.time()
+        M2 = andi_amd.dist_matrix(seqs, p_value=p_value, model=model, sa_on_host=True)
+        e2e_host = time.time() - t0
+        out["end_to_end"].update({
+            "dist_matrix_e2e_s": e2e, "dist_matrix_pairs_per_s": pairs_total / e2e,
+            "dist_matrix_e2e_s_suffix_arrays_on_host": e2e_host, "host_cores": os.cpu_count(),
+            "dist_matrix_equals_step": bool((M1 == full).all() and (M2 == full).all())})
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

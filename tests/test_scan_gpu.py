@@ -329,3 +329,20 @@ def test_pass_a_in_rounds_agrees(ctx, orc, monkeypatch, lines):
     for passes in ("1", "3", "50"):
         monkeypatch.setenv("ANDI_ROUNDS_PASSES", passes)
         _check_set(ctx, orc, seqs, segments=(0, 1500, 64))
+
+
+def test_realistic_divergence_structure(ctx, orc):
+    """Genomes as real data sets have them (docs/manual/andi-manual.tex:303-320) and the reference's generator has
+    not: multi-copy repeats on both strands, indels, inversions, 5-10 % of unrelated sequence, optionally cut into
+    contigs -- the regime in which the scan probes at nearly every step, walks repeated K-mers' occurrences and
+    changes diagonal all the time (src/process.c:113-123, src/esa.c:531-601).  Counts bit-exact, every model."""
+    from andi_amd import synth
+    seqs, ds = synth.realistic_set(6, 250000, 0.001, 0.06, seed=77, novel_fraction=0.07)
+    want = orc.dist_matrix(seqs, threads=0)
+    cov = want[:, :, :16].sum(axis=2) / np.maximum(want[:, :, 16], 1)
+    assert 0.3 < cov[0, 1] < 0.98  # homology is partial, as in real sets
+    _check_set(ctx, orc, seqs, segments=(0, 2048, 100))
+    for model in (0, 2, 4):
+        _check_set(ctx, orc, seqs[:4], model=model)
+    joined, _ = synth.realistic_set(4, 120000, 0.003, 0.04, seed=78, contigs=9)
+    _check_set(ctx, orc, joined, segments=(0, 700))
