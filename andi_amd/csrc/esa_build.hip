@@ -13,10 +13,11 @@
 //   K2a min_tree      64-ary min pyramid over LCP
 //   K2b child_table   CLD from nearest-smaller-value searches  (src/esa.c:312-363)
 //   K4  kmer_table    4^10 interval table, one thread per 10-mer (src/esa.c:73-215)
-// and the scan index (see "scan index" below):
-//   K5p pack_text        2-bit codes + ACGT bitmap of the text (L2-sized)
-//   K5a suffix_prefixes  K-mer code and valid length of every suffix
-//   K5b probe_table      4^K outcome table, one thread per suffix-array gap
+// and the scan index (see "scan index" below), built from RS and SA alone:
+//   pack_symbols (scan_lane.hip)  the text as 4-bit symbols in two alignments (N0, N1)
+//   probe_table                   4^K outcome table: a block takes 512 suffix-array gaps, makes the suffixes'
+//                                 records itself (one 8-byte gather each) and writes the table piece it owns
+// (the suffix array itself comes from the host or from sa_device.hip)
 #include "andi_dev.h"
 #include "esa_build.h"
 #include "scan.h"
@@ -387,8 +388,19 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 		if (live) {
 			// (a) present K-mers
 			if (hasR && REC_V(R) == full && !(hasL && REC_V(L) == full && REC_CODE(L) == REC_CODE(R))) {
+				// the end of the run of suffixes with this K-mer: a short walk (runs are short in genomes), then a
+				// binary search over the suffix array -- records of one K-mer are equal, later ones greater -- so
+				// that a K-mer with 10^6 occurrences (a homopolymer, a satellite) does not serialise on one lane
 				int32_t j = r;
-				while (j + 1 < n && rec(j + 1) == R) ++j;
+				while (j + 1 < n && j - r < 16 && rec(j + 1) == R) ++j;
+				if (j - r == 16 && j + 1 < n && rec(j + 1) == R) {
+					int32_t lo = j + 1, hi = n - 1; // rec(lo) == R; find the last index with rec == R
+					while (lo < hi) {
+						const int32_t mid = lo + ((hi - lo + 1) >> 1);
+						if (rec(mid) == R) lo = mid; else hi = mid - 1;
+					}
+					j = lo;
+				}
 				if (j == r) {
 					// the K-mer occurs once.  For the scan in rounds (scan_rounds.hip) its entry also carries the
 					// (up to 13) nucleotides that follow it in the text, so that a chance match is settled

@@ -7,6 +7,7 @@
  */
 #define _GNU_SOURCE
 #include <err.h>
+#include <ctype.h>
 #include <errno.h>
 #include <getopt.h>
 #include <limits.h>
@@ -99,9 +100,12 @@ static char *slurp(const char *file_name, size_t *len_out) {
 	return buf;
 }
 
-/* read_fasta, src/io.c:196-233: every record of the file becomes one sequence.
- * Record grammar as the reference's parser accepts it: '>' name [comment] NL,
- * then sequence lines up to the next '>' at the start of a line. */
+/* read_fasta, src/io.c:196-233: every record of the file becomes one sequence.  The record grammar and the
+ * messages are those of the reference's parser (libs/pfasta.c:304-480): the file must start with '>'; the name is
+ * the word behind it, the rest of the line a comment; the sequence is every following word of a line that starts
+ * with a letter, '-' or '*', across blank lines and blanks inside lines, CR LF or LF; anything else must be the
+ * next record's '>'.  A malformed record ends the file with a message (records read before it are kept). */
+#define IS_SPACE(c) (((c) >= '\t' && (c) <= '\r') || (c) == ' ')
 static void read_fasta(const char *file_name, genome_list *out) {
 	size_t len = 0;
 	char *text = slurp(file_name, &len);
@@ -110,43 +114,62 @@ static void read_fasta(const char *file_name, genome_list *out) {
 		warn("%s", file_name);
 		return;
 	}
+	if (len == 0) {
+		soft_warnx("%s: File is empty.", file_name);
+		free(text);
+		return;
+	}
+	if (text[0] != '>') {
+		soft_warnx("%s: File must start with '>'.", file_name);
+		free(text);
+		return;
+	}
 	char *p = text, *end = text + len;
-	while (p < end && (*p == '\n' || *p == '\r' || *p == ' ' || *p == '\t')) p++;
-	if (p == end) {
-		soft_warnx("%s: Empty file", file_name);
-		free(text);
-		return;
-	}
-	if (*p != '>') {
-		soft_warnx("%s: File does not start with '>'", file_name);
-		free(text);
-		return;
-	}
+	size_t line = 1;
 	while (p < end) {
-		/* header */
-		char *h = p + 1;
-		char *eol = memchr(h, '\n', (size_t)(end - h));
-		if (!eol) eol = end;
-		char *name_end = h;
-		while (name_end < eol && *name_end != ' ' && *name_end != '\t' && *name_end != '\r') name_end++;
-		if (name_end == h) {
-			soft_warnx("%s: Empty name", file_name);
+		if (*p != '>') {
+			soft_warnx("%s: Expected '>' but found '%c' on line %zu.", file_name, *p, line);
 			break;
 		}
-		genome g;
-		g.name = strndup(h, (size_t)(name_end - h));
-		/* body: up to the next line starting with '>' */
-		char *body = eol < end ? eol + 1 : end;
-		char *q = body;
-		while (q < end) {
-			if (*q == '>' && (q == body || q[-1] == '\n')) break;
-			q++;
+		/* name */
+		char *h = ++p;
+		while (p < end && !IS_SPACE(*p)) p++;
+		if (p == end) {
+			soft_warnx("%s: Unexpected EOF in name on line %zu.", file_name, line);
+			break;
 		}
-		g.seq = strndup(body, (size_t)(q - body));
-		if (!g.name || !g.seq) err(errno, "Out of memory");
+		if (p == h) {
+			soft_warnx("%s: Empty name on line %zu.", file_name, line);
+			break;
+		}
+		char *name_end = p;
+		/* comment: the rest of the line */
+		while (p < end && *p != '\n') p++;
+		if (p == end) {
+			soft_warnx("%s: Unexpected EOF in comment on line %zu.", file_name, line);
+			break;
+		}
+		/* sequence */
+		while (p < end && IS_SPACE(*p)) line += *p++ == '\n';
+		genome g;
+		g.seq = xmalloc((size_t)(end - p) + 1);
+		size_t n = 0;
+		while (p < end && (isalpha((unsigned char)*p) || *p == '-' || *p == '*')) {
+			while (p < end && !IS_SPACE(*p)) g.seq[n++] = *p++;
+			while (p < end && IS_SPACE(*p)) line += *p++ == '\n';
+		}
+		if (n == 0) {
+			soft_warnx("%s: Empty sequence on line %zu.", file_name, line);
+			free(g.seq);
+			break;
+		}
+		g.seq[n] = '\0';
+		g.name = strndup(h, (size_t)(name_end - h));
+		if (!g.name) err(errno, "Out of memory");
 		g.len = normalize(g.seq);
+		char *fit = realloc(g.seq, g.len + 1);
+		if (fit) g.seq = fit;
 		push_genome(out, g);
-		p = q;
 	}
 	free(text);
 }

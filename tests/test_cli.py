@@ -49,7 +49,39 @@ def test_cli_usage_and_validation(tmp_path):
     notfasta = tmp_path / "x.txt"
     notfasta.write_text("hello\n")
     rc, out, err = run([str(notfasta), two])
-    assert "does not start with '>'" in err
+    assert "x.txt: File must start with '>'." in err  # libs/pfasta.c:317-319
+
+
+def test_fasta_acceptance_rules(tmp_path):
+    """The reader takes and refuses what the reference's parser does (libs/pfasta.c:304-480, src/io.c:196-233),
+    with its messages: CR LF, blank lines, blanks inside sequence lines, '>' inside a sequence word, headers
+    without a comment; missing '>', empty name, header at the end of the file, text that is not a sequence."""
+    def records(text):  # what a file parses to: the run fails later ("less than two sequences") or goes on to the GPU
+        f = tmp_path / "t.fa"
+        f.write_bytes(text)
+        return run([str(f)])
+
+    # accepted: one record only -> "less than two sequences (1 given)" proves it was read as exactly one
+    for text in (b">A\r\nACGT\r\nACGT\r\n",                      # CR LF
+                 b">A\n\n\nACGT\n\n  \nAC GT\n",                  # blank lines, blanks inside a line
+                 b">A comment > with more\nAC>GT\nACGT",             # '>' inside a line is part of the word; no final newline
+                 b">A\n-ACGT*\n"):                                   # lines may start with '-' or '*'
+        rc, out, err = records(text)
+        assert rc == 1 and "less than two sequences (1 given)" in err, (text, err)
+    rc, out, err = records(b">A\nACGT\n>B\tcomment\nGGCC\n>C\nTT\n")
+    assert "less than two" not in err  # three records
+    # refused, with the parser's own words; records before the defect are kept
+    for text, msg, given in ((b"", "File is empty.", 0),
+                             (b"\n>A\nACGT\n", "File must start with '>'.", 0),
+                             (b">A\nACGT\n>\nACGT\n", "Empty name on line 3.", 1),
+                             (b">A\nACGT\n>B", "Unexpected EOF in name on line 3.", 1),
+                             (b">A\nACGT\n>B comment", "Unexpected EOF in comment on line 3.", 1),
+                             (b">A\nACGT\n>B\n\n", "Empty sequence on line 5.", 1),
+                             (b">A\nACGT\n>B\n>C\nACGT\n", "Empty sequence on line 4.", 1),
+                             (b">A\nACGT\n12 ACGT\n", "Expected '>' but found '1' on line 3.", 1)):
+        rc, out, err = records(text)
+        assert rc == 1 and ("t.fa: " + msg) in err, (text, err)
+        assert ("less than two sequences (%d given)" % given) in err, (text, err)
 
 
 @pytest.mark.gpu
