@@ -85,9 +85,10 @@ __device__ __forceinline__ uint32_t lcp_slide(LWin &w, const PairCtx &c, uint32_
 
 // Common prefix of Q[q0 + from ..] and S[q0 + from + dg ..], at most lim, where the
 // window holds the query symbols q0 .. q0 + 31 (the subject side is fetched).
-__device__ __forceinline__ uint32_t lane_extend(const LWin &w, const PairCtx &c, uint32_t from, int32_t dg,
-												uint32_t lim) {
-	uint4 d = neq32(w.q, ld_subject(c, (int32_t)w.q0 + dg));
+// (sv: the subject's 32 symbols against the window, already fetched)
+__device__ __forceinline__ uint32_t lane_extend_from(const LWin &w, const PairCtx &c, uint32_t from, int32_t dg,
+													 uint32_t lim, const uint4 &sv) {
+	uint4 d = neq32(w.q, sv);
 	uint32_t f = first_from(d, from);
 	if (f < WNT) {
 		const uint32_t len = f - from;
@@ -105,6 +106,11 @@ __device__ __forceinline__ uint32_t lane_extend(const LWin &w, const PairCtx &c,
 		len += WNT, qa += WNT;
 	}
 	return len < lim ? len : lim;
+}
+
+__device__ __forceinline__ uint32_t lane_extend(const LWin &w, const PairCtx &c, uint32_t from, int32_t dg,
+												uint32_t lim) {
+	return lane_extend_from(w, c, from, dg, lim, ld_subject(c, (int32_t)w.q0 + dg));
 }
 
 // model_count (src/model.c:309-337) of Q[q..q+len) against S[s..s+len) through the window.
@@ -221,6 +227,8 @@ __device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &
 	if (cnt > MULTI_MAX) return sa_range_match<1>(E, q, qrem, (int32_t)x, (int32_t)(x + cnt - 1), K);
 	// the longest match is the best of the occurrences' own common prefixes with the
 	// query and it is unique iff exactly one attains it
+	// (Four occurrences per round trip -- one 16-byte load of positions, four windows in flight -- were measured:
+	// 12 more registers, a wavefront less per SIMD, pass A 7.4 -> 7.9 ms.)
 	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
 	for (uint32_t i = 0; i < cnt; ++i) {
 		const uint32_t pos = (uint32_t)E.SA[x + i];
@@ -382,6 +390,130 @@ __global__ __launch_bounds__(1024) void k_pair_offsets(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------ pass A
+// Pass A with the chain step cut in two, so that the lanes of a wavefront do the same thing at the same
+// time: every trip of the loop a lane that is ON A DIAGONAL (lucky_anchor's precondition holds,
+// src/process.c:86-92) takes the next window of that diagonal and settles every anchor and mismatch inside
+// it -- lucky anchors behind single mismatches are a few register operations each, the window loads of all
+// those lanes are one load instruction and one wait -- and then the lanes whose lucky attempt FAILED, or that
+// are on no diagonal, probe (anchor(), src/process.c:113-123) together.  lane_step does the same work as one
+// straight-line function per step; its 64 lanes are then at ten different places, a load is issued for 5 or
+// 6 of them at a time, and the wavefront waits out each of those latencies in turn.  Same results.
+template <bool EXACT>
+__device__ __forceinline__ void lane_cold_stream(const ScanArgs &a, const LaneItem &it, uint32_t *s_hist) {
+	Tally tally;
+	tally_begin<1>(tally, s_hist + threadIdx.x);
+	PairCtx c = make_ctx(a, it.sub, it.qidx);
+	const uint32_t n = (uint32_t)c.E.n, thr = c.thr;
+	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, n);
+	LWin w;
+	w.q0 = EMPTY, w.dg = NO_DIAG;
+	const size_t slot = it.slot;
+	ColdMark *marks = a.marks + slot * ANDI_COLD_MARKS;
+	uint32_t anchors = 0;
+	uint32_t curLen = 0;    // symbols of the lucky attempt at st.p compared so far (all equal)
+	bool accounted = false; // the anchor at st.p is certain and has been accounted for
+	bool lucky = lucky_applies(st, n, thr);
+	bool active = it.valid && st.p < it.end;
+
+	auto commit = [&](uint32_t curS, uint32_t len) { // an anchor of `len` symbols at st.p, subject offset curS (src/process.c:157-197)
+		if (!accounted) lane_account<EXACT>(c, st, tally, w, curS);
+		st.lastS = curS, st.lastQ = st.p, st.lastLen = len;
+		st.p += len + 1;
+		curLen = 0, accounted = false;
+		if (++anchors == 1) *(uint4 *)marks[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
+		if (anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
+			ColdMark *m = marks + (anchors - 2);
+			ChainState ms = st;
+			ms.pad[0] = 1;
+			m->st = ms;
+			uint32_t v[16];
+#pragma unroll
+			for (int t = 0; t < 16; ++t) v[t] = tally.hist[t * BLOCK];
+			v[0] += tally.quarter + tally.same[0], v[5] += tally.quarter + tally.same[1];
+			v[10] += tally.quarter + tally.same[2], v[15] += tally.quarter + tally.rest + tally.same[3];
+			uint4 *mc = (uint4 *)m->counts;
+#pragma unroll
+			for (int t = 0; t < 4; ++t) mc[t] = make_uint4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
+		}
+	};
+
+	while (__any(active)) {
+		// ---- on a diagonal: one window of it
+		if (active && lucky) {
+			const uint32_t curS0 = st.lastS + (st.p - st.lastQ);
+			const int32_t dg = (int32_t)(curS0 - st.p);
+			uint32_t pos = st.p + curLen;
+			if (w.q0 == EMPTY || w.dg != dg || pos < w.q0 || pos - w.q0 >= WNT) {
+				uint32_t back = 0; // a fresh attempt: fetch the gap behind the last anchor too, it will be counted from the window
+				if (curLen == 0) back = st.p - st.lastQ - st.lastLen < 16 ? st.p - st.lastQ - st.lastLen : 16;
+				win_load(w, c, (pos - back) & ~1u, dg);
+				STAT(ST_LCP_RELOAD);
+			}
+			for (;;) { // the anchors and mismatches this window holds
+				const uint32_t maxlen = c.qlen - st.p, o = pos - w.q0, f = first_from(w.d, o);
+				curLen += f - o, pos += f - o;
+				if (f >= WNT && curLen < maxlen) { // the match runs on past the window: slide on the next trip
+					const uint32_t gap = st.p - st.lastQ - st.lastLen;
+					if (!accounted && curLen >= thr && maxlen >= thr && st.p - gap >= w.q0) {
+						// certainly an anchor already: count the gap while the window still holds it
+						lane_account<EXACT>(c, st, tally, w, st.lastS + (st.p - st.lastQ));
+						accounted = true;
+					}
+					break;
+				}
+				if (curLen > maxlen) curLen = maxlen;
+				if (curLen < thr) { // lucky_anchor failed: the probe follows, below
+					lucky = false;
+					break;
+				}
+				STAT(ST_STEP);
+				commit(st.lastS + (st.p - st.lastQ), curLen);
+				active = st.p < it.end;
+				lucky = lucky_applies(st, n, thr);
+				pos = st.p;
+				// the next attempt on this diagonal starts behind the mismatch: in this window still?
+				if (!active || !lucky || w.dg != dg || pos < w.q0 || pos - w.q0 >= WNT) break;
+			}
+		}
+		// ---- not on a diagonal, or the attempt on it failed: anchor(), src/process.c:113-123
+		if (active && !lucky) {
+			STAT(ST_STEP);
+			const Probe pr = lane_probe(c, st.p, w);
+			if (pr.unique && pr.len >= thr) {
+				accounted = false;
+				commit(pr.pos, pr.len);
+			} else {
+				st.p += pr.len + 1;
+			}
+			curLen = 0, accounted = false;
+			active = st.p < it.end;
+			lucky = lucky_applies(st, n, thr);
+		}
+	}
+	if (!it.valid) return;
+	for (uint32_t k = anchors < 2 ? 0 : anchors - 1; k < ANDI_COLD_MARKS; ++k) marks[k].st.pad[0] = 0; // unused marks
+
+	st.pad[1] = anchors < 255 ? anchors : 255;
+	a.cold_exit[slot] = st;
+	a.exit_p[slot] = st.p;
+	tally_finish<1>(tally);
+	uint32_t out[16];
+#pragma unroll
+	for (int t = 0; t < 16; ++t) out[t] = tally.hist[t * BLOCK];
+	uint4 *dst = (uint4 *)(a.cold_counts + slot * 16);
+#pragma unroll
+	for (int t = 0; t < 4; ++t) dst[t] = make_uint4(out[4 * t], out[4 * t + 1], out[4 * t + 2], out[4 * t + 3]);
+}
+
+template <bool EXACT, int OCC>
+__global__ __launch_bounds__(BLOCK, OCC) void k_lane_stream(ScanArgs a) {
+	__shared__ uint32_t s_hist[16 * BLOCK];
+	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
+	const LaneItem it = lane_item(a);
+	if (!__any(it.valid)) return;
+	lane_cold_stream<EXACT>(a, it, s_hist);
+}
+
 // The lanes of a wavefront take consecutive segments of one query, so they see the
 // same divergence and stay in step.  (Persistent lanes that fetch their next segment
 // from a counter when done were measured 15-50 % slower: they mix pairs of different
@@ -709,6 +841,15 @@ template <bool EXACT>
 static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	const char *pe = getenv("ANDI_LANE_LDS_PAD"); // experiments: unused LDS per block, limits the resident wavefronts
 	const size_t pad = pe ? (size_t)atoi(pe) : 0;
+	static const bool stream = getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) != 0; // measured slower: an experiment
+	if (stream) {
+		switch (lane_occupancy()) {
+			case 4: k_lane_stream<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
+			case 6: k_lane_stream<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break;
+			default: k_lane_stream<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
+		}
+		return hipGetLastError();
+	}
 	switch (lane_occupancy()) {
 		case 4: k_lane_cold<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
 		case 6: k_lane_cold<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break;

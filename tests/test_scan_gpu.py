@@ -346,3 +346,15 @@ def test_realistic_divergence_structure(ctx, orc):
         _check_set(ctx, orc, seqs[:4], model=model)
     joined, _ = synth.realistic_set(4, 120000, 0.003, 0.04, seed=78, contigs=9)
     _check_set(ctx, orc, joined, segments=(0, 700))
+
+
+def test_pass_a_as_two_phase_loop_agrees(ctx, orc, monkeypatch):
+    """ANDI_LANE_STREAM=1: pass A with the chain step cut in two (scan_lane.hip: lane_cold_stream) -- every trip
+    the lanes on a diagonal settle one window of it, then the lanes that need one probe together.  An experiment
+    (measured slower than the straight-line step); same counts."""
+    from andi_amd import synth
+    monkeypatch.setenv("ANDI_LANE_STREAM", "1")
+    seqs, _ = synth.realistic_set(5, 150000, 0.0005, 0.08, seed=5, novel_fraction=0.05)
+    seqs.append(seqs[0])  # identical to its subject: one anchor as long as the sequence
+    _check_set(ctx, orc, seqs, segments=(0, 1024, 77))
+    _check_set(ctx, orc, seqs[:3], model=4)
