@@ -841,7 +841,7 @@ template <bool EXACT>
 static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	const char *pe = getenv("ANDI_LANE_LDS_PAD"); // experiments: unused LDS per block, limits the resident wavefronts
 	const size_t pad = pe ? (size_t)atoi(pe) : 0;
-	static const bool stream = getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) != 0; // measured slower: an experiment
+	const bool stream = getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) != 0; // measured slower: an experiment
 	if (stream) {
 		switch (lane_occupancy()) {
 			case 4: k_lane_stream<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
@@ -916,7 +916,7 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 		stage(k_lane_stitch<true, false, false>, k_lane_stitch<true, false, true>);
 	else
 		stage(k_lane_stitch<false, false, false>, k_lane_stitch<false, false, true>);
-	static const bool again = !getenv("ANDI_NO_RESTITCH");
+	const bool again = !getenv("ANDI_NO_RESTITCH");
 	for (uint32_t r = 0; again && r < ANDI_RESTITCH_ROUNDS; ++r) {
 		a.restitch_round = r;
 		if (a.exact_equal)

@@ -11,6 +11,8 @@
 //   4  as 2, through LDS-DMA
 //   5  four neighbouring lanes share a random 64-B line (one piece each: a fully coalesced request)
 //   6  eight neighbouring lanes share a random 128-B line
+//   7, 8, 9  as 0, 2, 4 with every address 3 bytes off a 16-byte boundary (the subject side of the scan reads
+//      the packed text at byte granularity)
 // Reported: lines/s, bytes/s of lines, for footprints 1 GiB (HBM), 128 MiB (Infinity Cache) and
 // 16 MiB (half of the L2s), at 8 and at `occ` resident wavefronts per SIMD (LDS padding).
 #include <hip/hip_runtime.h>
@@ -19,6 +21,12 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 typedef __attribute__((address_space(1))) const uint4 *g_u4p;
+typedef __attribute__((address_space(1))) const uint8_t *g_u8;
+__device__ __forceinline__ uint4 ld16u(g_u8 p) { // any byte address
+	uint4 v;
+	__builtin_memcpy(&v, p, 16);
+	return v;
+}
 __device__ __forceinline__ uint4 ld16(g_u4p p) {
 	uint4 v;
 	__builtin_memcpy(&v, p, 16);
@@ -36,8 +44,8 @@ __global__ __launch_bounds__(256) void k_lines(const uint4 *buf_, uint32_t mask_
 	if (MODE == 5) x = (tid >> 2) * 2654435761u + 12345u;
 	if (MODE == 6) x = (tid >> 3) * 2654435761u + 12345u;
 	uint32_t acc = 0;
-	constexpr int PIECES = (MODE == 1 || MODE == 3) ? 4 : (MODE == 2 || MODE == 4) ? 8 : 1;
-	constexpr uint32_t LINE = (MODE == 2 || MODE == 4 || MODE == 6) ? 128u : 64u;
+	constexpr int PIECES = (MODE == 1 || MODE == 3) ? 4 : (MODE == 2 || MODE == 4 || MODE == 8 || MODE == 9) ? 8 : 1;
+	constexpr uint32_t LINE = (MODE == 2 || MODE == 4 || MODE == 6 || MODE == 8 || MODE == 9) ? 128u : 64u;
 	for (int i = 0; i < iters; ++i) {
 		x = x * 1664525u + 1013904223u;
 		const uint32_t line = ((x >> 4) & mask_bytes) & ~(LINE - 1u); // byte offset of the line
@@ -58,6 +66,22 @@ __global__ __launch_bounds__(256) void k_lines(const uint4 *buf_, uint32_t mask_
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			const uint4 v = s_dyn[(wave * PIECES + (x & (PIECES - 1))) * 64 + lane];
 			acc += v.x ^ v.w;
+		} else if constexpr (MODE == 7) {
+			const uint4 v = ld16u((g_u8)buf + line + 16 * (x & 3u) + 3);
+			acc += v.x ^ v.y ^ v.z ^ v.w;
+		} else if constexpr (MODE == 8) {
+			uint4 v[PIECES];
+#pragma unroll
+			for (int k = 0; k < PIECES; ++k) v[k] = ld16u((g_u8)buf + line + 16 * k + 3);
+#pragma unroll
+			for (int k = 0; k < PIECES; ++k) acc += v[k].x ^ v[k].w;
+		} else if constexpr (MODE == 9) {
+#pragma unroll
+			for (int k = 0; k < PIECES; ++k)
+				__builtin_amdgcn_global_load_lds((g_u8)buf + line + 16 * k + 3, (lds_p)(s_dyn + (wave * PIECES + k) * 64), 16, 0, 0);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			const uint4 v = s_dyn[(wave * PIECES + (x & (PIECES - 1))) * 64 + lane];
+			acc += v.x ^ v.w;
 		} else if constexpr (MODE == 5) {
 			const uint4 v = ld16(buf + (line >> 4) + (lane & 3u));
 			acc += v.x ^ v.w;
@@ -75,9 +99,9 @@ __global__ __launch_bounds__(256) void k_lines(const uint4 *buf_, uint32_t mask_
 template <int MODE>
 static void run(const char *what, const uint4 *buf, size_t bytes, int blocks_per_cu, uint32_t *out, hipEvent_t a, hipEvent_t b) {
 	const int blocks = 256 * 8 * 4, iters = 400;
-	constexpr int PIECES = (MODE == 1 || MODE == 3) ? 4 : (MODE == 2 || MODE == 4) ? 8 : 1;
-	constexpr uint32_t LINE = (MODE == 2 || MODE == 4 || MODE == 6) ? 128u : 64u;
-	size_t lds = (MODE == 3 || MODE == 4) ? (size_t)256 * PIECES * 16 : 0;
+	constexpr int PIECES = (MODE == 1 || MODE == 3) ? 4 : (MODE == 2 || MODE == 4 || MODE == 8 || MODE == 9) ? 8 : 1;
+	constexpr uint32_t LINE = (MODE == 2 || MODE == 4 || MODE == 6 || MODE == 8 || MODE == 9) ? 128u : 64u;
+	size_t lds = (MODE == 3 || MODE == 4 || MODE == 9) ? (size_t)256 * PIECES * 16 : 0;
 	const size_t want = (size_t)160 * 1024 / blocks_per_cu; // LDS per block that admits exactly blocks_per_cu
 	if (blocks_per_cu < 8 && lds < want - 1024) lds = want - 1024;
 	CK(hipFuncSetAttribute((const void *)k_lines<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -104,6 +128,18 @@ int main() {
 	hipEvent_t a, b;
 	CK(hipEventCreate(&a));
 	CK(hipEventCreate(&b));
+	if (getenv("LINE_FETCH_UNALIGNED")) { // the unaligned modes only
+		const size_t bytes = (size_t)1 << 30;
+		for (int occ : {8, 3}) {
+			run<0>("16-B piece of a 64-B line", buf, bytes - 256, occ, out, a, b);
+			run<7>("16 B, 3 bytes off alignment", buf, bytes - 256, occ, out, a, b);
+			run<2>("128-B line, 8 loads of one lane", buf, bytes - 256, occ, out, a, b);
+			run<8>("128 B from 3 bytes off, 8 loads", buf, bytes - 256, occ, out, a, b);
+			run<4>("128-B line, LDS-DMA", buf, bytes - 256, occ, out, a, b);
+			run<9>("128 B from 3 bytes off, LDS-DMA", buf, bytes - 256, occ, out, a, b);
+		}
+		return 0;
+	}
 	for (size_t bytes : {(size_t)1 << 30, (size_t)128 << 20, (size_t)16 << 20}) {
 		printf("---- footprint %zu MiB\n", bytes >> 20);
 		for (int occ : {8, 4, 3}) {
