@@ -10,7 +10,7 @@
 
 // -DANDI_LANE_STATS: count the memory accesses of pass A by kind (diagnostic builds only)
 #ifdef ANDI_LANE_STATS
-static __device__ unsigned long long g_lane_stats[16];
+static __device__ unsigned long long g_lane_stats[24];
 #define STAT(k) atomicAdd(&g_lane_stats[k], 1ull)
 #else
 #define STAT(k) ((void)0)
@@ -22,7 +22,8 @@ static __device__ unsigned long long g_lane_stats[16];
 #define KNOCK(c, bit) false
 #endif
 enum { ST_STEP, ST_LCP_RELOAD, ST_LCP_SLIDE, ST_PROBE, ST_PROBE_RELOAD, ST_TABLE, ST_FINAL_SA, ST_SINGLE, ST_EXT_LOOP,
-	   ST_MULTI, ST_MULTI_CAND, ST_SEARCH, ST_GAP_RELOAD, ST_GAP_WORDS, ST_SUBST, ST_LUCKY_TRY };
+	   ST_MULTI, ST_MULTI_CAND, ST_SEARCH, ST_GAP_RELOAD, ST_GAP_WORDS, ST_SUBST, ST_LUCKY_TRY,
+	   ST_X0, ST_X1, ST_X2, ST_X3, ST_X4, ST_X5, ST_X6, ST_X7 };
 
 constexpr uint32_t WNT = 32; // symbols per window
 constexpr uint32_t EMPTY = ~0u;

@@ -505,6 +505,103 @@ __device__ __forceinline__ void lane_cold_stream(const ScanArgs &a, const LaneIt
 	for (int t = 0; t < 4; ++t) dst[t] = make_uint4(out[4 * t], out[4 * t + 1], out[4 * t + 2], out[4 * t + 3]);
 }
 
+__device__ __forceinline__ uint32_t dpp_quad_floor(uint32_t v, int ctrl) { // quad_perm: broadcast lane `ctrl`, or lane ^ 1 (4), lane ^ 2 (5)
+	switch (ctrl) {
+		case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true);
+		case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, true);
+		case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, true);
+		case 3: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, true);
+		case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+		default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+	}
+}
+
+__device__ __forceinline__ void quad_transpose_floor(uint4 (&R)[4], uint32_t qi) { // R[r] of quad lane i <- R[i] of quad lane r
+	auto sel = [](bool c, const uint4 &a, const uint4 &b) { return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); };
+	auto dpp4 = [](const uint4 &v, int ctrl) {
+		return make_uint4(dpp_quad_floor(v.x, ctrl), dpp_quad_floor(v.y, ctrl), dpp_quad_floor(v.z, ctrl), dpp_quad_floor(v.w, ctrl));
+	};
+	const bool odd = qi & 1u, high = qi & 2u;
+	uint4 a = dpp4(sel(odd, R[0], R[1]), 4), b = dpp4(sel(odd, R[2], R[3]), 4);
+	R[0] = sel(odd, a, R[0]), R[1] = sel(odd, R[1], a), R[2] = sel(odd, b, R[2]), R[3] = sel(odd, R[3], b);
+	a = dpp4(sel(high, R[0], R[2]), 5), b = dpp4(sel(high, R[1], R[3]), 5);
+	R[0] = sel(high, a, R[0]), R[2] = sel(high, R[2], a), R[1] = sel(high, b, R[1]), R[3] = sel(high, R[3], b);
+}
+
+// Diagnostic (ANDI_FLOOR=v, results are wrong on purpose): what a lane-per-segment stream along the main diagonal
+// of the forward strand costs with nothing of the chain logic (v = 1: load, compare, count mismatching symbols),
+// with the work of an anchor per mismatch (v = 2), two windows per trip (v = 3, 4), and with the streams fetched
+// by quads of lanes -- 64 consecutive bytes per load instruction and quad, a 4 x 4 transpose by DPP (v = 5): the
+// floors under any pass A that reads its streams one of these ways (profiles/r02_stream/floor.txt).
+__global__ __launch_bounds__(BLOCK, 6) void k_stream_floor(ScanArgs a, int variant) {
+	__shared__ uint32_t s_hist[16 * BLOCK];
+	const LaneItem it = lane_item(a);
+	if (!it.valid) return;
+	Tally tally;
+	tally_begin<1>(tally, s_hist + threadIdx.x);
+	PairCtx c = make_ctx(a, it.sub, it.qidx);
+	const int32_t dg = (int32_t)(c.E.n / 2 + 1); // query position x of an indel-free descendant lies at RS[x + L + 1]
+	uint32_t mism = 0, lastQ = it.start, anchors = 0;
+	if (variant == 5) { // quads: 64 consecutive bytes of one lane's streams per load instruction, 4 x 4 transpose
+		const uint32_t qi = threadIdx.x & 3u;
+		for (uint32_t x = it.start & ~1u; x < it.end; x += 4 * WNT) {
+			uint4 Rq[4], Rs[4];
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const uint32_t ox = dpp_quad_floor(x, r);
+				Rq[r] = ld_query(c, ox + WNT * qi);
+				Rs[r] = ld_subject(c, (int32_t)(ox + WNT * qi) + dg);
+			}
+			quad_transpose_floor(Rq, qi);
+			quad_transpose_floor(Rs, qi);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint4 d = neq32(Rq[k], Rs[k]);
+				mism += __builtin_popcount(d.x) + __builtin_popcount(d.y) + __builtin_popcount(d.z) + __builtin_popcount(d.w);
+			}
+		}
+		a.exit_p[it.slot] = mism;
+		return;
+	}
+	const uint32_t step = variant >= 3 ? 2 * WNT : WNT;
+	for (uint32_t x = it.start & ~1u; x < it.end; x += step) {
+		const uint4 q0 = ld_query(c, x), s0 = ld_subject(c, (int32_t)x + dg);
+		uint4 q1 = q0, s1 = s0;
+		if (variant >= 3) q1 = ld_query(c, x + WNT), s1 = ld_subject(c, (int32_t)(x + WNT) + dg);
+		for (int h = 0; h < (variant >= 3 ? 2 : 1); ++h) {
+			const uint4 qv = h ? q1 : q0, sv = h ? s1 : s0, d = neq32(qv, sv);
+			if (variant == 1 || variant == 3) {
+				mism += __builtin_popcount(d.x) + __builtin_popcount(d.y) + __builtin_popcount(d.z) + __builtin_popcount(d.w);
+			} else {
+				uint32_t o = 0;
+				for (;;) { // every mismatch ends an anchor: count it as pass A's fast path would
+					const uint32_t f = first_from(d, o);
+					if (f >= WNT) break;
+					const uint32_t pos = x + h * WNT + f, len = pos - lastQ;
+					if (len >= c.thr) {
+						count_equal(tally, len);
+						const uint32_t sh = 4 * (f & 7u);
+						const uint32_t qn = (pick(qv, f >> 3) >> sh) & 15u, sn = (pick(sv, f >> 3) >> sh) & 15u;
+						if (!((qn | sn) & 4u)) atomicAdd(&tally.hist[(((sn & 3u) << 2) | (qn & 3u)) * BLOCK], 1u);
+						++anchors;
+					}
+					lastQ = pos + 1;
+					o = f + 1;
+					if (o >= WNT) break;
+				}
+			}
+		}
+	}
+	tally_finish<1>(tally);
+	ChainState st = initial_state();
+	st.p = it.end, st.lastQ = lastQ, st.lastLen = mism + anchors;
+	a.cold_exit[it.slot] = st;
+	a.exit_p[it.slot] = st.p;
+	uint32_t *dst = a.cold_counts + it.slot * 16;
+	for (int t = 0; t < 16; ++t) dst[t] = tally.hist[t * BLOCK];
+	a.marks[it.slot * ANDI_COLD_MARKS].st.pad[0] = 0;
+}
+
 template <bool EXACT, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void k_lane_stream(ScanArgs a) {
 	__shared__ uint32_t s_hist[16 * BLOCK];
@@ -841,6 +938,10 @@ template <bool EXACT>
 static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	const char *pe = getenv("ANDI_LANE_LDS_PAD"); // experiments: unused LDS per block, limits the resident wavefronts
 	const size_t pad = pe ? (size_t)atoi(pe) : 0;
+	if (const char *fl = getenv("ANDI_FLOOR")) { // diagnostic: the cost of the bare streams (wrong results)
+		k_stream_floor<<<grid, BLOCK, 0, st>>>(a, atoi(fl));
+		return hipGetLastError();
+	}
 	const bool stream = getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) != 0; // measured slower: an experiment
 	if (stream) {
 		switch (lane_occupancy()) {
@@ -882,13 +983,13 @@ hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st) {
 	hipError_t e = a.exact_equal ? lane_cold<true>(a, grid, st) : lane_cold<false>(a, grid, st);
 #ifdef ANDI_LANE_STATS
 	if (e == hipSuccess && getenv("ANDI_LANE_STATS")) {
-		static const char *names[16] = {"steps", "lcp_reload", "lcp_slide", "probes", "probe_reload", "table", "final_sa",
+		static const char *names[24] = {"steps", "lcp_reload", "lcp_slide", "probes", "probe_reload", "table", "final_sa",
 										"single", "ext_loop", "multi", "multi_cand", "search", "gap_reload", "gap_words",
-										"substitutions", "lucky_tries"};
-		unsigned long long h[16];
+										"substitutions", "lucky_tries", "x0", "x1", "x2", "x3", "x4", "x5", "x6", "x7"};
+		unsigned long long h[24];
 		(void)hipStreamSynchronize(st);
 		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lane_stats), sizeof h);
-		for (int k = 0; k < 16; ++k) fprintf(stderr, "lane_stats %-14s %llu\n", names[k], h[k]);
+		for (int k = 0; k < 24; ++k) fprintf(stderr, "lane_stats %-14s %llu\n", names[k], h[k]);
 		memset(h, 0, sizeof h);
 		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), h, sizeof h);
 	}
