@@ -59,6 +59,10 @@ struct andi_hip_ctx {
 	size_t desc_bytes = 0;
 	hipEvent_t desc_done = nullptr;
 	unsigned long long *d_fixups = nullptr;
+	// batched index builds: items (pinned host + device), guarded by ib_done
+	void *ib_host = nullptr, *ib_dev = nullptr;
+	size_t ib_cap = 0;
+	hipEvent_t ib_done = nullptr;
 	// device suffix sorter: workspace, two pinned ints
 	void *sa_ws = nullptr;
 	size_t sa_ws_bytes = 0;
@@ -276,6 +280,9 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
 	if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
 	if (ctx->d_fixups) (void)hipFree(ctx->d_fixups);
+	if (ctx->ib_dev) (void)hipFree(ctx->ib_dev);
+	if (ctx->ib_host) (void)hipHostFree(ctx->ib_host);
+	if (ctx->ib_done) (void)hipEventDestroy(ctx->ib_done);
 	if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
 	if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
 	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
@@ -483,6 +490,47 @@ int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	t.stop();
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index", err);
 	e->index_built = true;
+	return 0;
+}
+
+int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas, size_t count) {
+	if (!ctx || !esas || count == 0 || count > 65535) {
+		if (ctx) ctx->err = "andi_hip_esa_build_index_batch: bad arguments";
+		return 1;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (ctx->ib_cap < count) {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->ib_dev) (void)hipFree(ctx->ib_dev);
+		if (ctx->ib_host) (void)hipHostFree(ctx->ib_host);
+		ctx->ib_dev = ctx->ib_host = nullptr, ctx->ib_cap = 0;
+		const size_t cap = std::max<size_t>(count, 64);
+		HIP_TRY(ctx, hipMalloc(&ctx->ib_dev, cap * sizeof(AndiIndexBatchItem)));
+		HIP_TRY(ctx, hipHostMalloc(&ctx->ib_host, cap * sizeof(AndiIndexBatchItem), hipHostMallocDefault));
+		if (!ctx->ib_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ib_done, hipEventDisableTiming));
+		ctx->ib_cap = cap;
+	} else {
+		HIP_TRY(ctx, hipEventSynchronize(ctx->ib_done)); // the previous batch's items have been copied
+	}
+	auto *items = (AndiIndexBatchItem *)ctx->ib_host;
+	int32_t max_n = 0;
+	for (size_t k = 0; k < count; ++k) {
+		andi_hip_esa *e = esas[k];
+		if (!e) {
+			ctx->err = "andi_hip_esa_build_index_batch: null subject";
+			return 1;
+		}
+		items[k].S = e->S, items[k].SA = e->SA, items[k].deep = e->deep, items[k].N0 = e->N0, items[k].N1 = e->N1;
+		items[k].flags = e->flags, items[k].n = e->n, items[k].deepK = e->deepK;
+		max_n = std::max(max_n, e->n);
+	}
+	Timed t(ctx, 0);
+	hipError_t err = hipMemcpyAsync(ctx->ib_dev, ctx->ib_host, count * sizeof(AndiIndexBatchItem), hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess) err = hipEventRecord(ctx->ib_done, ctx->stream);
+	if (err == hipSuccess) err = andi_launch_index_build_batch((const AndiIndexBatchItem *)ctx->ib_dev, (uint32_t)count, max_n, ctx->stream);
+	t.stop();
+	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index_batch", err);
+	for (size_t k = 0; k < count; ++k) esas[k]->index_built = true;
 	return 0;
 }
 
@@ -1194,7 +1242,6 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 				}
 				if (ok && esa_upload(D.ctx, D.slots[b], p->RS, o.sa_on_host ? p->SA.data() : nullptr, p->n, p->thr)) bail("staging subject"), ok = false;
 				if (ok && !o.sa_on_host && esa_sort_suffixes(D.ctx, D.slots[b])) bail("suffix array"), ok = false;
-				if (ok && andi_hip_esa_build_index(D.ctx, D.slots[b])) bail("index build"), ok = false;
 				self[b] = (int64_t)(i0 + b);
 				andi_hip_free(p->RS);
 				delete p;
@@ -1205,6 +1252,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 				cv.notify_all();
 				if (!ok) return;
 			}
+			if (andi_hip_esa_build_index_batch(D.ctx, D.slots.data(), nb)) return bail("index build");
 			andi_hip_model *dst = use_rccl ? D.d_rows + (i0 - first[d]) * n : D.d_rows;
 			if (andi_hip_scan_rows(D.ctx, D.slots.data(), self.data(), nb, D.Q, o.model, o.segment, dst)) return bail("scan");
 			if (!use_rccl && andi_hip_copy_to_host(D.ctx, M + i0 * n, dst, nb * n * sizeof(andi_hip_model))) return bail("row copy");

@@ -27,7 +27,21 @@ struct EsaBuildArgs {
 	int32_t n;
 };
 
+// one subject of a batched scan-index build
+struct AndiIndexBatchItem {
+	const uint8_t *S;  // text (pack_symbols' source)
+	const int32_t *SA;
+	uint2 *deep;
+	uint8_t *N0, *N1;
+	int32_t *flags;
+	int32_t n, deepK;
+};
+
 size_t andi_min_tree_entries(int32_t n);
+// the scan indexes of `count` subjects (device array of items) in two launches; max_n = the longest text
+hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, hipStream_t st);
+// (scan_lane.hip) packed symbols of the items' texts, `bytes` source bytes each at most (shorter texts stop at their own end)
+hipError_t andi_launch_pack_symbols_batch(const AndiIndexBatchItem *d_items, uint32_t count, size_t bytes, hipStream_t st);
 // reference arrays LCP, CLD, FVC, tab (esa_init_LCP/_CLD/_FVC/_cache)
 hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st);
 // scan index: deep, side, flags from S and SA alone

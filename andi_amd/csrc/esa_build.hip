@@ -336,10 +336,9 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 #define PT_BLOCK 256
 #define PT_GAPS 2 /* gaps per thread: two independent gathers in flight per thread */
 #define PT_TILE (PT_BLOCK * PT_GAPS)
-__global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restrict__ N0,
-														  const int32_t *__restrict__ SA,
-														  uint2 *__restrict__ deep,
-														  int32_t *__restrict__ flags, int32_t n, int K, int single_ext) {
+__device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
+												  uint2 *__restrict__ deep, int32_t *__restrict__ flags, int32_t n, int K,
+												  int single_ext, uint32_t block) {
 	__shared__ uint32_t s_off[PT_TILE + 1]; // exclusive prefix sums of the gaps' entry counts
 	__shared__ uint32_t s_first[PT_TILE];   // first code a gap owns
 	__shared__ uint32_t s_absent[PT_TILE];  // number of absent codes it owns (they come first)
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 	__shared__ uint32_t s_wave[PT_BLOCK / 64];
 	__shared__ uint32_t s_rec[PT_TILE + 3]; // rec of the suffixes r0 - 2 .. r0 + PT_TILE
 
-	const int64_t r0 = (int64_t)blockIdx.x * PT_TILE;
+	const int64_t r0 = (int64_t)block * PT_TILE;
 	// the suffixes' records are made here (they used to be a kernel and an array of their own)
 	{
 		uint32_t mine[PT_GAPS];
@@ -529,6 +528,19 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 	}
 }
 
+__global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
+														  uint2 *__restrict__ deep, int32_t *__restrict__ flags, int32_t n, int K,
+														  int single_ext) {
+	probe_table_block(N0, SA, deep, flags, n, K, single_ext, blockIdx.x);
+}
+
+// the tables of several subjects in one launch (blockIdx.y = subject): no launch gaps, one tail
+__global__ __launch_bounds__(PT_BLOCK) void k_probe_table_batch(const AndiIndexBatchItem *__restrict__ items, int single_ext) {
+	const AndiIndexBatchItem it = items[blockIdx.y];
+	if ((int64_t)blockIdx.x * PT_TILE > (int64_t)it.n) return;
+	probe_table_block(it.N0, it.SA, it.deep, it.flags, it.n, it.deepK, single_ext, blockIdx.x);
+}
+
 // ---------------------------------------------------------------- host side
 size_t andi_min_tree_entries(int32_t n) {
 	size_t total = 0;
@@ -548,6 +560,16 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
 	if (e != hipSuccess) return e;
 	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_TILE - 1) / PT_TILE), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.deep, a.flags, n,
 																				  a.deepK, andi_rounds_lines() != 0);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, hipStream_t st) {
+	if (count == 0) return hipSuccess;
+	hipError_t e = andi_launch_pack_symbols_batch(d_items, count, (size_t)max_n + 1 + 64, st);
+	if (e != hipSuccess) return e;
+	const dim3 grid((unsigned)(((int64_t)max_n + 1 + PT_TILE - 1) / PT_TILE), count);
+	k_probe_table_batch<<<grid, PT_BLOCK, 0, st>>>(d_items, andi_rounds_lines() != 0);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }

@@ -15,6 +15,7 @@
 //
 // The chain logic, the probe table and the three-pass scheme (cold chains,
 // stitch, reduce) are those of scan.hip; the results are bit-identical.
+#include "esa_build.h"
 #include "lane_dev.h"
 
 #include <algorithm>
@@ -892,9 +893,8 @@ __device__ __forceinline__ bool in_alphabet(uint8_t ch) {
 
 // word j of N0 = symbols 8j .. 8j+7, word j of N1 = symbols 8j-1 .. 8j+6.  One thread
 // packs 16 bytes (two words of each copy) through a 256-entry table in LDS.
-__global__ __launch_bounds__(256) void k_pack_symbols(const uint8_t *__restrict__ src, int64_t pairs,
-													  uint2 *__restrict__ N0, uint2 *__restrict__ N1,
-													  int32_t *__restrict__ foreign) {
+__device__ __forceinline__ void pack_symbols_block(const uint8_t *__restrict__ src, int64_t pairs, uint2 *__restrict__ N0,
+													uint2 *__restrict__ N1, int32_t *__restrict__ foreign) {
 	__shared__ uint8_t lut[256]; // symbol | 0x80 if the byte is outside the alphabet
 	lut[threadIdx.x] = (uint8_t)(symbol_of((uint8_t)threadIdx.x) | (in_alphabet((uint8_t)threadIdx.x) ? 0u : 0x80u));
 	__syncthreads();
@@ -917,7 +917,26 @@ __global__ __launch_bounds__(256) void k_pack_symbols(const uint8_t *__restrict_
 	}
 }
 
+__global__ __launch_bounds__(256) void k_pack_symbols(const uint8_t *__restrict__ src, int64_t pairs,
+													  uint2 *__restrict__ N0, uint2 *__restrict__ N1,
+													  int32_t *__restrict__ foreign) {
+	pack_symbols_block(src, pairs, N0, N1, foreign);
+}
+
+__global__ __launch_bounds__(256) void k_pack_symbols_batch(const AndiIndexBatchItem *__restrict__ items) {
+	const AndiIndexBatchItem it = items[blockIdx.y];
+	pack_symbols_block(it.S, ((int64_t)it.n + 1 + 64 + 15) / 16, (uint2 *)it.N0, (uint2 *)it.N1, it.flags + 1);
+}
+
 } // namespace
+
+hipError_t andi_launch_pack_symbols_batch(const AndiIndexBatchItem *d_items, uint32_t count, size_t bytes, hipStream_t st) {
+	const int64_t pairs = (int64_t)((bytes + 15) / 16);
+	if (pairs == 0 || count == 0) return hipSuccess;
+	k_pack_symbols_batch<<<dim3((unsigned)((pairs + 255) / 256), count), 256, 0, st>>>(d_items);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
 
 hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N0, uint8_t *N1,
 									int32_t *foreign, hipStream_t st) {

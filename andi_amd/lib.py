@@ -101,6 +101,7 @@ SYMBOLS = {
     "andi_hip_esa_download_sa": (C.c_int, [_P, _P, _P]),
     "andi_hip_esa_build": (C.c_int, [_P, _P]),
     "andi_hip_esa_build_index": (C.c_int, [_P, _P]),
+    "andi_hip_esa_build_index_batch": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "andi_hip_esa_flags": (C.c_int, [_P, _P, _P]),
     "andi_hip_esa_download": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "andi_hip_esa_free": (None, [_P, _P]),
@@ -379,6 +380,13 @@ def match_positions(esa: Esa, queries: Queries, qidx, first, count, cached=True)
     esa.ctx._check(load().andi_hip_match_positions(esa.ctx._h, esa._h, queries._h, qidx, first, count,
                                                    int(cached), out.ctypes.data), "match_positions")
     return out
+
+
+def build_indexes(ctx: Context, esas):
+    """the scan indexes (probe tables) of several subjects in one pair of launches"""
+    n = len(esas)
+    hs = (_P * n)(*[e._h for e in esas])
+    ctx._check(load().andi_hip_esa_build_index_batch(ctx._h, hs, n), "esa_build_index_batch")
 
 
 def scan_rows_dev(ctx: Context, esas, selfs, queries: Queries, model, segment, dptr):

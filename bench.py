@@ -159,8 +159,7 @@ def main():
     dptr = andi_amd.lib._P(block.data_ptr())
 
     def step():
-        for e in esas:
-            e.build()  # device index build
+        lib.build_indexes(ctx, esas)  # device index builds (probe tables), all subjects in one pair of launches
         lib.scan_rows_dev(ctx, esas, selfs, Q, model, args.segment, dptr)  # anchor scan
         ctx.sync()  # the engine's stream is not torch's: finish before the collective
         if use_dist:  # RCCL over xGMI: the one exchange of the job, 68 B per ordered pair

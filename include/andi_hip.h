@@ -147,6 +147,8 @@ int andi_hip_esa_build(andi_hip_ctx *ctx, andi_hip_esa *esa);
  * a separator (flags[0], see andi_hip_esa_flags), andi_hip_scan_rows builds
  * the reference arrays for that subject and follows the reference's walk. */
 int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *esa);
+/* The same for several staged subjects in two launches (no launch gaps, one tail). */
+int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas, size_t count);
 /* flags[0]: see above; flags[2]: the 10-mer table kernel really produced such an
  * entry (only after andi_hip_esa_build). */
 int andi_hip_esa_flags(andi_hip_ctx *ctx, const andi_hip_esa *esa, int32_t *flags4);

@@ -169,3 +169,23 @@ def test_scan_on_device_built_suffix_arrays(ctx, orc):
     assert (andi_amd.dist_matrix(seqs, host_threads=2, sa_on_host=True) == want).all()
     with pytest.raises(andi_amd.AndiHipError, match="outside"):
         andi_amd.Esa(ctx, seqs[0][:500] + b"N" + seqs[0][500:1000], sa="device")
+
+
+def test_index_builds_in_one_batch(ctx, orc):
+    """andi_hip_esa_build_index_batch: the scan indexes of several subjects of different lengths (and one that
+    needs the reference walk) in one pair of launches; the scan on them equals the oracle."""
+    import andi_amd
+    from andi_amd import synth
+    rng = np.random.default_rng(8)
+    base = synth.base_codes(90000, 41)
+    seqs = [synth.to_bytes(synth.mutate_codes(base, d, 70 + k))[: 90000 - 7000 * k] for k, d in enumerate((0.0, 0.01, 0.05))]
+    seqs += [rand_dna(rng, 300), synth.join_contigs(seqs[1], 5, seed=3), b"ACGT" * 2000]
+    want = orc.dist_matrix(seqs, threads=0)
+    Q = andi_amd.Queries(ctx, seqs)
+    esas = [andi_amd.Esa(ctx, s, sa="device", build=False) for s in seqs]
+    andi_amd.lib.build_indexes(ctx, esas)
+    got = andi_amd.scan_rows(ctx, esas, list(range(len(seqs))), Q)
+    assert (got == want).all()
+    for e in esas:
+        e.close()
+    Q.close()
