@@ -49,6 +49,8 @@ struct EventPair {
 struct andi_hip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t side_stream = nullptr; // pass A's second kernel runs beside the first
+	hipEvent_t side_fork = nullptr, side_join = nullptr;
 	std::string err;
 	// scan scratch
 	void *scratch = nullptr;
@@ -259,6 +261,9 @@ int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t err
 	auto *ctx = new andi_hip_ctx;
 	ctx->device = device;
 	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
@@ -286,6 +291,12 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
 	if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
 	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
+	if (ctx->side_stream) {
+		(void)hipStreamSynchronize(ctx->side_stream);
+		(void)hipStreamDestroy(ctx->side_stream);
+	}
+	if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+	if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -877,6 +888,10 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	{
 		const char *mp = getenv("ANDI_ROUNDS_PASSES");
 		a.max_passes = mp && atoi(mp) > 0 ? (uint32_t)atoi(mp) : 3u;
+		const char *qm = getenv("ANDI_QUAD_MATCH"); // experiments: mean match length from which a pair goes to k_lane_quad (0: all, -1: none)
+		a.quad_min_match = qm ? (uint32_t)atoi(qm) : 128u;
+		a.quad_all = 0;
+		a.side_stream = ctx->side_stream, a.side_fork = ctx->side_fork, a.side_join = ctx->side_join;
 		const char *kn = getenv("ANDI_KNOCK");
 		a.knock = kn ? (uint32_t)atoi(kn) : 0u;
 	}

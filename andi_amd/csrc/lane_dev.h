@@ -112,6 +112,7 @@ __device__ __forceinline__ bool lane_kmer(const LWin &w, uint32_t o, uint32_t K,
 // 64 * W; all its lanes work on that pair.
 struct LaneItem {
 	uint32_t sub, qidx, seg_in_q, start, end, seg;
+	uint32_t cls; // per-pair segment lengths: the pair's pair_class byte (bits 0-1 the class of its segment length, bit 7: long matches), else 0
 	size_t slot;
 	bool valid;
 };
@@ -127,7 +128,7 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 		const uint32_t w = blockIdx.x * NT + threadIdx.x;
 		it.valid = w < a.total_segs;
 		it.qidx = it.seg_in_q = it.start = it.end = 0;
-		it.seg = a.seg;
+		it.seg = a.seg, it.cls = 0;
 		it.slot = (size_t)it.sub * a.total_segs + w;
 		if (it.valid) {
 			it.qidx = a.seg2query[w];
@@ -142,7 +143,7 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 	const uint32_t P = a.nsub * a.nq;
 	const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NT / 64) + (threadIdx.x >> 6)));
 	it.valid = false;
-	it.sub = it.qidx = it.seg_in_q = it.start = it.end = it.seg = 0, it.slot = 0;
+	it.sub = it.qidx = it.seg_in_q = it.start = it.end = it.seg = it.cls = 0, it.slot = 0;
 	if (W >= a.pair_wave0[P]) return it;
 	uint32_t lo = 0, hi = P; // the last pair whose first wavefront is <= W (pairs without work share their successor's)
 	while (hi - lo > 1) {
@@ -151,9 +152,9 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 	}
 	const uint32_t pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
 	it.sub = pair / a.nq, it.qidx = pair % a.nq;
-	const uint32_t seg = a.seg0 << a.pair_class[pair], qlen = a.qlen[it.qidx];
+	const uint32_t seg = a.seg0 << (a.pair_class[pair] & 3u), qlen = a.qlen[it.qidx];
 	it.seg_in_q = (W - a.pair_wave0[pair]) * 64 + (threadIdx.x & 63u);
-	it.seg = seg;
+	it.seg = seg, it.cls = a.pair_class[pair];
 	it.start = it.seg_in_q * seg;
 	it.valid = it.start < qlen;
 	it.end = it.start + seg < qlen ? it.start + seg : qlen;
@@ -171,7 +172,7 @@ __device__ __forceinline__ LaneItem lane_item_of_slot(const ScanArgs &a, unsigne
 		const uint32_t w = (uint32_t)(slot % a.total_segs);
 		it.qidx = a.seg2query[w];
 		it.seg_in_q = w - a.qseg_start[it.qidx];
-		it.seg = a.seg;
+		it.seg = a.seg, it.cls = 0;
 		const uint32_t qlen = a.qlen[it.qidx];
 		it.start = it.seg_in_q * a.seg;
 		it.end = it.start + a.seg < qlen ? it.start + a.seg : qlen;
@@ -184,10 +185,17 @@ __device__ __forceinline__ LaneItem lane_item_of_slot(const ScanArgs &a, unsigne
 		if (a.pair_wave0[mid] <= W) lo = mid; else hi = mid;
 	}
 	it.sub = lo / a.nq, it.qidx = lo % a.nq;
-	it.seg = a.seg0 << a.pair_class[lo];
+	it.seg = a.seg0 << (a.pair_class[lo] & 3u), it.cls = a.pair_class[lo];
 	const uint32_t qlen = a.qlen[it.qidx];
 	it.seg_in_q = (W - a.pair_wave0[lo]) * 64 + (uint32_t)(slot & 63u);
 	it.start = it.seg_in_q * it.seg;
 	it.end = it.start + it.seg < qlen ? it.start + it.seg : qlen;
 	return it;
+}
+
+// Pairs with long matches (k_pair_estimate: mean sampled match length >= a.quad_min_match) go to k_lane_quad, the
+// others to k_lane_cold; with one segment length for the call no pair is sampled and k_lane_cold takes everything.
+__device__ __forceinline__ bool lane_is_mine(const ScanArgs &a, const LaneItem &it, bool quad_kernel) {
+	const bool quad_pair = a.adaptive && (it.cls & 0x80u);
+	return quad_pair == quad_kernel;
 }

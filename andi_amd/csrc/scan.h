@@ -80,6 +80,14 @@ struct ScanArgs {
 	uint32_t max_waves;   // upper bound (every pair in class 0): the grid
 	int group;         // otherwise: lanes per chain of scan.hip's kernels (2, 4, 8)
 	uint32_t max_passes; // scan_rounds.hip: trips of the compute loop per round
+	// Pairs whose sampled mean match length is at least quad_min_match (per-pair segment lengths only) take pass A with
+	// the streams fetched by quads of lanes (scan_lane.hip: k_lane_quad), the others lane_step's; 0xffffffff: none do
+	uint32_t quad_min_match;
+	uint32_t quad_all; // experiments (ANDI_LANE_STREAM=2): k_lane_quad takes every pair
+	// host side only: a second stream and two events, so that pass A's two kernels (k_lane_quad for the pairs with long
+	// matches, k_lane_cold for the others) share the device instead of each ending in a tail of its own
+	hipStream_t side_stream;
+	hipEvent_t side_fork, side_join;
 	uint32_t knock;      // diagnostic builds (-DANDI_LANE_STATS): parts of pass A switched off to time them (results are then wrong)
 };
 

@@ -177,7 +177,7 @@ __device__ __forceinline__ PairGeom pair_geometry(const ScanArgs &a, uint32_t su
 	const uint32_t pair = sub * a.nq + qidx;
 	PairGeom g;
 	g.slot0 = (size_t)64 * a.pair_wave0[pair];
-	g.seg = a.seg0 << a.pair_class[pair];
+	g.seg = a.seg0 << (a.pair_class[pair] & 3u);
 	g.nseg = (a.qlen[qidx] + g.seg - 1) / g.seg;
 	return g;
 }

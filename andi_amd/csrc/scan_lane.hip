@@ -341,7 +341,8 @@ __global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
 		uint32_t cls = 0;
 		while (cls < a.max_class && (a.seg0 << cls) < want) ++cls;
 		const uint32_t seg = a.seg0 << cls, nseg = (c.qlen + seg - 1) / seg;
-		a.pair_class[pair] = (uint8_t)cls;
+		// bit 7: the pair's matches are long enough for pass A with the streams fetched by quads (k_lane_quad)
+		a.pair_class[pair] = (uint8_t)(cls | ((sum >> 6) >= a.quad_min_match ? 0x80u : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
 	}
 }
@@ -603,6 +604,200 @@ __global__ __launch_bounds__(BLOCK, 6) void k_stream_floor(ScanArgs a, int varia
 	a.marks[it.slot * ANDI_COLD_MARKS].st.pad[0] = 0;
 }
 
+__device__ __forceinline__ bool pos_in(const LWin &w, uint32_t p) {
+	return w.q0 != EMPTY && p >= w.q0 && p - w.q0 < WNT;
+}
+
+// Pass A with ALL streaming along diagonals done by QUADS of lanes (ANDI_LANE_STREAM=2).
+//
+// The floors (k_stream_floor, profiles/r02_stream/floor.txt): a lane that reads its own two streams 16 bytes at a
+// time is one request per load, 70-110 G of which the memory pipeline takes per second -- 3.2 ms for the bench set
+// with nothing but the comparison, and lane_step's pass A runs at 87 % of that request rate; four neighbouring
+// lanes reading 64 consecutive bytes are ONE request: 0.8 ms, 4 x 4 transposes included.
+//
+// Every trip of the wavefront's loop a lane says where it looks next -- at the start of a step: the gap behind its
+// last anchor and the position p on the lucky diagonal (or p alone, for the probe's K-mer); in the middle of a
+// comparison: where that stands -- and its quad fetches the 128 symbols of its two streams from there (four rounds:
+// the four lanes read 64 consecutive bytes of one lane's stream each; a transpose over the quad by DPP hands every
+// lane its own).  Then the lane goes on with its step out of those registers: lcp() of lucky_anchor
+// (src/process.c:59-65, 82-100) or of the one occurrence a probe found, window by window, until it ends or the
+// registers do (it is then resumed on the next trip); when it has ended, the rest of the step -- the probe if the
+// lucky attempt failed, the counting, the bookkeeping -- is lane_step's code.  A probe follows a match only 64
+// symbols by itself (lane_probe's cap); one that goes on is handed to the quads.
+template <bool EXACT>
+__device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem &it, uint32_t *s_hist) {
+	Tally tally;
+	tally_begin<1>(tally, s_hist + threadIdx.x);
+	PairCtx c = make_ctx(a, it.sub, it.qidx);
+	const uint32_t n = (uint32_t)c.E.n, thr = c.thr, qi = threadIdx.x & 3u;
+	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, n);
+	LWin w;
+	w.q0 = EMPTY, w.dg = NO_DIAG;
+	const size_t slot = it.slot;
+	ColdMark *marks = a.marks + slot * ANDI_COLD_MARKS;
+	uint32_t anchors = 0;
+	uint4 Bq[4], Bs[4]; // 128 symbols of the query from b0 (even) and of the subject against them on diagonal bdg
+	uint32_t b0 = EMPTY;
+	int32_t bdg = NO_DIAG;
+	// the comparison in progress: 0 none, 1 lucky_anchor's, 2 along the one occurrence a probe found
+	uint32_t mode = 0, curS = 0, curLen = 0;
+	bool accounted = false;
+	bool active = it.valid && st.p < it.end;
+	constexpr uint32_t PROBE_CAP = 64;
+
+	// make w the piece of the registers that holds query position x (false: they do not hold it)
+	auto point_w_at = [&](uint32_t x) -> bool {
+		bool hit = false;
+		if (b0 == EMPTY) return false;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t w0 = b0 + WNT * k;
+			if (x - w0 < WNT) {
+				w.q0 = w0, w.q = Bq[k], w.dg = bdg, hit = true;
+				if (bdg != NO_DIAG) w.s = Bs[k], w.d = neq32(Bq[k], Bs[k]);
+			}
+		}
+		return hit;
+	};
+
+	while (__any(active)) {
+		// ---- where does the lane look next?
+		uint32_t want = 0;
+		int32_t wdg = NO_DIAG;
+		if (active) {
+			if (mode == 0) { // the top of a step (src/process.c:153)
+				accounted = false;
+				if (lucky_applies(st, n, thr)) {
+					const uint32_t gap = st.p - st.lastQ - st.lastLen;
+					curS = st.lastS + (st.p - st.lastQ), curLen = 0, mode = 1;
+					want = st.p - (gap < 16 ? gap : 16), wdg = (int32_t)(curS - st.p);
+					STAT(ST_LUCKY_TRY);
+				} else {
+					want = st.p; // the probe's K-mer
+				}
+			} else {
+				want = st.p + curLen, wdg = (int32_t)(curS - st.p);
+			}
+		}
+		// ---- its registers, filled by its quad when one of the quad's lanes lacks what it wants
+		const bool lacks = active && (b0 == EMPTY || want < b0 || want - b0 >= 4 * WNT || (wdg != NO_DIAG && wdg != bdg));
+		if (__any(lacks)) {
+			const uint64_t lb = __ballot(lacks);
+			if ((lb >> (__lane_id() & ~3u)) & 0xFu) { // (uniform in the quad: all its active lanes take new registers from where they look)
+				const uint32_t nb0 = want & ~1u;
+				const uint64_t qbase = (uint64_t)(uintptr_t)c.Qn;
+				STAT(ST_LCP_RELOAD);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const bool o_on = dpp_quad_floor(active ? 1u : 0u, r) != 0;
+					const bool o_s = dpp_quad_floor(wdg != NO_DIAG ? 1u : 0u, r) != 0;
+					const uint32_t o_q = dpp_quad_floor(nb0, r), o_sa = dpp_quad_floor(nb0 + (uint32_t)wdg, r);
+					const uint64_t o_base = dpp_quad_floor((uint32_t)qbase, r) | ((uint64_t)dpp_quad_floor((uint32_t)(qbase >> 32), r) << 32);
+					Bq[r] = Bs[r] = make_uint4(0, 0, 0, 0);
+					if (o_on) {
+						Bq[r] = ld_u128_unaligned((g_u8p)(uintptr_t)o_base + ((o_q + WNT * qi) >> 1)); // (the owner's query; the subject is the wavefront's)
+						if (o_s) Bs[r] = ld_subject(c, (int32_t)(o_sa + WNT * qi));
+					}
+				}
+				quad_transpose_floor(Bq, qi);
+				quad_transpose_floor(Bs, qi);
+				b0 = active ? nb0 : EMPTY, bdg = wdg;
+			}
+		}
+		if (!active) continue;
+
+		// ---- the comparison, out of the registers
+		bool ended = mode == 0; // (no comparison to make: straight to the probe)
+		if (mode != 0) {
+			const uint32_t maxlen = c.qlen - st.p;
+			uint32_t pos = st.p + curLen;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t w0 = b0 + WNT * k;
+				if (!ended && pos - w0 < WNT) {
+					const uint4 d = neq32(Bq[k], Bs[k]);
+					const uint32_t o = pos - w0, f = first_from(d, o);
+					curLen += f - o, pos += f - o;
+					if (f < WNT || curLen >= maxlen) ended = true;
+				}
+			}
+			if (curLen > maxlen) curLen = maxlen;
+			if (!ended && !accounted && mode == 1 && curLen >= thr && maxlen >= thr) {
+				// certainly an anchor already: count the gap behind it while the registers hold it (src/process.c:157-190)
+				if (!point_w_at(st.lastQ + st.lastLen)) w.q0 = EMPTY;
+				lane_account<EXACT>(c, st, tally, w, curS);
+				accounted = true;
+			}
+		}
+		if (!ended) continue; // resumed on the next trip
+
+		// ---- the rest of the step (src/process.c:113-197)
+		STAT(ST_STEP);
+		bool found = mode != 0 && curLen >= thr; // (mode 2: the occurrence is the only one)
+		if (!found && mode != 2) {
+			if (!point_w_at(st.p)) w.q0 = EMPTY; // the probe starts from the window that holds p
+			Probe pr = lane_probe(c, st.p, w, PROBE_CAP);
+			if (pr.len >= PROBE_CAP && PROBE_CAP < c.qlen - st.p) {
+				if (pr.unique) { // the match goes on: follow it with the quads
+					curS = pr.pos, curLen = PROBE_CAP, mode = 2, accounted = false;
+					continue;
+				}
+				pr = lane_probe(c, st.p, w); // several occurrences match that far: the whole answer, by the lane itself
+			}
+			curS = pr.pos, curLen = pr.len;
+			found = pr.unique && curLen >= thr;
+		}
+		if (found) {
+			if (!accounted) {
+				if (mode != 0) (void)point_w_at(st.lastQ + st.lastLen); // the gap behind a lucky anchor is in the registers (lane_count_gap checks)
+				lane_account<EXACT>(c, st, tally, w, curS);
+			}
+			st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
+		}
+		st.p += curLen + 1;
+		mode = 0;
+		if (found && ++anchors == 1) *(uint4 *)marks[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
+		if (found && anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
+			ColdMark *m = marks + (anchors - 2);
+			ChainState ms = st;
+			ms.pad[0] = 1;
+			m->st = ms;
+			uint32_t v[16];
+#pragma unroll
+			for (int t = 0; t < 16; ++t) v[t] = tally.hist[t * BLOCK];
+			v[0] += tally.quarter + tally.same[0], v[5] += tally.quarter + tally.same[1];
+			v[10] += tally.quarter + tally.same[2], v[15] += tally.quarter + tally.rest + tally.same[3];
+			uint4 *mc = (uint4 *)m->counts;
+#pragma unroll
+			for (int t = 0; t < 4; ++t) mc[t] = make_uint4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
+		}
+		active = st.p < it.end;
+	}
+	if (!it.valid) return;
+	for (uint32_t k = anchors < 2 ? 0 : anchors - 1; k < ANDI_COLD_MARKS; ++k) marks[k].st.pad[0] = 0; // unused marks
+
+	st.pad[1] = anchors < 255 ? anchors : 255;
+	a.cold_exit[slot] = st;
+	a.exit_p[slot] = st.p;
+	tally_finish<1>(tally);
+	uint32_t out[16];
+#pragma unroll
+	for (int t = 0; t < 16; ++t) out[t] = tally.hist[t * BLOCK];
+	uint4 *dst = (uint4 *)(a.cold_counts + slot * 16);
+#pragma unroll
+	for (int t = 0; t < 4; ++t) dst[t] = make_uint4(out[4 * t], out[4 * t + 1], out[4 * t + 2], out[4 * t + 3]);
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(BLOCK, 4) void k_lane_quad(ScanArgs a) {
+	__shared__ uint32_t s_hist[16 * BLOCK];
+	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
+	LaneItem it = lane_item(a);
+	if (!a.quad_all && !lane_is_mine(a, it, true)) it.valid = false; // (a wavefront is one pair's: all or none)
+	if (!__any(it.valid)) return;
+	lane_cold_quad<EXACT>(a, it, s_hist);
+}
+
 template <bool EXACT, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void k_lane_stream(ScanArgs a) {
 	__shared__ uint32_t s_hist[16 * BLOCK];
@@ -621,7 +816,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 	__shared__ uint32_t s_hist[16 * BLOCK];
 	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
 	const LaneItem it = lane_item(a);
-	if (!it.valid) return;
+	if (!it.valid || !lane_is_mine(a, it, false)) return;
 	Tally tally;
 	tally_begin<1>(tally, s_hist + threadIdx.x);
 
@@ -961,8 +1156,14 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 		k_stream_floor<<<grid, BLOCK, 0, st>>>(a, atoi(fl));
 		return hipGetLastError();
 	}
+	if (getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) == 2) { // experiments: everything through the quads
+		ScanArgs b = a;
+		b.quad_all = 1;
+		k_lane_quad<EXACT><<<grid, BLOCK, 0, st>>>(b);
+		return hipGetLastError();
+	}
 	const bool stream = getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) != 0; // measured slower: an experiment
-	if (stream) {
+	if (stream) { // (k_lane_stream knows no classes: it takes every pair)
 		switch (lane_occupancy()) {
 			case 4: k_lane_stream<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
 			case 6: k_lane_stream<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break;
@@ -970,11 +1171,22 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 		}
 		return hipGetLastError();
 	}
+	const bool quads = a.adaptive && a.quad_min_match != 0xffffffffu;
+	const bool side = quads && a.side_stream && !getenv("ANDI_NO_SIDE_STREAM");
+	if (quads) { // the pairs with long matches, beside the others
+		if (side) {
+			(void)hipEventRecord(a.side_fork, st);
+			(void)hipStreamWaitEvent(a.side_stream, a.side_fork, 0);
+		}
+		k_lane_quad<EXACT><<<grid, BLOCK, 0, side ? a.side_stream : st>>>(a);
+		if (side) (void)hipEventRecord(a.side_join, a.side_stream);
+	}
 	switch (lane_occupancy()) {
 		case 4: k_lane_cold<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
 		case 6: k_lane_cold<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break;
 		default: k_lane_cold<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
 	}
+	if (side) (void)hipStreamWaitEvent(st, a.side_join, 0);
 	return hipGetLastError();
 }
 

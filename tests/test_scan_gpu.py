@@ -348,13 +348,35 @@ def test_realistic_divergence_structure(ctx, orc):
     _check_set(ctx, orc, joined, segments=(0, 700))
 
 
-def test_pass_a_as_two_phase_loop_agrees(ctx, orc, monkeypatch):
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_pass_a_variants_agree(ctx, orc, monkeypatch, variant):
     """ANDI_LANE_STREAM=1: pass A with the chain step cut in two (scan_lane.hip: lane_cold_stream) -- every trip
-    the lanes on a diagonal settle one window of it, then the lanes that need one probe together.  An experiment
-    (measured slower than the straight-line step); same counts."""
+    the lanes on a diagonal settle one window of it, then the lanes that need one probe together; an experiment
+    (measured slower than the straight-line step).  ANDI_LANE_STREAM=2: EVERY pair through k_lane_quad -- the
+    streams fetched by quads of lanes, comparisons resumed trip after trip -- which by default takes only the pairs
+    with long matches and only with per-pair segment lengths (here also with one segment length for the call, where
+    the lanes of a quad belong to different queries).  Same counts."""
     from andi_amd import synth
-    monkeypatch.setenv("ANDI_LANE_STREAM", "1")
+    monkeypatch.setenv("ANDI_LANE_STREAM", variant)
     seqs, _ = synth.realistic_set(5, 150000, 0.0005, 0.08, seed=5, novel_fraction=0.05)
     seqs.append(seqs[0])  # identical to its subject: one anchor as long as the sequence
+    seqs.append(synth.to_bytes(synth.mutate_codes(synth.realistic_base(150000, 5), 0.0004, 9)))  # long matches
     _check_set(ctx, orc, seqs, segments=(0, 1024, 77))
     _check_set(ctx, orc, seqs[:3], model=4)
+
+
+def test_pairs_with_long_matches_take_the_quad_kernel(ctx, orc, monkeypatch):
+    """With per-pair segment lengths the pairs whose sampled matches are long (>= 128 symbols on average) go through
+    k_lane_quad, the others through k_lane_cold, side by side on two streams: a set with both kinds, every threshold."""
+    from andi_amd import synth
+    base = synth.base_codes(400000, 77)
+    seqs = [synth.to_bytes(synth.mutate_codes(base, d, 20 + k)) for k, d in enumerate((0.0, 0.0002, 0.001, 0.004, 0.02, 0.06))]
+    seqs.append(synth.join_contigs(seqs[1], 4, seed=9))
+    want = orc.dist_matrix(seqs, threads=0)
+    for env in ({}, {"ANDI_QUAD_MATCH": "0"}, {"ANDI_QUAD_MATCH": "1000"}, {"ANDI_QUAD_MATCH": "-1"}, {"ANDI_NO_SIDE_STREAM": "1"}):
+        for k in ("ANDI_QUAD_MATCH", "ANDI_NO_SIDE_STREAM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, t = _gpu_rows(ctx, seqs)
+        assert t["adaptive_calls"] >= 1 and (got == want).all(), env
