@@ -569,6 +569,18 @@ int andi_hip_esa_download(andi_hip_ctx *ctx, const andi_hip_esa *e, int32_t *LCP
 	return 0;
 }
 
+int andi_hip_esa_download_index(andi_hip_ctx *ctx, const andi_hip_esa *e, uint32_t *table, int *K) {
+	if (!ctx || !e) return 1;
+	if (!e->index_built) {
+		ctx->err = "andi_hip_esa_download_index: scan index not built (call andi_hip_esa_build_index)";
+		return 1;
+	}
+	if (K) *K = e->deepK;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (table) HIP_TRY(ctx, hipMemcpy(table, e->deep, (size_t)8 << (2 * e->deepK), hipMemcpyDeviceToHost));
+	return 0;
+}
+
 void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!e) return;
 	if (ctx) {

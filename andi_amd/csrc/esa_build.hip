@@ -336,6 +336,20 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 #define PT_BLOCK 256
 #define PT_GAPS 2 /* gaps per thread: two independent gathers in flight per thread */
 #define PT_TILE (PT_BLOCK * PT_GAPS)
+#define PT_WORDS (PT_TILE / 64) /* 64-bit ballots that cover the tile: gap i = u * PT_BLOCK + thread is bit i & 63 of word i >> 6 */
+#define PT_RANKED 2048          /* entries of a block whose owners are found by rank (the block's piece is seldom longer) */
+// inclusive prefix sums over the 64 lanes of a wavefront in six DPP additions: shifts by 1, 2, 4, 8 inside the rows
+// of 16 lanes, then lane 15 of a row into the next row, lane 31 into the upper half
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+	return v;
+}
+
 __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
 												  uint2 *__restrict__ deep, int32_t *__restrict__ flags, int32_t n, int K,
 												  int single_ext, uint32_t block) {
@@ -346,8 +360,13 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 	__shared__ uint2 s_present[PT_TILE];    // entry of the K-mer of suffix r, if the gap owns it
 	__shared__ uint32_t s_wave[PT_BLOCK / 64];
 	__shared__ uint32_t s_rec[PT_TILE + 3]; // rec of the suffixes r0 - 2 .. r0 + PT_TILE
+	__shared__ uint64_t s_some[PT_WORDS];   // gap i owns entries
+	__shared__ uint32_t s_bits[PT_RANKED / 32]; // bit t: an owning gap's entries start at t
+	__shared__ uint32_t s_before[PT_RANKED / 32]; // set bits in the words before this one
+	__shared__ uint16_t s_owner[PT_TILE];   // the owning gaps, in order
 
 	const int64_t r0 = (int64_t)block * PT_TILE;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	// the suffixes' records are made here (they used to be a kernel and an array of their own)
 	{
 		uint32_t mine[PT_GAPS];
@@ -361,6 +380,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 	}
 	if (threadIdx.x < 2) s_rec[threadIdx.x] = r0 + threadIdx.x >= 2 ? suffix_rec(N0, SA, (int32_t)(r0 + threadIdx.x - 2), K) : 0u;
 	if (threadIdx.x == 2) s_rec[PT_TILE + 2] = r0 + PT_TILE < n ? suffix_rec(N0, SA, (int32_t)(r0 + PT_TILE), K) : 0u;
+	if (threadIdx.x < PT_RANKED / 32) s_bits[threadIdx.x] = 0;
 	__syncthreads();
 	auto rec = [&](int32_t j) { // 0 <= j < n; inside the block's range from LDS
 		const int64_t k = (int64_t)j - r0 + 2;
@@ -386,19 +406,32 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 
 		if (live) {
 			// (a) present K-mers
-			if (hasR && REC_V(R) == full && !(hasL && REC_V(L) == full && REC_CODE(L) == REC_CODE(R))) {
-				// the end of the run of suffixes with this K-mer: a short walk (runs are short in genomes), then a
-				// binary search over the suffix array -- records of one K-mer are equal, later ones greater -- so
-				// that a K-mer with 10^6 occurrences (a homopolymer, a satellite) does not serialise on one lane
+			if (hasR && REC_V(R) == full && !(hasL && L == R)) {
+				// the end of the run of suffixes with this K-mer: inside the tile the first gap behind r that is not
+				// inside a run; a run that leaves the tile is followed by binary search over the suffix array --
+				// records of one K-mer are equal, later ones greater -- so that a K-mer with 10^6 occurrences (a
+				// homopolymer, a satellite) does not serialise on one lane
+				// the end of the run of suffixes with this K-mer: runs are short in genomes, so the next three records
+				// are looked at together; a longer run is walked a little further and then followed by binary search
+				// over the suffix array -- records of one K-mer are equal, later ones greater -- so that a K-mer with
+				// 10^6 occurrences (a homopolymer, a satellite) does not serialise on one lane
 				int32_t j = r;
-				while (j + 1 < n && j - r < 16 && rec(j + 1) == R) ++j;
-				if (j - r == 16 && j + 1 < n && rec(j + 1) == R) {
-					int32_t lo = j + 1, hi = n - 1; // rec(lo) == R; find the last index with rec == R
-					while (lo < hi) {
-						const int32_t mid = lo + ((hi - lo + 1) >> 1);
-						if (rec(mid) == R) lo = mid; else hi = mid - 1;
+				bool more = true;
+				if (i + 5 < PT_TILE + 3) { // (records of suffixes beyond the text are 0: never equal to R)
+					const uint32_t a1 = s_rec[i + 3], a2 = s_rec[i + 4], a3 = s_rec[i + 5];
+					const int32_t m = a1 != R ? 0 : (a2 != R ? 1 : (a3 != R ? 2 : 3));
+					j = r + m, more = m == 3;
+				}
+				if (more) {
+					while (j + 1 < n && j - r < 16 && rec(j + 1) == R) ++j;
+					if (j - r == 16 && j + 1 < n && rec(j + 1) == R) {
+						int32_t lo = j + 1, hi = n - 1; // rec(lo) == R; find the last index with rec == R
+						while (lo < hi) {
+							const int32_t mid = lo + ((hi - lo + 1) >> 1);
+							if (rec(mid) == R) lo = mid; else hi = mid - 1;
+						}
+						j = lo;
 					}
-					j = lo;
 				}
 				if (j == r) {
 					// the K-mer occurs once.  For the scan in rounds (scan_rounds.hip) its entry also carries the
@@ -408,17 +441,17 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 					if (!single_ext) {
 						present = make_uint2(pos, DEEP_SINGLE | (1u << 2) | (full << 8));
 					} else {
-					const uint64_t w = ld_u64_unaligned((g_u8p)N0 + (e0 >> 1)) >> (4 * (e0 & 1u)); // 15 symbols from e0 on
-					uint32_t nval = (uint32_t)__builtin_ctzll((w & 0x4444444444444444ull) | (1ull << 52)) >> 2; // <= 13
-					auto squeeze = [](uint32_t x) { // 8 nibbles -> 8 x 2 bits, first symbol in the low bits
-						x &= 0x33333333u;
-						x = (x | (x >> 2)) & 0x0f0f0f0fu;
-						x = (x | (x >> 4)) & 0x00ff00ffu;
-						x = (x | (x >> 8)) & 0x0000ffffu;
-						return x;
-					};
-					const uint32_t ext = (squeeze((uint32_t)w) | (squeeze((uint32_t)(w >> 32)) << 16)) & ((1u << (2 * nval)) - 1u);
-					present = make_uint2(pos, DEEP_SINGLE | (nval << 2) | (ext << 6));
+						const uint64_t w = ld_u64_unaligned((g_u8p)N0 + (e0 >> 1)) >> (4 * (e0 & 1u)); // 15 symbols from e0 on
+						uint32_t nval = (uint32_t)__builtin_ctzll((w & 0x4444444444444444ull) | (1ull << 52)) >> 2; // <= 13
+						auto squeeze = [](uint32_t x) { // 8 nibbles -> 8 x 2 bits, first symbol in the low bits
+							x &= 0x33333333u;
+							x = (x | (x >> 2)) & 0x0f0f0f0fu;
+							x = (x | (x >> 4)) & 0x00ff00ffu;
+							x = (x | (x >> 8)) & 0x0000ffffu;
+							return x;
+						};
+						const uint32_t ext = (squeeze((uint32_t)w) | (squeeze((uint32_t)(w >> 32)) << 16)) & ((1u << (2 * nval)) - 1u);
+						present = make_uint2(pos, DEEP_SINGLE | (nval << 2) | (ext << 6));
 					}
 				} else if ((uint32_t)(j - r) < (1u << 24)) {
 					present = make_uint2((uint32_t)r, DEEP_MULTI | ((uint32_t)(j - r) << 8));
@@ -467,19 +500,15 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		}
 		s_first[i] = first, s_absent[i] = absent, s_present[i] = present;
 		counts[u] = absent + owns_present;
+		const uint64_t b = __ballot(counts[u] != 0);
+		if (lane == 0) s_some[u * (PT_BLOCK / 64) + wave] = b;
 	}
 
 	// block-wide exclusive scan of the entry counts, gap order = u * PT_BLOCK + thread
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t total = 0;
 #pragma unroll
 	for (int u = 0; u < PT_GAPS; ++u) {
-		uint32_t incl = counts[u];
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			uint32_t other = (uint32_t)__shfl_up((int)incl, d);
-			if (lane >= (uint32_t)d) incl += other;
-		}
+		const uint32_t incl = wave_scan_incl(counts[u]);
 		__syncthreads(); // s_wave free again
 		if (lane == 63) s_wave[wave] = incl;
 		__syncthreads();
@@ -492,14 +521,37 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		total += all;
 	}
 	if (threadIdx.x == 0) s_off[PT_TILE] = total;
+	// the owners of the first PT_RANKED entries by rank: a bit where an owning gap's entries start (starts are
+	// distinct), the owning gaps listed in order; the owner of entry t is then number (set bits up to t) of the list
+#pragma unroll
+	for (int u = 0; u < PT_GAPS; ++u) {
+		if (counts[u] == 0) continue;
+		const uint32_t i = threadIdx.x + u * PT_BLOCK, word = u * (PT_BLOCK / 64) + wave, off = s_off[i];
+		uint32_t rank = (uint32_t)__builtin_popcountll(s_some[word] & ((1ull << lane) - 1ull));
+		for (uint32_t w = 0; w < word; ++w) rank += (uint32_t)__builtin_popcountll(s_some[w]);
+		s_owner[rank] = (uint16_t)i;
+		if (off < PT_RANKED) atomicOr(&s_bits[off >> 5], 1u << (off & 31u));
+	}
+	__syncthreads();
+	if (wave == 0) { // set bits before each word of s_bits (64 words: one wavefront)
+		const uint32_t mine = (uint32_t)__builtin_popcount(s_bits[lane]);
+		s_before[lane] = wave_scan_incl(mine) - mine;
+	}
 	__syncthreads();
 
 	for (uint32_t t = threadIdx.x; t < total; t += PT_BLOCK) {
-		// the gap that owns entry t: the last one whose offset is <= t
-		uint32_t a = 0, b = PT_TILE; // invariant: s_off[a] <= t < s_off[b]
-		while (b - a > 1) {
-			uint32_t mid = (a + b) >> 1;
-			if (s_off[mid] <= t) a = mid; else b = mid;
+		uint32_t a;
+		if (t < PT_RANKED) {
+			const uint32_t word = t >> 5;
+			a = s_owner[s_before[word] + (uint32_t)__builtin_popcount(s_bits[word] & (0xffffffffu >> (31u - (t & 31u)))) - 1u];
+		} else {
+			// the gap that owns entry t: the last one whose offset is <= t
+			uint32_t b = PT_TILE; // invariant: s_off[a] <= t < s_off[b]
+			a = 0;
+			while (b - a > 1) {
+				uint32_t mid = (a + b) >> 1;
+				if (s_off[mid] <= t) a = mid; else b = mid;
+			}
 		}
 		const uint32_t k = t - s_off[a], c = s_first[a] + k;
 		if (k >= s_absent[a]) { // the K-mer of suffix r itself

@@ -104,6 +104,7 @@ SYMBOLS = {
     "andi_hip_esa_build_index_batch": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "andi_hip_esa_flags": (C.c_int, [_P, _P, _P]),
     "andi_hip_esa_download": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "andi_hip_esa_download_index": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int)]),
     "andi_hip_esa_free": (None, [_P, _P]),
     "andi_hip_esa_bytes": (C.c_size_t, [_P]),
     "andi_hip_queries_stage": (C.c_int, [_P, C.POINTER(Seq), C.c_size_t, C.POINTER(_P)]),
@@ -323,6 +324,15 @@ class Esa:
         self.ctx._check(load().andi_hip_esa_download(self.ctx._h, self._h, LCP.ctypes.data, CLD.ctypes.data,
                                                      FVC.ctypes.data, cache.ctypes.data), "esa_download")
         return LCP, CLD, FVC, cache
+
+    def download_index(self):
+        """(K, table): the probe table of the scan index, uint32[4^K, 2] (test hook; andi_hip.h has the layout)."""
+        K = C.c_int(0)
+        self.ctx._check(load().andi_hip_esa_download_index(self.ctx._h, self._h, None, C.byref(K)), "esa_download_index")
+        table = np.empty((1 << (2 * K.value), 2), np.uint32)
+        self.ctx._check(load().andi_hip_esa_download_index(self.ctx._h, self._h, table.ctypes.data, C.byref(K)),
+                        "esa_download_index")
+        return K.value, table
 
     def nbytes(self):
         return load().andi_hip_esa_bytes(self._h)

@@ -156,6 +156,13 @@ int andi_hip_esa_flags(andi_hip_ctx *ctx, const andi_hip_esa *esa, int32_t *flag
  * LCP/CLD have n+1 entries, FVC n, cache 4^10. */
 int andi_hip_esa_download(andi_hip_ctx *ctx, const andi_hip_esa *esa, int32_t *LCP,
 						  int32_t *CLD, uint8_t *FVC, andi_hip_interval *cache);
+/* Test hook: the scan index's probe table (what the scan consults in place of get_match_cached,
+ * src/esa.c:636-656), 4^K entries of two 32-bit words {x, y}; *K receives the depth.  y & 3 is the kind:
+ * 0 FINAL -- the K-mer is absent from RS, its longest match is y >> 8 (< K) characters, unique iff y & 4,
+ * and then x is the suffix-array index of the one suffix; 1 SINGLE -- it occurs once, at RS offset x;
+ * 2 MULTI -- it occurs (y >> 8) + 1 times, at the suffix-array indices x, x + 1, ...; 3 -- search the
+ * whole suffix array.  `table` may be NULL (only K is wanted); it needs 8 << 2K bytes. */
+int andi_hip_esa_download_index(andi_hip_ctx *ctx, const andi_hip_esa *esa, uint32_t *table, int *K);
 void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *esa);
 size_t andi_hip_esa_bytes(const andi_hip_esa *esa);
 

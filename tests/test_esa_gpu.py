@@ -189,3 +189,73 @@ def test_index_builds_in_one_batch(ctx, orc):
     for e in esas:
         e.close()
     Q.close()
+
+
+def _table_subjects():
+    from andi_amd import synth
+    rng = np.random.default_rng(33)
+    yield "tiny", b"ACGTTGCA"
+    yield "homopolymer", b"A" * 700
+    yield "two-letter", rand_dna(rng, 2500, b"AC")
+    yield "random-1.5k", rand_dna(rng, 1500)
+    yield "repeats", rand_dna(rng, 300) * 6 + rand_dna(rng, 200)
+    yield "joined", synth.join_contigs(rand_dna(rng, 3000), 9)
+    yield "short-contigs", b"!".join([b"ACG", b"ACGT", b"AC", b"ACGTA", b"ACG"] * 30)
+    yield "random-40k", rand_dna(rng, 40000)
+
+
+@pytest.mark.parametrize("name,seq", list(_table_subjects()), ids=[n for n, _ in _table_subjects()])
+def test_probe_table_entries_against_brute_force(ctx, name, seq):
+    """The scan index (esa_build.hip: k_probe_table) entry by entry: for EVERY K-mer w the table must say what
+    get_match would find for a query that starts with w (src/esa.c:615-631) -- where w occurs (once: its position;
+    several times: its suffix-array interval), or, if it does not occur, the length of its longest prefix that
+    does, whether exactly one suffix starts with that prefix, and which.  The expectation is made from the text
+    alone by counting, per length, how many positions start with each prefix."""
+    import andi_amd
+    E = andi_amd.Esa(ctx, seq, sa="device")
+    K, table = E.download_index()
+    rs = np.frombuffer(E.RS, np.uint8)
+    n = len(rs)
+    SA = E.SA
+    rank = np.empty(n, np.int64)
+    rank[SA] = np.arange(n)
+    code = np.full(256, 4, np.int64)
+    code[list(b"ACGT")] = [0, 1, 2, 3]
+    t = np.concatenate([code[rs], np.full(K, 4, np.int64)])
+    # count[l][c], where[l][c]: positions that start with the l-mer c (ACGT only), and one of them
+    count, where = [None], [None]
+    pref = np.zeros(n, np.int64)
+    ok = np.ones(n, bool)
+    for l in range(1, K + 1):
+        ok &= t[l - 1:l - 1 + n] < 4
+        pref = pref * 4 + np.minimum(t[l - 1:l - 1 + n], 3)
+        count.append(np.bincount(pref[ok], minlength=4 ** l))
+        w = np.zeros(4 ** l, np.int64)
+        w[pref[ok]] = np.nonzero(ok)[0]
+        where.append(w)
+    codes = np.arange(4 ** K)
+    x, y = table[:, 0].astype(np.int64), table[:, 1].astype(np.int64)
+    kind = y & 3
+    occurs = count[K]
+    assert ((kind == 1) == (occurs == 1)).all() and ((kind == 2) == (occurs > 1)).all() and (kind != 3).all()
+    once = occurs == 1
+    assert (x[once] == where[K][once]).all()
+    many = occurs > 1
+    assert ((y[many] >> 8) + 1 == occurs[many]).all()
+    first = np.full(4 ** K, n, np.int64)  # smallest suffix-array index among the positions of each K-mer
+    full = np.nonzero(ok)[0]
+    np.minimum.at(first, pref[full], rank[full])
+    assert (x[many] == first[many]).all()
+    absent = occurs == 0
+    best = np.zeros(4 ** K, np.int64)
+    cnt = np.full(4 ** K, n, np.int64)  # (the empty prefix: every suffix shares it)
+    one = np.zeros(4 ** K, np.int64)
+    for l in range(1, K):
+        c = codes >> (2 * (K - l))
+        hit = count[l][c] > 0
+        best[hit], cnt[hit], one[hit] = l, count[l][c][hit], where[l][c][hit]
+    assert ((y[absent] >> 8) == best[absent]).all()
+    uniq = (cnt == 1) & absent
+    assert ((((y >> 2) & 1) == 1)[absent] == uniq[absent]).all()
+    assert (x[uniq] == rank[one[uniq]]).all()
+    E.close()
