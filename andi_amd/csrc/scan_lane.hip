@@ -85,33 +85,23 @@ __device__ __forceinline__ uint32_t lcp_slide(LWin &w, const PairCtx &c, uint32_
 }
 
 // Common prefix of Q[q0 + from ..] and S[q0 + from + dg ..], at most lim, where the
-// window holds the query symbols q0 .. q0 + 31 (the subject side is fetched).
-// (sv: the subject's 32 symbols against the window, already fetched)
-__device__ __forceinline__ uint32_t lane_extend_from(const LWin &w, const PairCtx &c, uint32_t from, int32_t dg,
-													 uint32_t lim, const uint4 &sv) {
-	uint4 d = neq32(w.q, sv);
-	uint32_t f = first_from(d, from);
-	if (f < WNT) {
-		const uint32_t len = f - from;
-		return len < lim ? len : lim;
-	}
-	uint32_t len = WNT - from, qa = w.q0 + WNT;
-	while (len < lim) {
-		d = neq32(ld_query(c, qa), ld_subject(c, (int32_t)qa + dg));
-		STAT(ST_EXT_LOOP);
-		f = first_from(d, 0);
-		if (f < WNT) {
-			len += f;
-			break;
-		}
-		len += WNT, qa += WNT;
-	}
-	return len < lim ? len : lim;
-}
-
+// window holds the query symbols q0 .. q0 + 31 (the subject side is fetched).  One loop,
+// one place where windows are compared: a wavefront executes every such place once per
+// trip whenever one of its lanes gets there, and pass A is bound by instruction issue.
 __device__ __forceinline__ uint32_t lane_extend(const LWin &w, const PairCtx &c, uint32_t from, int32_t dg,
 												uint32_t lim) {
-	return lane_extend_from(w, c, from, dg, lim, ld_subject(c, (int32_t)w.q0 + dg));
+	uint4 q = w.q;
+	uint32_t qa = w.q0, len = 0;
+	for (;;) {
+		const uint4 d = neq32(q, ld_subject(c, (int32_t)qa + dg));
+		const uint32_t f = first_from(d, from);
+		len += f - from;
+		if (f < WNT || len >= lim) break;
+		STAT(ST_EXT_LOOP);
+		qa += WNT, from = 0;
+		q = ld_query(c, qa);
+	}
+	return len < lim ? len : lim;
 }
 
 // model_count (src/model.c:309-337) of Q[q..q+len) against S[s..s+len) through the window.
@@ -211,29 +201,25 @@ __device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &
 		if (r.unique && r.len >= (uint32_t)E.thr) STAT(ST_FINAL_SA);
 		return r;
 	}
-	if (kind == DEEP_SINGLE) {
-		r.pos = x, r.unique = true;
-		STAT(ST_SINGLE);
-		r.len = K + lane_extend(w, c, o + K, (int32_t)(x - p), qrem - K);
-		return r;
-	}
-	if (kind != DEEP_MULTI) return sa_range_match<1>(E, q, qrem, 0, E.n - 1, 0);
-	const uint32_t cnt = (y >> 8) + 1;
-	STAT(ST_MULTI);
-	if (KNOCK(c, 0)) {
+	if (kind != DEEP_SINGLE && kind != DEEP_MULTI) return sa_range_match<1>(E, q, qrem, 0, E.n - 1, 0);
+	const uint32_t cnt = kind == DEEP_SINGLE ? 1u : (y >> 8) + 1;
+	if (kind == DEEP_SINGLE) STAT(ST_SINGLE); else STAT(ST_MULTI);
+	if (KNOCK(c, 0) && kind == DEEP_MULTI) {
 		r.len = K, r.unique = false, r.pos = 0;
 		return r;
 	}
 	if (cnt > MULTI_MAX) STAT(ST_SEARCH);
 	if (cnt > MULTI_MAX) return sa_range_match<1>(E, q, qrem, (int32_t)x, (int32_t)(x + cnt - 1), K);
 	// the longest match is the best of the occurrences' own common prefixes with the
-	// query and it is unique iff exactly one attains it
+	// query and it is unique iff exactly one attains it.  A K-mer that occurs once takes the
+	// same loop as one that occurs several times (its position is in the entry itself): one
+	// place where the lanes of a wavefront extend matches, not two in a row.
 	// (Four occurrences per round trip -- one 16-byte load of positions, four windows in flight -- were measured:
 	// 12 more registers, a wavefront less per SIMD, pass A 7.4 -> 7.9 ms.)
 	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
 	for (uint32_t i = 0; i < cnt; ++i) {
-		const uint32_t pos = (uint32_t)E.SA[x + i];
-		STAT(ST_MULTI_CAND);
+		const uint32_t pos = kind == DEEP_SINGLE ? x : (uint32_t)E.SA[x + i];
+		if (kind != DEEP_SINGLE) STAT(ST_MULTI_CAND);
 		const uint32_t len = K + lane_extend(w, c, o + K, (int32_t)(pos - p), qrem - K);
 		if (len > bestLen) {
 			bestLen = len, bestCnt = 1, bestPos = pos;
