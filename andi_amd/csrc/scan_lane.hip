@@ -53,33 +53,19 @@ __device__ __forceinline__ uint32_t lcp_window(LWin &w, const PairCtx &c, uint32
 	return f - o;
 }
 
-// Follows a match past the window.  Most matches end in the next window, so that one is
-// fetched alone; a match that survives it is a long one (a pair of low divergence) and is
-// then followed two windows per round trip.  (Four -- a whole cache line of each sequence
-// -- were measured slower: the extra pieces are mostly wasted accesses.)  The window is
-// left on the piece where the match ended.
+// Follows a match past the window, a window per round trip; the window is left on the piece where
+// the match ended.  (Pairs whose matches are long take pass A through k_lane_quad.  Before that kernel
+// existed a match that survived its second window was followed two windows per round trip -- a second
+// and a third place where windows are compared, which every wavefront paid for on nearly every trip.
+// Folding this loop and lcp_window into one loop with a conditional fetch was measured: slower.)
 __device__ __forceinline__ uint32_t lcp_slide(LWin &w, const PairCtx &c, uint32_t len, uint32_t maxlen) {
 	const int32_t dg = w.dg;
-	if (len < maxlen) {
+	while (len < maxlen) {
 		win_load(w, c, w.q0 + WNT, dg);
 		STAT(ST_LCP_SLIDE);
 		const uint32_t f = first_from(w.d, 0);
-		if (f < WNT) return len + f;
-		len += WNT;
-	}
-	while (len < maxlen) {
-		const uint32_t qa = w.q0 + WNT;
-		const int32_t sa = (int32_t)qa + dg;
-		const uint4 q0 = ld_query(c, qa), q1 = ld_query(c, qa + WNT);
-		const uint4 s0 = ld_subject(c, sa), s1 = ld_subject(c, sa + (int32_t)WNT);
-		STAT(ST_FINAL_SA); // (diagnostic builds count the double rounds in this slot)
-		auto piece = [&](uint32_t k, const uint4 &q, const uint4 &sv) { // done if it holds a mismatch or reaches maxlen
-			w.q0 = qa + k * WNT, w.q = q, w.s = sv, w.d = neq32(q, sv);
-			const uint32_t f = first_from(w.d, 0);
-			len += f;
-			return f < WNT || len >= maxlen;
-		};
-		if (piece(0, q0, s0) || piece(1, q1, s1)) break;
+		len += f;
+		if (f < WNT) break;
 	}
 	return len;
 }
