@@ -82,6 +82,8 @@ struct andi_hip_esa {
 	uint2 *deep = nullptr;
 	uint8_t *Nraw = nullptr;              // 4-bit symbols for the lane scan: N0 and N1 with their padding
 	uint8_t *N0 = nullptr, *N1 = nullptr;
+	uint32_t *rec = nullptr;    // the suffixes' records in suffix-array order, left by the device sorter (sa_device.hip) for the index build
+	bool rec_valid = false;
 	int32_t *flags = nullptr;   // device, 4 ints
 	int32_t *h_flags = nullptr; // the same 4 ints as the host sees them (flags live in pinned host memory)
 	int32_t deepK = 0;
@@ -206,6 +208,7 @@ EsaBuildArgs build_args(const andi_hip_esa *e) {
 	EsaBuildArgs a;
 	a.S = e->S, a.SA = e->SA, a.LCP = e->LCP, a.CLD = e->CLD, a.FVC = e->FVC, a.tab = e->tab;
 	a.deep = e->deep, a.flags = e->flags, a.deepK = e->deepK;
+	a.rec = e->rec_valid ? e->rec : nullptr;
 	a.N0 = e->N0, a.N1 = e->N1;
 	a.min_scratch = e->min_scratch;
 	a.n = e->n;
@@ -378,6 +381,7 @@ static int esa_upload(andi_hip_ctx *ctx, andi_hip_esa *e, const char *RS, const 
 	e->thr = (int32_t)threshold;
 	e->deepK = pick_deep_k(n);
 	e->ref_built = e->index_built = false;
+	e->rec_valid = false;
 	// the flags are functions of the text and its suffix array: cleared here, only ever set by the builds
 	hipError_t err = hipStreamSynchronize(ctx->stream);
 	memset(e->h_flags, 0, 4 * sizeof(int32_t));
@@ -401,9 +405,14 @@ static int esa_sort_suffixes(andi_hip_ctx *ctx, andi_hip_esa *e) {
 		ctx->sa_ws_bytes = need;
 	}
 	if (!ctx->sa_pinned) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->sa_pinned, 2 * sizeof(int32_t), hipHostMallocDefault));
+	if (!e->rec && !getenv("ANDI_NO_SORTED_RECORDS")) { // (experiments: the index build then gathers from the text, as with a host-made suffix array)
+		HIP_TRY(ctx, hipMalloc((void **)&e->rec, (e->cap + 8) * sizeof(uint32_t)));
+		e->bytes += (e->cap + 8) * sizeof(uint32_t);
+	}
 	const auto t0 = std::chrono::steady_clock::now();
 	int rounds = 0;
-	hipError_t err = andi_sa_device(e->S, e->n, e->SA, ctx->sa_ws, ctx->sa_ws_bytes, ctx->sa_pinned, ctx->stream, &rounds);
+	hipError_t err = andi_sa_device(e->S, e->n, e->SA, ctx->sa_ws, ctx->sa_ws_bytes, ctx->sa_pinned, ctx->stream, &rounds, e->rec, e->deepK);
+	e->rec_valid = err == hipSuccess && e->rec != nullptr;
 	if (err == hipErrorInvalidSymbol) {
 		ctx->err = "a subject holds a byte outside {A,C,G,T,!,;,#}";
 		return 1;
@@ -533,6 +542,7 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 		}
 		items[k].S = e->S, items[k].SA = e->SA, items[k].deep = e->deep, items[k].N0 = e->N0, items[k].N1 = e->N1;
 		items[k].flags = e->flags, items[k].n = e->n, items[k].deepK = e->deepK;
+		items[k].rec = e->rec_valid ? e->rec : nullptr;
 		max_n = std::max(max_n, e->n);
 	}
 	Timed t(ctx, 0);
@@ -595,6 +605,7 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	(void)hipFree(e->tab);
 	(void)hipFree(e->deep);
 	(void)hipFree(e->Nraw);
+	(void)hipFree(e->rec);
 	(void)hipFree(e->min_scratch);
 	if (e->h_flags) (void)hipHostFree(e->h_flags);
 	delete e;

@@ -22,6 +22,7 @@ struct EsaBuildArgs {
 	uint2 *deep;        // 4^deepK (out)
 	uint8_t *N0, *N1;   // 4-bit symbols of the text, two alignments (out; see andi_dev.h)
 	int32_t *flags;     // 4 ints  (out)
+	const uint32_t *rec; // the suffixes' records in suffix-array order if the device sorter made them (sa_device.hip), else null
 	int32_t deepK;
 	int32_t *min_scratch; // andi_min_tree_entries(n) ints
 	int32_t n;
@@ -34,6 +35,7 @@ struct AndiIndexBatchItem {
 	uint2 *deep;
 	uint8_t *N0, *N1;
 	int32_t *flags;
+	const uint32_t *rec; // as EsaBuildArgs.rec
 	int32_t n, deepK;
 };
 

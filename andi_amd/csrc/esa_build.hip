@@ -351,8 +351,8 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 }
 
 __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
-												  uint2 *__restrict__ deep, int32_t *__restrict__ flags, int32_t n, int K,
-												  int single_ext, uint32_t block) {
+												  const uint32_t *__restrict__ REC, uint2 *__restrict__ deep,
+												  int32_t *__restrict__ flags, int32_t n, int K, int single_ext, uint32_t block) {
 	__shared__ uint32_t s_off[PT_TILE + 1]; // exclusive prefix sums of the gaps' entry counts
 	__shared__ uint32_t s_first[PT_TILE];   // first code a gap owns
 	__shared__ uint32_t s_absent[PT_TILE];  // number of absent codes it owns (they come first)
@@ -367,24 +367,25 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 
 	const int64_t r0 = (int64_t)block * PT_TILE;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	// the suffixes' records are made here (they used to be a kernel and an array of their own)
+	// the suffixes' records: read in order if the device sorter left them (REC), else made here from one gather each
+	auto make_rec = [&](int32_t j) { return REC ? REC[j] : suffix_rec(N0, SA, j, K); };
 	{
 		uint32_t mine[PT_GAPS];
 #pragma unroll
 		for (int u = 0; u < PT_GAPS; ++u) {
 			const int64_t g = r0 + threadIdx.x + u * PT_BLOCK;
-			mine[u] = g < n ? suffix_rec(N0, SA, (int32_t)g, K) : 0u;
+			mine[u] = g < n ? make_rec((int32_t)g) : 0u;
 		}
 #pragma unroll
 		for (int u = 0; u < PT_GAPS; ++u) s_rec[threadIdx.x + u * PT_BLOCK + 2] = mine[u];
 	}
-	if (threadIdx.x < 2) s_rec[threadIdx.x] = r0 + threadIdx.x >= 2 ? suffix_rec(N0, SA, (int32_t)(r0 + threadIdx.x - 2), K) : 0u;
-	if (threadIdx.x == 2) s_rec[PT_TILE + 2] = r0 + PT_TILE < n ? suffix_rec(N0, SA, (int32_t)(r0 + PT_TILE), K) : 0u;
+	if (threadIdx.x < 2) s_rec[threadIdx.x] = r0 + threadIdx.x >= 2 ? make_rec((int32_t)(r0 + threadIdx.x - 2)) : 0u;
+	if (threadIdx.x == 2) s_rec[PT_TILE + 2] = r0 + PT_TILE < n ? make_rec((int32_t)(r0 + PT_TILE)) : 0u;
 	if (threadIdx.x < PT_RANKED / 32) s_bits[threadIdx.x] = 0;
 	__syncthreads();
 	auto rec = [&](int32_t j) { // 0 <= j < n; inside the block's range from LDS
 		const int64_t k = (int64_t)j - r0 + 2;
-		return (k >= 0 && k < PT_TILE + 3) ? s_rec[k] : suffix_rec(N0, SA, j, K);
+		return (k >= 0 && k < PT_TILE + 3) ? s_rec[k] : make_rec(j);
 	};
 	const uint32_t full = (uint32_t)K;
 	if (threadIdx.x == 0) s_h[0] = r0 >= 2 ? rec_lcp(s_rec[0], s_rec[1], K) : 0u;
@@ -581,16 +582,16 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 }
 
 __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
-														  uint2 *__restrict__ deep, int32_t *__restrict__ flags, int32_t n, int K,
-														  int single_ext) {
-	probe_table_block(N0, SA, deep, flags, n, K, single_ext, blockIdx.x);
+														  const uint32_t *__restrict__ rec, uint2 *__restrict__ deep,
+														  int32_t *__restrict__ flags, int32_t n, int K, int single_ext) {
+	probe_table_block(N0, SA, rec, deep, flags, n, K, single_ext, blockIdx.x);
 }
 
 // the tables of several subjects in one launch (blockIdx.y = subject): no launch gaps, one tail
 __global__ __launch_bounds__(PT_BLOCK) void k_probe_table_batch(const AndiIndexBatchItem *__restrict__ items, int single_ext) {
 	const AndiIndexBatchItem it = items[blockIdx.y];
 	if ((int64_t)blockIdx.x * PT_TILE > (int64_t)it.n) return;
-	probe_table_block(it.N0, it.SA, it.deep, it.flags, it.n, it.deepK, single_ext, blockIdx.x);
+	probe_table_block(it.N0, it.SA, it.rec, it.deep, it.flags, it.n, it.deepK, single_ext, blockIdx.x);
 }
 
 // ---------------------------------------------------------------- host side
@@ -610,7 +611,7 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
 	// symbols for the lane scan: the text, its NUL and 64 bytes of the zero padding behind it
 	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 1, st);
 	if (e != hipSuccess) return e;
-	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_TILE - 1) / PT_TILE), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.deep, a.flags, n,
+	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_TILE - 1) / PT_TILE), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.rec, a.deep, a.flags, n,
 																				  a.deepK, andi_rounds_lines() != 0);
 	CHECK_LAUNCH();
 	return hipSuccess;

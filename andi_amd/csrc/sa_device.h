@@ -9,5 +9,7 @@ size_t andi_sa_device_workspace(int32_t n);
 // SA[0..n) of the text S[0..n) (device pointers; S readable 32 bytes past n, zeros there), bytes in unsigned
 // order -- what divsufsort() computes at src/esa.c:303.  h_pinned2: two ints of pinned host memory.  Synchronises
 // the stream once per round.  hipErrorInvalidSymbol: the text holds a byte outside {A C G T ! ; #}.
+// rec (n entries, or null): the suffixes' records for a probe table of depth recK, in suffix-array order
+// (esa_build.hip: suffix_rec) -- a by-product of the first round's sorted keys.
 hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *workspace, size_t workspace_bytes,
-						  int32_t *h_pinned2, hipStream_t st, int *rounds_out);
+						  int32_t *h_pinned2, hipStream_t st, int *rounds_out, uint32_t *rec, int recK);

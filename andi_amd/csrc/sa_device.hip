@@ -95,6 +95,30 @@ __global__ __launch_bounds__(SA_BLOCK) void k_sa_apply(const uint64_t *__restric
 	slots_out[t] = ((uint64_t)pos << 32) | idx;
 }
 
+// The sorted round-0 keys hold the first 21 symbols of every suffix IN SUFFIX-ARRAY ORDER.  The scan index's
+// builder (esa_build.hip: k_probe_table) wants, per suffix, the 2-bit code of its first K characters, the number of
+// leading nucleotides and the separator class behind them -- its record, suffix_rec there -- which it would
+// otherwise gather from the text, one random access per suffix.  Made here from the keys, the records are a
+// sequential read for it.  (Symbol codes: NUL 0, '!' 1, '#' 2, ';' 3, A C G T 4..7; symbol j in bits 62-3j..60-3j.)
+__global__ __launch_bounds__(SA_BLOCK) void k_sa_records(const uint64_t *__restrict__ key, int32_t n, int K, uint32_t *__restrict__ rec) {
+	const int64_t i = (int64_t)blockIdx.x * SA_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t k = key[i];
+	const uint64_t other = ~k & 0x4924924924924924ull; // top bit of a symbol clear: not a nucleotide
+	uint32_t v = other ? ((uint32_t)__builtin_clzll(other) - 1u) / 3u : 21u;
+	uint32_t sep = 0;
+	if (v < (uint32_t)K) {
+		const uint32_t sym = (uint32_t)(k >> (60 - 3 * v)) & 7u;
+		sep = sym == 1 ? 1u : (sym == 3 ? 2u : 3u);
+	} else {
+		v = (uint32_t)K;
+	}
+	uint32_t y = 0; // 2-bit codes of the first 16 symbols, the first in the top two bits
+#pragma unroll
+	for (int j = 0; j < 16; ++j) y |= ((uint32_t)(k >> (60 - 3 * j)) & 3u) << (30 - 2 * j);
+	rec[i] = ((y >> (32 - 2 * K)) << 6) | (sep << 4) | v;
+}
+
 // round r >= 1: key of an open slot = (its group, the group of the suffix h symbols further on)
 __global__ __launch_bounds__(SA_BLOCK) void k_sa_keys(const uint64_t *__restrict__ slots, uint32_t m, const uint32_t *__restrict__ rank,
 													   int32_t n, uint32_t h, int bits, uint64_t *__restrict__ key,
@@ -125,7 +149,7 @@ size_t andi_sa_device_workspace(int32_t n) {
 }
 
 hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *workspace, size_t workspace_bytes,
-						  int32_t *h_pinned2, hipStream_t st, int *rounds_out) {
+						  int32_t *h_pinned2, hipStream_t st, int *rounds_out, uint32_t *rec, int recK) {
 	if (n <= 0) return hipSuccess;
 	if (workspace_bytes < andi_sa_device_workspace(n)) return hipErrorInvalidValue;
 	const size_t N = ((size_t)n + 63) & ~(size_t)63;
@@ -158,6 +182,7 @@ hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *worksp
 	for (;;) {
 		size_t tb = tmp_bytes;
 		SA_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keyA, keyB, valA, valB, (int)m, 0, rounds == 0 ? 63 : 2 * bits, st));
+		if (rounds == 0 && rec) k_sa_records<<<blocks(m), SA_BLOCK, 0, st>>>(keyB, n, recK, rec);
 		k_sa_heads<<<blocks(m), SA_BLOCK, 0, st>>>(keyB, slots, m, hv);
 		SA_TRY(hipGetLastError());
 		tb = tmp_bytes;

@@ -801,6 +801,18 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 	uint32_t anchors = 0;
 	while (st.p < it.end) {
 		bool found;
+#ifdef ANDI_LANE_STATS
+		{ // trips of the wavefront's loop, and those with at most 32 / 16 / 8 lanes still at work
+			const uint64_t on = __ballot(1);
+			if (__lane_id() == (uint32_t)__builtin_ctzll(on)) {
+				const int k = __builtin_popcountll(on);
+				STAT(ST_X0);
+				if (k <= 32) STAT(ST_X1);
+				if (k <= 16) STAT(ST_X2);
+				if (k <= 8) STAT(ST_X3);
+			}
+		}
+#endif
 		st = lane_step<EXACT>(c, st, tally, w, found);
 		if (found && ++anchors == 1) *(uint4 *)marks[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
 		if (found && anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
