@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 }
 
 template <bool EXACT, bool AGAIN, bool LISTED>
-__global__ __launch_bounds__(BLOCK, 3) void k_lane_stitch(ScanArgs a) {
+__global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) { // (4 wavefronts per SIMD with 30 spilled registers: 1.33 -> 1.25 ms for passes B/C; 5 with 175: 1.78 ms)
 	__shared__ uint32_t s_hist[2][16 * BLOCK];
 	// stitching again is for the successors of segments whose true chain never fell in with the cold one, and then
 	// for the successors of those that were stitched again
