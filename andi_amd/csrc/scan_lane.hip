@@ -238,14 +238,18 @@ template <bool EXACT>
 __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st, Tally &tally, LWin &w, bool &found) {
 	const uint32_t n = (uint32_t)c.E.n;
 	uint32_t curS = 0, curLen = 0;
-	bool accounted = false;
 	found = false;
 	STAT(ST_STEP);
 
-	// lucky_anchor, src/process.c:82-100
+	// lucky_anchor, src/process.c:82-100.  A match that runs on past the window is followed in a window of its own
+	// (t): w keeps the symbols around p -- the gap behind the last anchor, which is counted once the match is known
+	// to be an anchor (one place where gaps are counted, not one before the slide and one after), and the K-mer at p,
+	// should it fail -- and takes over t's last piece when the step is done.
 	const uint32_t advance = st.p - st.lastQ;
 	const uint32_t gap = advance - st.lastLen;
 	const uint32_t tryS = st.lastS + advance;
+	uint4 tq = make_uint4(0, 0, 0, 0), ts = tq;
+	uint32_t tq0 = EMPTY;
 	if (tryS < n && gap <= c.thr) {
 		STAT(ST_LUCKY_TRY);
 		const uint32_t maxlen = c.qlen - st.p;
@@ -253,13 +257,16 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 		curS = tryS;
 		curLen = lcp_window(w, c, st.p, tryS, gap, open);
 		if (open && !KNOCK(c, 1)) {
-			// certainly an anchor already: count the gap while the window still holds it
-			// (only then: a gap that starts before the window would move the window)
-			if (curLen >= c.thr && maxlen >= c.thr && st.p - gap >= w.q0) {
-				lane_account<EXACT>(c, st, tally, w, curS);
-				accounted = true;
+			const int32_t dg = w.dg;
+			uint32_t qa = w.q0;
+			while (curLen < maxlen) {
+				qa += WNT;
+				tq0 = qa, tq = ld_query(c, qa), ts = ld_subject(c, (int32_t)qa + dg);
+				STAT(ST_LCP_SLIDE);
+				const uint32_t f = first_from(neq32(tq, ts), 0);
+				curLen += f;
+				if (f < WNT) break;
 			}
-			curLen = lcp_slide(w, c, curLen, maxlen);
 		}
 		if (curLen > maxlen) curLen = maxlen;
 		found = curLen >= c.thr;
@@ -273,11 +280,12 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 	}
 
 	if (found) {
-		if (!accounted) lane_account<EXACT>(c, st, tally, w, curS);
+		lane_account<EXACT>(c, st, tally, w, curS);
 		st.lastS = curS;
 		st.lastQ = st.p;
 		st.lastLen = curLen;
 	}
+	if (tq0 != EMPTY) w.q0 = tq0, w.q = tq, w.s = ts, w.d = neq32(tq, ts); // (w.dg: the diagonal followed)
 	st.p += curLen + 1;
 	return st;
 }
@@ -1129,7 +1137,7 @@ hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N
 static int lane_occupancy() { // waves per SIMD pass A is compiled for (experiments: ANDI_LANE_OCC)
 	const char *e = getenv("ANDI_LANE_OCC");
 	int v = e ? atoi(e) : 0;
-	return (v == 4 || v == 6 || v == 8) ? v : 6; // 6: no spills, measured best
+	return (v == 4 || v == 6 || v == 7 || v == 8) ? v : 6; // 6: no spills, measured best
 }
 
 template <bool EXACT>
@@ -1168,6 +1176,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	switch (lane_occupancy()) {
 		case 4: k_lane_cold<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
 		case 6: k_lane_cold<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break;
+		case 7: k_lane_cold<EXACT, 7><<<grid, BLOCK, pad, st>>>(a); break;
 		default: k_lane_cold<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
 	}
 	if (side) (void)hipStreamWaitEvent(st, a.side_join, 0);
