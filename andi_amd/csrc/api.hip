@@ -48,6 +48,7 @@ struct EventPair {
 
 struct andi_hip_ctx {
 	int device = 0;
+	size_t queries_hint = 0; // andi_hip_ctx_expect_queries
 	hipStream_t stream = nullptr;
 	hipStream_t side_stream = nullptr; // pass A's second kernel runs beside the first
 	hipEvent_t side_fork = nullptr, side_join = nullptr;
@@ -87,6 +88,7 @@ struct andi_hip_esa {
 	int32_t *flags = nullptr;   // device, 4 ints
 	int32_t *h_flags = nullptr; // the same 4 ints as the host sees them (flags live in pinned host memory)
 	int32_t deepK = 0;
+	int32_t deepK_cap = 0; // the depth the table was allocated for
 	int32_t n = 0;
 	int32_t thr = 0;
 	size_t cap = 0;     // characters the buffers were sized for (>= n)
@@ -194,9 +196,13 @@ EsaDev esa_view(const andi_hip_esa *e, int mode) {
 }
 
 // probe table depth: smallest K with 4^K >= n, within [4, 13]
-int pick_deep_k(size_t n) {
+// (queries: how many queries a subject of this context will meet, 0 = unknown.  A table one level deeper answers more
+// probes without touching the text -- pass A of a C4-shaped call 53.2 -> 50.0 ms -- and costs its build four times the
+// stores -- 0.06 -> 0.19 ms per 4.2 M-character subject: it pays from about a thousand queries per subject on.)
+int pick_deep_k(size_t n, size_t queries) {
 	int K = 4;
 	while (K < ANDI_MAX_DEEP_K && ((size_t)1 << (2 * K)) < n) ++K;
+	if (queries >= 1024 && K < ANDI_MAX_DEEP_K) ++K;
 	if (const char *ev = getenv("ANDI_DEEP_K")) {
 		int v = atoi(ev);
 		if (v >= 4 && v <= ANDI_MAX_DEEP_K) K = v;
@@ -279,6 +285,10 @@ int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t err
 	return 0;
 }
 
+void andi_hip_ctx_expect_queries(andi_hip_ctx *ctx, size_t queries) {
+	if (ctx) ctx->queries_hint = queries;
+}
+
 void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
@@ -343,7 +353,8 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	auto chk = [&](hipError_t x) {
 		if (err == hipSuccess) err = x;
 	};
-	const size_t deep_entries = (size_t)1 << (2 * pick_deep_k(cap));
+	e->deepK_cap = pick_deep_k(cap, ctx->queries_hint);
+	const size_t deep_entries = (size_t)1 << (2 * e->deepK_cap);
 	chk(dmalloc(&e->S, cap + 1 + ANDI_PAD));
 	chk(dmalloc(&e->SA, cap + 8)); // +8: the scan reads the occurrences of a repeated K-mer eight entries at a time
 	chk(dmalloc(&e->deep, deep_entries + 2)); // +2: entries are fetched with 16-byte loads
@@ -379,7 +390,7 @@ static int esa_upload(andi_hip_ctx *ctx, andi_hip_esa *e, const char *RS, const 
 	}
 	e->n = (int32_t)n;
 	e->thr = (int32_t)threshold;
-	e->deepK = pick_deep_k(n);
+	e->deepK = std::min(pick_deep_k(n, ctx->queries_hint), e->deepK_cap);
 	e->ref_built = e->index_built = false;
 	e->rec_valid = false;
 	// the flags are functions of the text and its suffix array: cleared here, only ever set by the builds
@@ -1237,15 +1248,26 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	};
 	std::vector<Dev> dv(ndev);
 
+	const bool trace = getenv("ANDI_E2E_TRACE") != nullptr; // diagnostics: where the call's wall time goes (device 0's driver)
+	auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t_call = now_ms();
 	auto drive = [&](size_t d) {
 		Dev &D = dv[d];
 		char eb[256] = "";
+		double t_last = now_ms(), acc_take = 0, acc_upload = 0, acc_sort = 0, acc_scan = 0, acc_copy = 0;
+		auto lap = [&](double &acc) {
+			const double t = now_ms();
+			acc += t - t_last, t_last = t;
+		};
+		double t_ctx = 0, t_queries = 0, t_slots = 0;
 		auto bail = [&](const char *what) {
 			char msg[512];
 			snprintf(msg, sizeof msg, "%s (device %d): %s", what, devs[d], D.ctx ? andi_hip_last_error(D.ctx) : eb);
 			fail_all(msg);
 		};
 		if (andi_hip_ctx_create(&D.ctx, devs[d], eb, sizeof eb)) return bail("creating a context");
+		andi_hip_ctx_expect_queries(D.ctx, n - 1);
+		lap(t_ctx);
 		const size_t rows = last[d] - first[d];
 		// Subject slots: device buffers sized for the longest genome, reused batch after batch (no
 		// allocation inside the loop).  Several subjects per scan call keep the GPU filled; low_memory
@@ -1254,16 +1276,18 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		{
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-				const size_t per_slot = 10 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap))) + (1 << 20);
+				const size_t per_slot = 10 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap, D.ctx->queries_hint))) + (1 << 20);
 				while (batch > 1 && batch * per_slot > free_b / (2 * ndev)) batch /= 2;
 			}
 		}
 		if (batch > rows) batch = rows;
 		D.slots.assign(batch, nullptr);
 		if (andi_hip_queries_stage(D.ctx, seqs, n, &D.Q)) return bail("staging queries");
+		lap(t_queries);
 		for (size_t b = 0; b < batch; ++b)
 			if (esa_reserve(D.ctx, rs_cap, &D.slots[b])) return bail("allocating subject slots");
 		if (andi_hip_dev_alloc(D.ctx, (use_rccl ? rows : batch) * n * sizeof(andi_hip_model), (void **)&D.d_rows)) return bail("row buffer");
+		lap(t_slots);
 
 		std::vector<int64_t> self(batch);
 		for (size_t i0 = first[d]; i0 < last[d]; i0 += batch) {
@@ -1271,6 +1295,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			for (size_t b = 0; b < nb; ++b) {
 				Prepared *p = take(i0 + b);
 				if (!p) return;
+				lap(acc_take);
 				bool ok = true;
 				if (p->rc) {
 					char msg[96];
@@ -1279,7 +1304,9 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 					ok = false;
 				}
 				if (ok && esa_upload(D.ctx, D.slots[b], p->RS, o.sa_on_host ? p->SA.data() : nullptr, p->n, p->thr)) bail("staging subject"), ok = false;
+				lap(acc_upload);
 				if (ok && !o.sa_on_host && esa_sort_suffixes(D.ctx, D.slots[b])) bail("suffix array"), ok = false;
+				lap(acc_sort);
 				self[b] = (int64_t)(i0 + b);
 				andi_hip_free(p->RS);
 				delete p;
@@ -1293,14 +1320,20 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			if (andi_hip_esa_build_index_batch(D.ctx, D.slots.data(), nb)) return bail("index build");
 			andi_hip_model *dst = use_rccl ? D.d_rows + (i0 - first[d]) * n : D.d_rows;
 			if (andi_hip_scan_rows(D.ctx, D.slots.data(), self.data(), nb, D.Q, o.model, o.segment, dst)) return bail("scan");
+			if (trace) (void)andi_hip_sync(D.ctx);
+			lap(acc_scan);
 			if (!use_rccl && andi_hip_copy_to_host(D.ctx, M + i0 * n, dst, nb * n * sizeof(andi_hip_model))) return bail("row copy");
 			if (use_rccl && andi_hip_sync(D.ctx)) return bail("scan"); // the slots are reused by the next batch
+			lap(acc_copy);
 			if (o.progress) {
 				std::lock_guard<std::mutex> lk(mu);
 				rows_done += nb;
 				o.progress(rows_done * (n - 1), n * n - n, o.ud);
 			}
 		}
+		if (trace && d == 0)
+			fprintf(stderr, "andi_hip_dist_matrix trace (ms): context %.1f, queries %.1f, slots %.1f, waiting for the host pool %.1f, subject uploads %.1f, suffix arrays %.1f, index builds + scans %.1f, row copies %.1f; driver total %.1f\n",
+					t_ctx, t_queries, t_slots, acc_take, acc_upload, acc_sort, acc_scan, acc_copy, now_ms() - t_call);
 	};
 
 	std::vector<std::thread> pool, drivers;
@@ -1389,6 +1422,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		if (D.Q) andi_hip_queries_free(D.ctx, D.Q);
 		andi_hip_ctx_destroy(D.ctx);
 	}
+	if (trace) fprintf(stderr, "andi_hip_dist_matrix trace: call total %.1f ms\n", now_ms() - t_call);
 	return rc;
 }
 

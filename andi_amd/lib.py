@@ -94,6 +94,7 @@ SYMBOLS = {
     "andi_hip_device_count": (C.c_int, []),
     "andi_hip_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_size_t]),
     "andi_hip_ctx_destroy": (None, [_P]),
+    "andi_hip_ctx_expect_queries": (None, [_P, C.c_size_t]),
     "andi_hip_last_error": (C.c_char_p, [_P]),
     "andi_hip_sync": (C.c_int, [_P]),
     "andi_hip_esa_stage": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
@@ -226,6 +227,10 @@ class Context:
         if L.andi_hip_ctx_create(C.byref(self._h), device, err, len(err)):
             raise AndiHipError(err.value.decode())
         self.device = device
+
+    def expect_queries(self, queries):
+        """queries per subject from now on (decides the depth of the probe tables; results do not depend on it)"""
+        load().andi_hip_ctx_expect_queries(self._h, int(queries))
 
     def _check(self, rc, what):
         if rc:

@@ -138,6 +138,7 @@ def main():
     S = args.subjects if 0 < args.subjects <= G else G  # subject rows of the job
     r0, r1 = shard.row_block(S, world, rank)
     ctx = andi_amd.Context(local_rank)
+    ctx.expect_queries(G - 1)  # as andi_hip_dist_matrix does: every subject meets every other sequence
     # ---- untimed staging: queries, and for the owned rows RS (host: seq_subject_init) and its suffix array (device)
     t_stage = time.time()
     Q = andi_amd.Queries(ctx, seqs)

@@ -124,6 +124,12 @@ typedef struct andi_hip_queries andi_hip_queries; /* all query sequences in HBM 
 int andi_hip_device_count(void); /* visible HIP devices; 0 if none (or no usable runtime) */
 int andi_hip_ctx_create(andi_hip_ctx **ctx, int device, char *errbuf, size_t errlen);
 void andi_hip_ctx_destroy(andi_hip_ctx *ctx);
+/* How many queries the subjects staged in this context from now on will be scanned against (0 = unknown, the
+ * default).  Decides the depth of their probe tables: from 1024 queries on, one level deeper than the text's length
+ * asks for (4x the table, built once per subject; fewer text accesses per probe, paid back over the queries).
+ * andi_hip_dist_matrix sets it itself (n - 1: distMatrix compares every sequence with every other,
+ * src/dist_hack.h:59-68).  Results do not depend on it. */
+void andi_hip_ctx_expect_queries(andi_hip_ctx *ctx, size_t queries);
 const char *andi_hip_last_error(const andi_hip_ctx *ctx);
 int andi_hip_sync(andi_hip_ctx *ctx);
 

@@ -380,3 +380,25 @@ def test_pairs_with_long_matches_take_the_quad_kernel(ctx, orc, monkeypatch):
             monkeypatch.setenv(k, v)
         got, t = _gpu_rows(ctx, seqs)
         assert t["adaptive_calls"] >= 1 and (got == want).all(), env
+
+
+def test_deeper_probe_table_for_many_queries(ctx, orc):
+    """andi_hip_ctx_expect_queries: subjects that will meet a thousand queries or more get a probe table one level
+    deeper (what andi_hip_dist_matrix asks for on a C4-shaped job).  The table's depth changes, the counts do not."""
+    import andi_amd
+    from andi_amd import synth
+    seqs, _ = synth.realistic_set(4, 120000, 0.001, 0.05, seed=3, novel_fraction=0.05)
+    seqs.append(synth.join_contigs(seqs[1], 5, seed=2))
+    try:
+        ctx.expect_queries(0)
+        e = andi_amd.Esa(ctx, seqs[0], sa="device")
+        k0, _ = e.download_index()
+        e.close()
+        ctx.expect_queries(3084)
+        e = andi_amd.Esa(ctx, seqs[0], sa="device")
+        k1, _ = e.download_index()
+        e.close()
+        assert k1 == k0 + 1
+        _check_set(ctx, orc, seqs, segments=(0, 512))
+    finally:
+        ctx.expect_queries(0)
