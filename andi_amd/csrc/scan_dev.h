@@ -128,9 +128,10 @@ __device__ __forceinline__ uint32_t entry_source(const ScanArgs &a, size_t row, 
 	uint32_t j = k - 1;
 	while (j >= 1) {
 		const uint32_t e = (j + 1) * seg, end_j = e < qlen ? e : qlen;
-		bool covered = false;
-		for (uint32_t back = 1; back <= ANDI_SPAN_WINDOW && back <= j && !covered; ++back)
-			covered = a.exit_p[row + j - back] >= end_j;
+		bool covered = false; // (the window's exit positions are fetched together, not one round trip after the other)
+#pragma unroll
+		for (uint32_t back = 1; back <= ANDI_SPAN_WINDOW; ++back)
+			covered |= a.exit_p[row + j - (back <= j ? back : j)] >= end_j && back <= j;
 		if (!covered) break;
 		--j;
 	}

@@ -604,8 +604,9 @@ __device__ __forceinline__ bool pos_in(const LWin &w, uint32_t p) {
 // registers do (it is then resumed on the next trip); when it has ended, the rest of the step -- the probe if the
 // lucky attempt failed, the counting, the bookkeeping -- is lane_step's code.  A probe follows a match only 64
 // symbols by itself (lane_probe's cap); one that goes on is handed to the quads.
+#define QUAD_STAGE (4 * 65) /* uint4 per wavefront: four rounds of 64 pieces, rows one piece apart from a multiple of the banks */
 template <bool EXACT>
-__device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem &it, uint32_t *s_hist) {
+__device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem &it, uint32_t *s_hist, uint4 *s_stage) {
 	Tally tally;
 	tally_begin<1>(tally, s_hist + threadIdx.x);
 	PairCtx c = make_ctx(a, it.sub, it.qidx);
@@ -624,6 +625,11 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 	bool accounted = false;
 	bool active = it.valid && st.p < it.end;
 	constexpr uint32_t PROBE_CAP = 64;
+	// A match longer than a segment is found by the cold chain of every segment it covers, each from its own start,
+	// and each would follow it to its end: m segments, m^2 / 2 segments' worth of comparing.  But the lane to the
+	// right holds the next segment of the same pair: once a comparison has reached the segment's end, and the
+	// neighbour's first anchor starts right there on the same diagonal, the rest of the match is that anchor.
+	uint32_t fQ = EMPTY, fS = 0, fLen = 0; // the chain's first anchor
 
 	// make w the piece of the registers that holds query position x (false: they do not hold it)
 	auto point_w_at = [&](uint32_t x) -> bool {
@@ -641,10 +647,27 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 	};
 
 	while (__any(active)) {
+#ifdef ANDI_LANE_STATS
+		{ // trips of the wavefront's loop (x4), lanes at work in them (x5), lanes in the middle of a comparison (x6)
+			const uint64_t on = __ballot(active), mid = __ballot(active && mode != 0);
+			if (__lane_id() == (uint32_t)__builtin_ctzll(on)) {
+				STAT(ST_X4);
+				atomicAdd(&g_lane_stats[ST_X5], (unsigned long long)__builtin_popcountll(on));
+				atomicAdd(&g_lane_stats[ST_X6], (unsigned long long)__builtin_popcountll(mid));
+			}
+		}
+#endif
+		const bool has_nb = (threadIdx.x & 63u) != 63u;
+		const uint32_t nbQ = (uint32_t)__shfl_down((int)fQ, 1), nbS = (uint32_t)__shfl_down((int)fS, 1), nbLen = (uint32_t)__shfl_down((int)fLen, 1);
+		bool nb_end = false;
+		if (active && mode != 0 && has_nb && st.p + curLen >= it.end && nbQ == it.end && nbS - nbQ == curS - st.p) {
+			curLen = (it.end - st.p) + nbLen, nb_end = true;
+			STAT(ST_FINAL_SA); // (diagnostic builds count the matches ended by the neighbour in this slot)
+		}
 		// ---- where does the lane look next?
 		uint32_t want = 0;
 		int32_t wdg = NO_DIAG;
-		if (active) {
+		if (active && !nb_end) {
 			if (mode == 0) { // the top of a step (src/process.c:153)
 				accounted = false;
 				if (lucky_applies(st, n, thr)) {
@@ -660,13 +683,16 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 			}
 		}
 		// ---- its registers, filled by its quad when one of the quad's lanes lacks what it wants
-		const bool lacks = active && (b0 == EMPTY || want < b0 || want - b0 >= 4 * WNT || (wdg != NO_DIAG && wdg != bdg));
+		const bool lacks = active && !nb_end && (b0 == EMPTY || want < b0 || want - b0 >= 4 * WNT || (wdg != NO_DIAG && wdg != bdg));
 		if (__any(lacks)) {
 			const uint64_t lb = __ballot(lacks);
 			if ((lb >> (__lane_id() & ~3u)) & 0xFu) { // (uniform in the quad: all its active lanes take new registers from where they look)
 				const uint32_t nb0 = want & ~1u;
 				const uint64_t qbase = (uint64_t)(uintptr_t)c.Qn;
 				STAT(ST_LCP_RELOAD);
+#ifdef ANDI_LANE_STATS
+				if (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(1))) STAT(ST_X7); // trips with a fetch
+#endif
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					const bool o_on = dpp_quad_floor(active ? 1u : 0u, r) != 0;
@@ -679,16 +705,28 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 						if (o_s) Bs[r] = ld_subject(c, (int32_t)(o_sa + WNT * qi));
 					}
 				}
-				quad_transpose_floor(Bq, qi);
-				quad_transpose_floor(Bs, qi);
+				// every lane its own: piece i of owner r came to lane i in round r.  Through LDS -- written as loaded
+				// (round r, lane l at [65 r + l]: contiguous), read back by the owner (its round, its quad's four
+				// lanes; the odd row length spreads the owners over the banks) -- the transposition costs the vector
+				// ALUs, which bound this kernel, nothing (two 4 x 4 transposes over the quad by DPP: 128 instructions).
+				uint4 *stage = s_stage + (threadIdx.x >> 6) * QUAD_STAGE;
+				const uint32_t ln = threadIdx.x & 63u;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) stage[65 * r + ln] = Bq[r];
+#pragma unroll
+				for (int k = 0; k < 4; ++k) Bq[k] = stage[65 * qi + (ln & ~3u) + k];
+#pragma unroll
+				for (int r = 0; r < 4; ++r) stage[65 * r + ln] = Bs[r];
+#pragma unroll
+				for (int k = 0; k < 4; ++k) Bs[k] = stage[65 * qi + (ln & ~3u) + k];
 				b0 = active ? nb0 : EMPTY, bdg = wdg;
 			}
 		}
 		if (!active) continue;
 
 		// ---- the comparison, out of the registers
-		bool ended = mode == 0; // (no comparison to make: straight to the probe)
-		if (mode != 0) {
+		bool ended = mode == 0 || nb_end; // (no comparison to make: straight to the probe; or the neighbour knew the rest)
+		if (mode != 0 && !nb_end) {
 			const uint32_t maxlen = c.qlen - st.p;
 			uint32_t pos = st.p + curLen;
 #pragma unroll
@@ -736,7 +774,10 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 		}
 		st.p += curLen + 1;
 		mode = 0;
-		if (found && ++anchors == 1) *(uint4 *)marks[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
+		if (found && ++anchors == 1) {
+			*(uint4 *)marks[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
+			fQ = st.lastQ, fS = st.lastS, fLen = st.lastLen;
+		}
 		if (found && anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
 			ColdMark *m = marks + (anchors - 2);
 			ChainState ms = st;
@@ -771,11 +812,12 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 template <bool EXACT>
 __global__ __launch_bounds__(BLOCK, 4) void k_lane_quad(ScanArgs a) {
 	__shared__ uint32_t s_hist[16 * BLOCK];
+	__shared__ uint4 s_stage[WAVES_PER_BLOCK * QUAD_STAGE];
 	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
 	LaneItem it = lane_item(a);
 	if (!a.quad_all && !lane_is_mine(a, it, true)) it.valid = false; // (a wavefront is one pair's: all or none)
 	if (!__any(it.valid)) return;
-	lane_cold_quad<EXACT>(a, it, s_hist);
+	lane_cold_quad<EXACT>(a, it, s_hist, s_stage);
 }
 
 template <bool EXACT, int OCC>
