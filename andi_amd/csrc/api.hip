@@ -863,7 +863,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	const size_t pairs_all = nsub * q->nq;
 	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
-	const size_t need = slots * (3 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4 + 8) + 128 +
+	const size_t need = slots * (3 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4 + 8 + 8) + 128 +
 						(adaptive ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -902,6 +902,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.defer_count = a.restitch_count + 8;
 	p += 64;
 	a.defer_list = (unsigned long long *)p;
+	p += slots * sizeof(unsigned long long);
+	a.first_pub = (unsigned long long *)p; // (k_lane_quad, per-pair segment lengths only)
 	p += slots * sizeof(unsigned long long);
 	a.adaptive = adaptive ? 1 : 0;
 	a.seg0 = seg0, a.max_waves = (uint32_t)max_waves;

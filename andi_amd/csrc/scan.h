@@ -60,6 +60,9 @@ struct ScanArgs {
 	unsigned long long *defer_list; // slots
 	uint32_t *defer_count;
 	uint32_t defer_base; // first list entry of this launch
+	// k_lane_quad: where a cold chain's first anchor starts at its segment's start, (pos_S << 32 | length), published for
+	// the chain of the segment before it -- in another wavefront -- whose match may run on into it (all ones: none yet)
+	unsigned long long *first_pub;
 	uint32_t *owned;       // [..][16] counts the true chain adds inside the segment
 	andi_hip_model *M;     // [nsub][nq]
 	unsigned long long *fixups;

@@ -658,9 +658,14 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 		}
 #endif
 		const bool has_nb = (threadIdx.x & 63u) != 63u;
-		const uint32_t nbQ = (uint32_t)__shfl_down((int)fQ, 1), nbS = (uint32_t)__shfl_down((int)fS, 1), nbLen = (uint32_t)__shfl_down((int)fLen, 1);
+		uint32_t nbQ = (uint32_t)__shfl_down((int)fQ, 1), nbS = (uint32_t)__shfl_down((int)fS, 1), nbLen = (uint32_t)__shfl_down((int)fLen, 1);
 		bool nb_end = false;
-		if (active && mode != 0 && has_nb && st.p + curLen >= it.end && nbQ == it.end && nbS - nbQ == curS - st.p) {
+		const bool at_end = active && mode != 0 && st.p + curLen >= it.end;
+		if (at_end && !has_nb && it.end < c.qlen) { // the next segment is another wavefront's: what its chain has published
+			const unsigned long long pub = __hip_atomic_load(a.first_pub + slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			nbQ = pub != ~0ull ? it.end : EMPTY, nbS = (uint32_t)(pub >> 32), nbLen = (uint32_t)pub;
+		}
+		if (at_end && (has_nb || it.end < c.qlen) && nbQ == it.end && nbS - nbQ == curS - st.p) {
 			curLen = (it.end - st.p) + nbLen, nb_end = true;
 			STAT(ST_FINAL_SA); // (diagnostic builds count the matches ended by the neighbour in this slot)
 		}
@@ -777,6 +782,8 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 		if (found && ++anchors == 1) {
 			*(uint4 *)marks[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
 			fQ = st.lastQ, fS = st.lastS, fLen = st.lastLen;
+			if ((threadIdx.x & 63u) == 0 && fQ == it.start)
+				__hip_atomic_store(a.first_pub + slot, ((unsigned long long)fS << 32) | fLen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		if (found && anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
 			ColdMark *m = marks + (anchors - 2);
@@ -1193,6 +1200,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	if (getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) == 2) { // experiments: everything through the quads
 		ScanArgs b = a;
 		b.quad_all = 1;
+		(void)hipMemsetAsync(a.first_pub, 0xff, (a.adaptive ? (size_t)64 * a.max_waves : (size_t)a.nsub * a.total_segs) * sizeof(unsigned long long), st);
 		k_lane_quad<EXACT><<<grid, BLOCK, 0, st>>>(b);
 		return hipGetLastError();
 	}
@@ -1208,6 +1216,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	const bool quads = a.adaptive && a.quad_min_match != 0xffffffffu;
 	const bool side = quads && a.side_stream && !getenv("ANDI_NO_SIDE_STREAM");
 	if (quads) { // the pairs with long matches, beside the others
+		(void)hipMemsetAsync(a.first_pub, 0xff, (size_t)64 * a.max_waves * sizeof(unsigned long long), st);
 		if (side) {
 			(void)hipEventRecord(a.side_fork, st);
 			(void)hipStreamWaitEvent(a.side_stream, a.side_fork, 0);

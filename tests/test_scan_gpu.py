@@ -402,3 +402,27 @@ def test_deeper_probe_table_for_many_queries(ctx, orc):
         _check_set(ctx, orc, seqs, segments=(0, 512))
     finally:
         ctx.expect_queries(0)
+
+
+def test_matches_longer_than_many_segments(ctx, orc):
+    """Genomes a handful of substitutions apart: one match covers hundreds of segments, several wavefronts, several
+    blocks.  The cold chain of every covered segment finds it; in k_lane_quad a chain whose comparison has reached its
+    segment's end takes the rest from the next segment's first anchor -- the lane to its right, or what the next
+    wavefront's first lane has published (scan_lane.hip: first_pub) -- instead of following the match to its end.
+    Same counts as the sequential loop, with the shortest segments (every boundary kind) and the usual ones."""
+    from andi_amd import synth
+    base = synth.base_codes(2500000, 41)
+    rng = np.random.default_rng(5)
+
+    def with_snps(k):
+        c = base.copy()
+        pos = rng.choice(len(c), size=k, replace=False)
+        c[pos] = (c[pos] + 1 + rng.integers(0, 3, size=k)) % 4
+        return synth.to_bytes(c)
+
+    seqs = [synth.to_bytes(base), with_snps(3), with_snps(40), synth.to_bytes(base), synth.to_bytes(synth.mutate_codes(base, 0.001, 8))]
+    want = orc.dist_matrix(seqs, threads=0)
+    got, t = _gpu_rows(ctx, seqs)
+    assert t["adaptive_calls"] >= 1 and (got == want).all()
+    got, _ = _gpu_rows(ctx, seqs[:3], segment=1024)  # (one segment length for the call: k_lane_cold follows them itself)
+    assert (got == want[:3, :3]).all()
