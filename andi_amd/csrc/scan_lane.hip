@@ -1016,12 +1016,27 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 			}
 		}
 	}
+	// The state right behind the cold chain's FIRST anchor is a mark too, and one that costs nothing to keep: the cold
+	// chain has counted nothing by then (its first anchor is no right anchor and has no anchor before it to count), and
+	// it leaves with last_was_right_anchor clear.  A true chain that finds that anchor from the same position -- in a
+	// stretch without homology the two chains fall in with each other's positions after a few steps, and chance
+	// anchors come every few hundred nucleotides -- and is no right anchor of what it remembers is in that state:
+	// it need not walk on to the cold chain's second anchor.
+	ChainState MF = initial_state();
+	bool hasF = false;
+	if (totalC >= 1 && totalC != ANDI_ANCHORS_UNKNOWN) {
+		const uint4 f1 = *(const uint4 *)marks[0].first;
+		MF.p = f1.x + f1.z + 1, MF.lastS = f1.y, MF.lastQ = f1.x, MF.lastLen = f1.z;
+		hasF = f1.x + f1.z + 1 < it.end; // (an anchor that leaves the segment is the cold exit: nothing to gain)
+		if (hasF && MF.p > lastMarkP) lastMarkP = MF.p;
+	}
 	int hit = -1;
-	if (anyMark) {
+	if (anyMark || hasF) {
 		for (;;) {
 #pragma unroll
 			for (int k = 0; k < ANDI_COLD_MARKS; ++k)
 				if (hit < 0 && M[k].pad[0] && same_state(T, M[k])) hit = k;
+			if (hit < 0 && hasF && same_state(T, MF)) hit = ANDI_COLD_MARKS;
 			if (hit >= 0 || T.p >= it.end || T.p > lastMarkP) break;
 			if (over_budget()) return;
 			T = lane_step<EXACT>(c, T, tT, w, found);
@@ -1029,8 +1044,12 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 	}
 	if (hit >= 0) {
 		tally_finish<1>(tT);
-		const uint32_t *markCounts = marks[hit].counts;
-		for (int t = 0; t < 16; ++t) owned[t] = tT.hist[t * BLOCK] + coldCounts[t] - markCounts[t];
+		if (hit == ANDI_COLD_MARKS) {
+			for (int t = 0; t < 16; ++t) owned[t] = tT.hist[t * BLOCK] + coldCounts[t];
+		} else {
+			const uint32_t *markCounts = marks[hit].counts;
+			for (int t = 0; t < 16; ++t) owned[t] = tT.hist[t * BLOCK] + coldCounts[t] - markCounts[t];
+		}
 		a.true_exit[slot] = a.cold_exit[slot];
 		return;
 	}
