@@ -978,6 +978,7 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 					owned[t] = v;
 				}
 				a.true_exit[slot] = a.cold_exit[slot];
+				STAT(ST_X0);
 				return;
 			}
 		}
@@ -1044,6 +1045,10 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 	}
 	if (hit >= 0) {
 		tally_finish<1>(tT);
+#ifdef ANDI_LANE_STATS
+		if (hit == ANDI_COLD_MARKS) STAT(ST_X1); else STAT(ST_X2);
+		atomicAdd(&g_lane_stats[ST_X7], (unsigned long long)steps);
+#endif
 		if (hit == ANDI_COLD_MARKS) {
 			for (int t = 0; t < 16; ++t) owned[t] = tT.hist[t * BLOCK] + coldCounts[t];
 		} else {
@@ -1100,6 +1105,10 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 			if (found) ++foundC;
 		}
 	}
+#ifdef ANDI_LANE_STATS
+	if (synced) STAT(ST_X3); else if (psynced) STAT(ST_X4); else STAT(ST_X5);
+	atomicAdd(&g_lane_stats[(synced || psynced) ? ST_X7 : ST_X6], (unsigned long long)steps);
+#endif
 	tally_finish<1>(tT);
 	tally_finish<1>(tC);
 	// from the meeting point on, the cold chain's trajectory is the true one
@@ -1311,6 +1320,19 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 		stage(k_lane_stitch<true, false, false>, k_lane_stitch<true, false, true>);
 	else
 		stage(k_lane_stitch<false, false, false>, k_lane_stitch<false, false, true>);
+#ifdef ANDI_LANE_STATS
+	if (getenv("ANDI_LANE_STATS")) { // pass B's first stage: how its segments were settled, and the chain steps that took
+		static const char *names[8] = {"entered behind the cold chain's first anchor", "met behind its first anchor", "met at a mark",
+									   "met in phase 2", "position-synced", "left on their own", "steps of those that left on their own", "steps of the others"};
+		unsigned long long h[24];
+		(void)hipStreamSynchronize(st);
+		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lane_stats), sizeof h);
+		for (int k = 0; k < 8; ++k) fprintf(stderr, "stitch_stats %-48s %llu\n", names[k], h[ST_X0 + k]);
+		fprintf(stderr, "stitch_stats %-48s %llu\n", "reached phase 2", h[ST_SEARCH]);
+		memset(h, 0, sizeof h);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), h, sizeof h);
+	}
+#endif
 	const bool again = !getenv("ANDI_NO_RESTITCH");
 	for (uint32_t r = 0; again && r < ANDI_RESTITCH_ROUNDS; ++r) {
 		a.restitch_round = r;
