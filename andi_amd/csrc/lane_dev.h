@@ -29,6 +29,7 @@ constexpr uint32_t WNT = 32; // symbols per window
 constexpr uint32_t EMPTY = ~0u;
 constexpr int32_t NO_DIAG = INT32_MIN;
 constexpr uint32_t ONES = 0x11111111u;
+constexpr uint32_t TOPS = 0x88888888u;
 constexpr uint32_t MULTI_MAX = 32; // occurrences a lane extends along one by one; more: binary search
 constexpr uint32_t ROUNDS_MULTI_MAX = 8; // (scan_rounds.hip keeps the positions in registers)
 
@@ -36,26 +37,26 @@ constexpr uint32_t ROUNDS_MULTI_MAX = 8; // (scan_rounds.hip keeps the positions
 struct LWin {
 	uint32_t q0;
 	int32_t dg;
-	uint4 q, s;
-	uint4 d; // bit 4k of word j: symbols 8j + k differ
+	uint4 q, s; // (where they differ is two instructions per word away, neq32: not worth four registers)
 };
 
 __device__ __forceinline__ uint32_t pick(const uint4 &v, uint32_t j) {
 	return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : j == 3 ? v.w : 0u;
 }
 
-__device__ __forceinline__ uint32_t neq8(uint32_t a, uint32_t b) { // one bit per differing nibble
-	uint32_t x = a ^ b;
-	x |= x >> 1;
-	x |= x >> 2;
-	return x & ONES;
+// One bit per differing symbol, the top bit of its nibble (bit 4k + 3 of a word: its symbols k differ).  Symbols are 0 ... 7 (k_pack_symbols; the paddings are
+// filled with 7s), so a nibble of a ^ b is 0 ... 7 and adding 7 carries into its top bit iff it is not 0 -- never
+// beyond: two instructions per word (v_xad_u32, v_and_b32) where or-ing the nibble's bits down took six, at ten
+// places of pass A's loop.
+__device__ __forceinline__ uint32_t neq8(uint32_t a, uint32_t b) {
+	return ((a ^ b) + 0x77777777u) & TOPS;
 }
 
 __device__ __forceinline__ uint4 neq32(const uint4 &a, const uint4 &b) {
 	return make_uint4(neq8(a.x, b.x), neq8(a.y, b.y), neq8(a.z, b.z), neq8(a.w, b.w));
 }
 
-// index (0..31) of the first marked symbol at or after symbol o, 32 if none
+// index (0..31) of the first marked symbol (any bit of its nibble) at or after symbol o, 32 if none
 __device__ __forceinline__ uint32_t first_from(const uint4 &d, uint32_t o) {
 	uint64_t lo = d.x | ((uint64_t)d.y << 32), hi = d.z | ((uint64_t)d.w << 32);
 	const uint32_t sh = 4 * o;
@@ -79,10 +80,13 @@ __device__ __forceinline__ uint4 ld_query(const PairCtx &c, uint32_t qa) { // qa
 	return ld_u128_unaligned(c.Qn + (qa >> 1));
 }
 
+// (One uniform base and a 32-bit lane offset -- N1 lies behind N0 in the same allocation, less than 4 GB away -- so
+// that the load takes its base from scalar registers: no 64-bit address arithmetic in the vector ALUs.)
 __device__ __forceinline__ uint4 ld_subject(const PairCtx &c, int32_t sa) { // sa >= -32
-	const int32_t odd = sa & 1;
-	g_u8p base = odd ? c.E.N1 : c.E.N0;
-	return ld_u128_unaligned(base + ((sa + odd) >> 1));
+	const uint32_t odd = (uint32_t)sa & 1u;
+	const uint32_t n1 = (uint32_t)(c.E.N1 - c.E.N0);
+	const uint32_t off = ((uint32_t)(sa + 32 + (int32_t)odd) >> 1) + (odd ? n1 : 0u);
+	return ld_u128_unaligned(c.E.N0 - 16 + off);
 }
 
 // 2-bit code (first symbol most significant) of the K symbols at offset o of the
@@ -120,10 +124,13 @@ struct LaneItem {
 // the work item of a slot (see lane_item for the layouts)
 __device__ __forceinline__ LaneItem lane_item_of_slot(const ScanArgs &a, unsigned long long slot);
 
-template <int NT = BLOCK> // threads per block
+// LAYOUT: 0 = whichever the call uses (a.adaptive), 1 = per-pair segments, 2 = one segment length.  A kernel compiled
+// for layout 1 knows that all lanes of a wavefront work on one pair: the query's base address and length stay in
+// scalar registers (five vector registers less per lane, query loads with a scalar base).
+template <int NT = BLOCK, int LAYOUT = 0> // NT: threads per block
 __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 	LaneItem it;
-	if (!a.adaptive) {
+	if (LAYOUT == 2 || (LAYOUT == 0 && !a.adaptive)) {
 		it.sub = blockIdx.y;
 		const uint32_t w = blockIdx.x * NT + threadIdx.x;
 		it.valid = w < a.total_segs;

@@ -200,7 +200,7 @@ __device__ __forceinline__ void window_count_gap(Window<G> &w, Tally &tally, g_u
 			uint32_t t = (uint32_t)__builtin_ctz(d);
 			uint32_t word = t < 8 ? (t < 4 ? w.sb.x : w.sb.y) : (t < 12 ? w.sb.z : w.sb.w);
 			uint8_t sb = (uint8_t)(word >> (8 * (t & 3u)));
-			if ((int8_t)sb >= 'A') atomicAdd(&tally.hist[((nt_code(sb) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)) * tally.hs], 1u);
+			if ((int8_t)sb >= 'A') lds_add(&tally.hist[((nt_code(sb) << 2) | ((w.qc >> (30 - 2 * t)) & 3u)) * tally.hs], 1u);
 		}
 		const uint32_t done = hi - lo;
 		q += done, s += done, len -= done;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 
 	// src/process.c:199-211
 	Tally last;
-	last.hist = total, last.hs = 1, last.quarter = 0, last.rest = 0;
+	last.hist = (lds_u32 *)total, last.hs = 1, last.quarter = 0, last.rest = 0;
 	last.same[0] = last.same[1] = last.same[2] = last.same[3] = 0;
 	if (fin.lastLen >= c.qlen || fin.lwra || fin.lastLen >= 2 * c.thr) {
 		const bool whole = fin.lastLen >= c.qlen;

@@ -54,8 +54,15 @@ __device__ __forceinline__ ChainState cold_state(uint32_t start, uint32_t n) {
 // per-group histogram in LDS; the equal runs of model_count_equal (RAW/JC/Kimura:
 // len/4 to A->A, C->C, G->G and len/4 + len%4 to T->T, src/model.c:247-253) are
 // two running sums in registers, folded into the histogram at the end.
+// (The histogram pointer carries its address space: pass B picks one of two tallies per lane, and through a generic
+// pointer the compiler can no longer tell that the counts go to LDS -- flat atomics, the tally structs on the stack.)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ void lds_add(lds_u32 *p, uint32_t v) {
+	(void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 struct Tally {
-	uint32_t *hist;        // LDS, 16 cells `hs` words apart: substitutions found in gaps
+	lds_u32 *hist;         // LDS, 16 cells `hs` words apart: substitutions found in gaps
 	uint32_t hs;
 	uint32_t quarter, rest; // equal runs (uniform within the group)
 	uint32_t same[4];      // A->A, C->C, G->G, T->T pairs this lane saw in gaps
@@ -75,7 +82,7 @@ __device__ __forceinline__ constexpr uint32_t hist_stride() {
 
 template <int G>
 __device__ __forceinline__ void tally_begin(Tally &t, uint32_t *hist) {
-	t.hist = hist, t.hs = hist_stride<G>(), t.quarter = 0, t.rest = 0;
+	t.hist = (lds_u32 *)hist, t.hs = hist_stride<G>(), t.quarter = 0, t.rest = 0;
 	t.same[0] = t.same[1] = t.same[2] = t.same[3] = 0;
 	for (uint32_t c = Group<G>::sub(); c < 16; c += G) hist[c * t.hs] = 0;
 }

@@ -27,7 +27,6 @@ __device__ __forceinline__ void win_load(LWin &w, const PairCtx &c, uint32_t qa,
 	w.q = ld_query(c, qa);
 	if (dg != NO_DIAG) {
 		w.s = ld_subject(c, (int32_t)qa + dg);
-		w.d = neq32(w.q, w.s);
 	}
 }
 
@@ -48,7 +47,7 @@ __device__ __forceinline__ uint32_t lcp_window(LWin &w, const PairCtx &c, uint32
 		STAT(ST_LCP_RELOAD);
 		o = p - qa;
 	}
-	const uint32_t f = first_from(w.d, o);
+	const uint32_t f = first_from(neq32(w.q, w.s), o);
 	open = f >= WNT;
 	return f - o;
 }
@@ -63,7 +62,7 @@ __device__ __forceinline__ uint32_t lcp_slide(LWin &w, const PairCtx &c, uint32_
 	while (len < maxlen) {
 		win_load(w, c, w.q0 + WNT, dg);
 		STAT(ST_LCP_SLIDE);
-		const uint32_t f = first_from(w.d, 0);
+		const uint32_t f = first_from(neq32(w.q, w.s), 0);
 		len += f;
 		if (f < WNT) break;
 	}
@@ -103,19 +102,20 @@ __device__ __forceinline__ void lane_count_gap(LWin &w, const PairCtx &c, Tally 
 		const uint32_t lo = q - w.q0, hi = lo + len < WNT ? lo + len : WNT;
 		for (uint32_t j = lo >> 3; 8 * j < hi; ++j) {
 			const uint32_t a = lo > 8 * j ? lo - 8 * j : 0u, b = hi - 8 * j < 8 ? hi - 8 * j : 8u;
-			const uint32_t qw = pick(w.q, j), sw = pick(w.s, j), dw = pick(w.d, j);
+			const uint32_t qw = pick(w.q, j), sw = pick(w.s, j), dw = neq8(qw, sw) >> 3;
 			STAT(ST_GAP_WORDS);
 			// both symbols are nucleotides (bit 2 clear), src/model.c:318-320
 			const uint32_t ok = symbol_range(a, b) & ~(qw >> 2) & ~(sw >> 2);
 			const uint32_t eq = ok & ~dw, b0 = qw, b1 = qw >> 1;
-			tally.same[0] += (uint32_t)__builtin_popcount(eq & ~(b0 | b1));
-			tally.same[1] += (uint32_t)__builtin_popcount(eq & b0 & ~b1);
-			tally.same[2] += (uint32_t)__builtin_popcount(eq & b1 & ~b0);
-			tally.same[3] += (uint32_t)__builtin_popcount(eq & b0 & b1);
+			// (equal pairs go to the diagonal cells in LDS like the substitutions, not to tally.same: four registers less)
+			lds_add(&tally.hist[0], (uint32_t)__builtin_popcount(eq & ~(b0 | b1)));
+			lds_add(&tally.hist[5 * tally.hs], (uint32_t)__builtin_popcount(eq & b0 & ~b1));
+			lds_add(&tally.hist[10 * tally.hs], (uint32_t)__builtin_popcount(eq & b1 & ~b0));
+			lds_add(&tally.hist[15 * tally.hs], (uint32_t)__builtin_popcount(eq & b0 & b1));
 			for (uint32_t ne = ok & dw; ne; ne &= ne - 1) {
 				const uint32_t k = (uint32_t)__builtin_ctz(ne);
 				STAT(ST_SUBST);
-				atomicAdd(&tally.hist[((((sw >> k) & 3u) << 2) | ((qw >> k) & 3u)) * tally.hs], 1u);
+				lds_add(&tally.hist[((((sw >> k) & 3u) << 2) | ((qw >> k) & 3u)) * tally.hs], 1u);
 			}
 		}
 		const uint32_t done = hi - lo;
@@ -139,10 +139,10 @@ __device__ __forceinline__ void lane_count_anchor(const PairCtx &c, Tally &t, ui
 			const uint32_t a = lo > 8 * j ? lo - 8 * j : 0u, b = hi - 8 * j < 8 ? hi - 8 * j : 8u;
 			const uint32_t qw = pick(qv, j);
 			const uint32_t ok = symbol_range(a, b) & ~(qw >> 2), b0 = qw, b1 = qw >> 1;
-			t.same[0] += (uint32_t)__builtin_popcount(ok & ~(b0 | b1));
-			t.same[1] += (uint32_t)__builtin_popcount(ok & b0 & ~b1);
-			t.same[2] += (uint32_t)__builtin_popcount(ok & b1 & ~b0);
-			t.same[3] += (uint32_t)__builtin_popcount(ok & b0 & b1);
+			lds_add(&t.hist[0], (uint32_t)__builtin_popcount(ok & ~(b0 | b1)));
+			lds_add(&t.hist[5 * t.hs], (uint32_t)__builtin_popcount(ok & b0 & ~b1));
+			lds_add(&t.hist[10 * t.hs], (uint32_t)__builtin_popcount(ok & b1 & ~b0));
+			lds_add(&t.hist[15 * t.hs], (uint32_t)__builtin_popcount(ok & b0 & b1));
 		}
 	}
 }
@@ -285,7 +285,7 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 		st.lastQ = st.p;
 		st.lastLen = curLen;
 	}
-	if (tq0 != EMPTY) w.q0 = tq0, w.q = tq, w.s = ts, w.d = neq32(tq, ts); // (w.dg: the diagonal followed)
+	if (tq0 != EMPTY) w.q0 = tq0, w.q = tq, w.s = ts; // (w.dg: the diagonal followed)
 	st.p += curLen + 1;
 	return st;
 }
@@ -432,7 +432,7 @@ __device__ __forceinline__ void lane_cold_stream(const ScanArgs &a, const LaneIt
 				STAT(ST_LCP_RELOAD);
 			}
 			for (;;) { // the anchors and mismatches this window holds
-				const uint32_t maxlen = c.qlen - st.p, o = pos - w.q0, f = first_from(w.d, o);
+				const uint32_t maxlen = c.qlen - st.p, o = pos - w.q0, f = first_from(neq32(w.q, w.s), o);
 				curLen += f - o, pos += f - o;
 				if (f >= WNT && curLen < maxlen) { // the match runs on past the window: slide on the next trip
 					const uint32_t gap = st.p - st.lastQ - st.lastLen;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_stream_floor(ScanArgs a, int varia
 						count_equal(tally, len);
 						const uint32_t sh = 4 * (f & 7u);
 						const uint32_t qn = (pick(qv, f >> 3) >> sh) & 15u, sn = (pick(sv, f >> 3) >> sh) & 15u;
-						if (!((qn | sn) & 4u)) atomicAdd(&tally.hist[(((sn & 3u) << 2) | (qn & 3u)) * BLOCK], 1u);
+						if (!((qn | sn) & 4u)) lds_add(&tally.hist[(((sn & 3u) << 2) | (qn & 3u)) * BLOCK], 1u);
 						++anchors;
 					}
 					lastQ = pos + 1;
@@ -640,7 +640,7 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 			const uint32_t w0 = b0 + WNT * k;
 			if (x - w0 < WNT) {
 				w.q0 = w0, w.q = Bq[k], w.dg = bdg, hit = true;
-				if (bdg != NO_DIAG) w.s = Bs[k], w.d = neq32(Bq[k], Bs[k]);
+				if (bdg != NO_DIAG) w.s = Bs[k];
 			}
 		}
 		return hit;
@@ -840,11 +840,11 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_stream(ScanArgs a) {
 // same divergence and stay in step.  (Persistent lanes that fetch their next segment
 // from a counter when done were measured 15-50 % slower: they mix pairs of different
 // divergence in one wavefront.)
-template <bool EXACT, int OCC>
+template <bool EXACT, int OCC, bool PER_PAIR>
 __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 	__shared__ uint32_t s_hist[16 * BLOCK];
-	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
-	const LaneItem it = lane_item(a);
+	if (!PER_PAIR && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
+	const LaneItem it = lane_item<BLOCK, PER_PAIR ? 1 : 2>(a);
 	if (!it.valid || !lane_is_mine(a, it, false)) return;
 	Tally tally;
 	tally_begin<1>(tally, s_hist + threadIdx.x);
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 	LWin w;
 	w.q0 = EMPTY, w.dg = NO_DIAG;
 	const size_t slot = it.slot;
-	ColdMark *marks = a.marks + slot * ANDI_COLD_MARKS;
+	auto marks = [&]() { return a.marks + slot * ANDI_COLD_MARKS; }; // (formed where it is used: not held through the loop)
 	uint32_t anchors = 0;
 	while (st.p < it.end) {
 		bool found;
@@ -871,9 +871,9 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 		}
 #endif
 		st = lane_step<EXACT>(c, st, tally, w, found);
-		if (found && ++anchors == 1) *(uint4 *)marks[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
+		if (found && ++anchors == 1) *(uint4 *)marks()[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
 		if (found && anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
-			ColdMark *m = marks + (anchors - 2);
+			ColdMark *m = marks() + (anchors - 2);
 			ChainState ms = st;
 			ms.pad[0] = 1;
 			m->st = ms;
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 			for (int t = 0; t < 4; ++t) mc[t] = make_uint4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
 		}
 	}
-	for (uint32_t k = anchors < 2 ? 0 : anchors - 1; k < ANDI_COLD_MARKS; ++k) marks[k].st.pad[0] = 0; // unused marks
+	for (uint32_t k = anchors < 2 ? 0 : anchors - 1; k < ANDI_COLD_MARKS; ++k) marks()[k].st.pad[0] = 0; // unused marks
 
 	st.pad[1] = anchors < 255 ? anchors : 255;
 	a.cold_exit[slot] = st;
@@ -1214,7 +1214,7 @@ hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N
 static int lane_occupancy() { // waves per SIMD pass A is compiled for (experiments: ANDI_LANE_OCC)
 	const char *e = getenv("ANDI_LANE_OCC");
 	int v = e ? atoi(e) : 0;
-	return (v == 4 || v == 6 || v == 7 || v == 8) ? v : 6; // 6: no spills, measured best
+	return (v == 6 || v == 7 || v == 8) ? v : 8; // 8 (64 registers, two spilled outside the loop): 6.29 ms against 6.41 at 7 and 6.6 at 6 on the bench set
 }
 
 template <bool EXACT>
@@ -1252,11 +1252,18 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 		k_lane_quad<EXACT><<<grid, BLOCK, 0, side ? a.side_stream : st>>>(a);
 		if (side) (void)hipEventRecord(a.side_join, a.side_stream);
 	}
-	switch (lane_occupancy()) {
-		case 4: k_lane_cold<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
-		case 6: k_lane_cold<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break;
-		case 7: k_lane_cold<EXACT, 7><<<grid, BLOCK, pad, st>>>(a); break;
-		default: k_lane_cold<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
+	if (a.adaptive) {
+		switch (lane_occupancy()) {
+			case 6: k_lane_cold<EXACT, 6, true><<<grid, BLOCK, pad, st>>>(a); break;
+			case 7: k_lane_cold<EXACT, 7, true><<<grid, BLOCK, pad, st>>>(a); break;
+			default: k_lane_cold<EXACT, 8, true><<<grid, BLOCK, pad, st>>>(a); break;
+		}
+	} else {
+		switch (lane_occupancy()) {
+			case 6: k_lane_cold<EXACT, 6, false><<<grid, BLOCK, pad, st>>>(a); break;
+			case 7: k_lane_cold<EXACT, 7, false><<<grid, BLOCK, pad, st>>>(a); break;
+			default: k_lane_cold<EXACT, 8, false><<<grid, BLOCK, pad, st>>>(a); break;
+		}
 	}
 	if (side) (void)hipStreamWaitEvent(st, a.side_join, 0);
 	return hipGetLastError();

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void k_rounds_cold(ScanArgs a) {
 	uint4 *const lq = s_q + lane, *const ls = s_s + lane; // this lane's piece 0; piece k is 64 further
 
 	Tally tally;
-	tally.hist = s_hist + lane, tally.hs = 64, tally.quarter = 0, tally.rest = 0;
+	tally.hist = (lds_u32 *)(s_hist + lane), tally.hs = 64, tally.quarter = 0, tally.rest = 0;
 	tally.same[0] = tally.same[1] = tally.same[2] = tally.same[3] = 0;
 #pragma unroll
 	for (int t = 0; t < 16; ++t) tally.hist[t * 64] = 0;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64) void k_rounds_cold(ScanArgs a) {
 					const uint32_t lo = gq - x, hi = lo + glen < WNT ? lo + glen : WNT;
 					for (uint32_t j = lo >> 3; 8 * j < hi; ++j) {
 						const uint32_t wa = lo > 8 * j ? lo - 8 * j : 0u, wb = hi - 8 * j < 8 ? hi - 8 * j : 8u;
-						const uint32_t qw = pick(qv, j), sw = pick(sv, j), dw = pick(dv, j);
+						const uint32_t qw = pick(qv, j), sw = pick(sv, j), dw = pick(dv, j) >> 3;
 						STAT(ST_GAP_WORDS);
 						// both symbols are nucleotides (bit 2 clear), src/model.c:318-320
 						const uint32_t ok = symbol_range(wa, wb) & ~(qw >> 2) & ~(sw >> 2);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void k_rounds_cold(ScanArgs a) {
 						for (uint32_t ne = ok & dw; ne; ne &= ne - 1) {
 							const uint32_t k = (uint32_t)__builtin_ctz(ne);
 							STAT(ST_SUBST);
-							atomicAdd(&tally.hist[((((sw >> k) & 3u) << 2) | ((qw >> k) & 3u)) * 64], 1u);
+							lds_add(&tally.hist[((((sw >> k) & 3u) << 2) | ((qw >> k) & 3u)) * 64], 1u);
 						}
 					}
 					const uint32_t dn = hi - lo;
