@@ -113,6 +113,9 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 #define ANDI_RESTITCH_ROUNDS 3
 #define ANDI_STITCH_BUDGET 48
 #define ANDI_LISTED_LANES 2
+#ifndef ANDI_LISTED_BLOCKS
+#define ANDI_LISTED_BLOCKS 1024 /* one round of the device at 4 wavefronts per SIMD; 4096: passes B/C 15.5 ms on the realistic set, 1024: 13.3, 512: 13.7 */
+#endif
 #define ANDI_STITCH_TOGETHER 40 /* steps of pass B's phase 2 in which the cold chain is replayed beside the true one */
 // pass A in rounds with line buffers (scan_rounds.hip); andi_rounds_lines() != 0: in use
 int andi_rounds_lines(void);

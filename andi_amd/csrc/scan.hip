@@ -461,13 +461,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	}
 	PairCtx c = make_ctx(a, sub, qidx);
 
-	// every segment k >= 1 was stitched assuming it is entered in the cold exit of entry_source(k)
+	// every segment k >= 1 was stitched assuming it is entered in the state used_entry[k]: right iff the true chain
+	// left segment k - 1 in that state
 	bool ok = true;
 	for (uint32_t k = 1 + threadIdx.x; k < nseg; k += BLOCK)
 		ok = ok && same_state(a.true_exit[row + k - 1], a.used_entry[row + k]);
 	const bool all_ok = __syncthreads_and(ok);
-	ChainState fin;
-	if (all_ok) {
+	{ // the owned counts of all segments (a segment that turns out wrong below is taken out again)
 		uint32_t sum[16];
 #pragma unroll
 		for (int t = 0; t < 16; ++t) sum[t] = 0;
@@ -485,42 +485,50 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 			for (int d = 32; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
 			if (lane == 0) atomicAdd(&total[t], v);
 		}
-		__syncthreads();
-		if (threadIdx.x >= 64) return;
-		fin = a.true_exit[row + nseg - 1];
-	} else {
-		if (threadIdx.x >= 64) return; // what follows is sequential: the first wavefront alone
-		ChainState st = initial_state();
-		for (uint32_t k = 0; k < nseg; ++k) {
-			ChainState assumed = k == 0 ? initial_state() : a.used_entry[row + k];
-			if (same_state(st, assumed)) {
-				if (lane < 16) total[lane] += a.owned[(row + k) * 16 + lane];
-				st = a.true_exit[row + k];
-			} else {
-				if (lane == 0) atomicAdd(a.fixups, 1ull);
-				uint32_t start = k * seg;
-				uint32_t e = start + seg;
-				uint32_t end = e < c.qlen ? e : c.qlen;
-				// rare; the general variant (runtime mode, per-nucleotide counting if asked for)
-				if (c.E.mode == ANDI_MODE_REFERENCE) {
-					if (c.exact)
-						stitch_segment<64, ANDI_MODE_REFERENCE, true>(c, st, start, end, a.cold_exit[row + k],
+	}
+	__syncthreads();
+	if (threadIdx.x >= 64) return; // what follows is sequential: the first wavefront alone
+	ChainState fin = a.true_exit[row + nseg - 1];
+	if (!all_ok) {
+		// Fix-ups.  The segments are consistent up to the first k whose check fails; from there the true chain is
+		// stitched again, segment after segment, until it enters a segment in the state that was assumed for it --
+		// from that segment on what pass B recorded holds again, up to the next check that fails.  (The wavefront
+		// looks for the failing checks 64 at a time: walking all segments of a pair one after the other, three
+		// dependent loads each, took longer than the fix-ups themselves -- 3 ms per step on the realistic set.)
+		uint32_t next = 1; // segments below this are settled
+		for (uint32_t base = 1; base < nseg; base += 64) {
+			const uint32_t kk = base + lane;
+			uint64_t bad = __ballot(kk < nseg && !same_state(a.true_exit[row + kk - 1], a.used_entry[row + kk]));
+			for (; bad; bad &= bad - 1) {
+				uint32_t k = base + (uint32_t)__builtin_ctzll(bad);
+				if (k < next) continue; // (inside, or right behind, a stretch that has been stitched again)
+				ChainState st = a.true_exit[row + k - 1];
+				while (k < nseg && !same_state(st, a.used_entry[row + k])) {
+					if (lane == 0) atomicAdd(a.fixups, 1ull);
+					const uint32_t start = k * seg, e = start + seg, end = e < c.qlen ? e : c.qlen;
+					// rare; the general variant (runtime mode, per-nucleotide counting if asked for)
+					if (c.E.mode == ANDI_MODE_REFERENCE) {
+						if (c.exact)
+							stitch_segment<64, ANDI_MODE_REFERENCE, true>(c, st, start, end, a.cold_exit[row + k],
+																		  a.cold_counts + (row + k) * 16, histT, histC);
+						else
+							stitch_segment<64, ANDI_MODE_REFERENCE, false>(c, st, start, end, a.cold_exit[row + k],
+																		   a.cold_counts + (row + k) * 16, histT, histC);
+					} else {
+						if (c.exact)
+							stitch_segment<64, ANDI_MODE_PROBE, true>(c, st, start, end, a.cold_exit[row + k],
 																	  a.cold_counts + (row + k) * 16, histT, histC);
-					else
-						stitch_segment<64, ANDI_MODE_REFERENCE, false>(c, st, start, end, a.cold_exit[row + k],
+						else
+							stitch_segment<64, ANDI_MODE_PROBE, false>(c, st, start, end, a.cold_exit[row + k],
 																	   a.cold_counts + (row + k) * 16, histT, histC);
-				} else {
-					if (c.exact)
-						stitch_segment<64, ANDI_MODE_PROBE, true>(c, st, start, end, a.cold_exit[row + k],
-																  a.cold_counts + (row + k) * 16, histT, histC);
-					else
-						stitch_segment<64, ANDI_MODE_PROBE, false>(c, st, start, end, a.cold_exit[row + k],
-																   a.cold_counts + (row + k) * 16, histT, histC);
+					}
+					if (lane < 16) total[lane] += histT[lane] - a.owned[(row + k) * 16 + lane];
+					++k;
 				}
-				if (lane < 16) total[lane] += histT[lane];
+				if (k == nseg) fin = st; // (the last segment itself was stitched again)
+				next = k + 1;
 			}
 		}
-		fin = st;
 	}
 
 	// src/process.c:199-211

@@ -259,14 +259,18 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 		if (open && !KNOCK(c, 1)) {
 			const int32_t dg = w.dg;
 			uint32_t qa = w.q0;
+			// (A wavefront runs this loop as often as its longest match needs, so a round is kept to the test "all 32
+			// symbols equal?" -- seven instructions; where the match ends inside the last window is found once, behind it.)
+			bool differ = false;
 			while (curLen < maxlen) {
 				qa += WNT;
 				tq0 = qa, tq = ld_query(c, qa), ts = ld_subject(c, (int32_t)qa + dg);
 				STAT(ST_LCP_SLIDE);
-				const uint32_t f = first_from(neq32(tq, ts), 0);
-				curLen += f;
-				if (f < WNT) break;
+				differ = (((tq.x ^ ts.x) | (tq.y ^ ts.y)) | ((tq.z ^ ts.z) | (tq.w ^ ts.w))) != 0;
+				if (differ) break;
+				curLen += WNT;
 			}
+			if (differ) curLen += first_from(neq32(tq, ts), 0);
 		}
 		if (curLen > maxlen) curLen = maxlen;
 		found = curLen >= c.thr;
@@ -1317,7 +1321,7 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 	// segments that have a predecessor)
 	const size_t slots = a.adaptive ? (size_t)64 * a.max_waves : (size_t)a.nsub * a.total_segs;
 	const uint32_t per_block = WAVES_PER_BLOCK * ANDI_LISTED_LANES;
-	const unsigned lblocks = (unsigned)std::min<size_t>((slots + per_block - 1) / per_block, 4096); // (strides over the list)
+	const unsigned lblocks = (unsigned)std::min<size_t>((slots + per_block - 1) / per_block, ANDI_LISTED_BLOCKS); // (strides over the list)
 	auto stage = [&](auto main_kernel, auto listed_kernel) {
 		(void)hipMemsetAsync(a.defer_count, 0, sizeof(uint32_t), st);
 		main_kernel<<<grid, BLOCK, 0, st>>>(a);

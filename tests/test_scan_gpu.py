@@ -348,6 +348,26 @@ def test_realistic_divergence_structure(ctx, orc):
     _check_set(ctx, orc, joined, segments=(0, 700))
 
 
+def test_fixups_in_pass_c(ctx, orc, monkeypatch):
+    """Pass C stitches again, one after the other, the segments whose assumed entry state turned out wrong
+    (k_scan_reduce): it looks for the failing checks 64 at a time and follows each stretch until the true chain
+    enters a segment in the state that was assumed for it.  Without pass B's re-stitch rounds, on genomes with
+    repeats and unrelated stretches and with short segments, there are hundreds of such stretches -- isolated ones,
+    runs over several segments, the last segment of a query: the counts stay bit-exact and the fix-ups are counted."""
+    from andi_amd import synth
+    monkeypatch.setenv("ANDI_NO_RESTITCH", "1")
+    seqs, _ = synth.realistic_set(5, 200000, 0.001, 0.06, seed=41, novel_fraction=0.1)
+    seqs.append(seqs[1][:150017])  # ends inside a segment
+    want = orc.dist_matrix(seqs, threads=4)
+    total = 0
+    for seg in (0, 64, 300, 2048):
+        ctx.timings_reset()
+        got, t = _gpu_rows(ctx, seqs, segment=seg)
+        assert (got == want).all(), seg
+        total += t["fixups"]
+    assert total > 100, total
+
+
 @pytest.mark.parametrize("variant", ["1", "2"])
 def test_pass_a_variants_agree(ctx, orc, monkeypatch, variant):
     """ANDI_LANE_STREAM=1: pass A with the chain step cut in two (scan_lane.hip: lane_cold_stream) -- every trip
