@@ -320,13 +320,34 @@ __global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
 	uint32_t sum = r.len < cap ? r.len : cap;
 #pragma unroll
 	for (int d = 32; d; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d);
+	// A pair whose matches are long on average may still spend most of its chain steps where it has none: 10 % of
+	// unrelated sequence (genomic islands: a step every 13 nucleotides there) are most of the steps of a pair with
+	// a mismatch every 500, and probing is what k_lane_quad is slow at (the realistic set: pass A 11.2 ms with
+	// such pairs in k_lane_quad, 10.6 ms without).  So a candidate is sampled at 192 more positions, and goes to
+	// k_lane_quad only if its short matches are no more than its mean explains (matches end at random: a fraction
+	// 1 - exp(-threshold / mean) of the positions sees less than the threshold), within two standard deviations.
+	bool islands = false;
+	if ((sum >> 6) >= a.quad_min_match && a.quad_min_match != 0) { // (wave-uniform)
+		uint32_t shorts = r.len < c.thr ? 1u : 0u;
+		for (uint32_t k = 1; k < 4; ++k) {
+			const uint32_t pk = (uint32_t)(((uint64_t)(8 * lane + 2 * k + 1) * c.qlen) >> 9); // between the first samples
+			LWin wk;
+			wk.q0 = EMPTY, wk.dg = NO_DIAG;
+			const Probe rk = lane_probe(c, pk, wk, c.thr + 1);
+			shorts += rk.len < c.thr ? 1u : 0u;
+		}
+#pragma unroll
+		for (int d = 32; d; d >>= 1) shorts += (uint32_t)__shfl_xor((int)shorts, d);
+		const float expect = 256.f * (1.f - __expf(-(float)c.thr / (float)(sum >> 6)));
+		islands = (float)shorts > expect + 2.f * sqrtf(expect * (1.f - expect / 256.f)) + 2.f;
+	}
 	if (lane == 0) {
 		const uint32_t want = (sum >> 6) * a.seg_factor; // mean match length * factor
 		uint32_t cls = 0;
 		while (cls < a.max_class && (a.seg0 << cls) < want) ++cls;
 		const uint32_t seg = a.seg0 << cls, nseg = (c.qlen + seg - 1) / seg;
 		// bit 7: the pair's matches are long enough for pass A with the streams fetched by quads (k_lane_quad)
-		a.pair_class[pair] = (uint8_t)(cls | ((sum >> 6) >= a.quad_min_match ? 0x80u : 0u));
+		a.pair_class[pair] = (uint8_t)(cls | ((sum >> 6) >= a.quad_min_match && !islands ? 0x80u : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
 	}
 }
