@@ -54,9 +54,11 @@ struct ScanArgs {
 	ChainState *used_entry; // the state pass B let the true chain enter the segment in (pass C verifies it)
 	uint32_t *restitch_count; // [r]: segments stitched again in round r (lane scan); [ANDI_RESTITCH_ROUNDS]: true chains that left their segment on their own
 	uint32_t restitch_round;
-	// Segments whose stitching takes more than ANDI_STITCH_BUDGET chain steps are put on a list and
-	// stitched by a second launch, 64 of them per wavefront: one long replay (through a repeat, along the
-	// edge of an island) would otherwise hold up the 63 settled segments of its wavefront.
+	// Segments whose stitching takes more than ANDI_STITCH_BUDGET chain steps -- or more than ANDI_STITCH_FIRST
+	// when no more than ANDI_STITCH_FEW lanes of their wavefront are still at it and the call has had more than
+	// ANDI_STITCH_MANY such replays -- are put on a list and stitched
+	// by a second launch, few of them per wavefront: one long replay (through a repeat, along the edge of an
+	// island) would otherwise hold up the 63 settled segments of its wavefront.
 	unsigned long long *defer_list; // slots
 	uint32_t *defer_count;
 	uint32_t defer_base; // first list entry of this launch
@@ -111,7 +113,19 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 // settles one more segment of every such stretch, all stretches at once.  Rounds after one without any
 // re-stitched segment return at once.
 #define ANDI_RESTITCH_ROUNDS 3
+#ifndef ANDI_STITCH_FIRST
+#define ANDI_STITCH_FIRST 12
+#endif
+#ifndef ANDI_STITCH_FEW
+#define ANDI_STITCH_FEW 12
+#endif
+#ifndef ANDI_STITCH_MANY
+#define ANDI_STITCH_MANY 4096
+#endif
+#define ANDI_STRAGGLERS 12 /* restitch_count[this]: replays of the call so far that went past ANDI_STITCH_FIRST steps */
+#ifndef ANDI_STITCH_BUDGET
 #define ANDI_STITCH_BUDGET 48
+#endif
 #define ANDI_LISTED_LANES 2
 #ifndef ANDI_LISTED_BLOCKS
 #define ANDI_LISTED_BLOCKS 1024 /* one round of the device at 4 wavefronts per SIMD; 4096: passes B/C 15.5 ms on the realistic set, 1024: 13.3, 512: 13.7 */

@@ -934,8 +934,15 @@ template <bool EXACT, bool AGAIN, bool LISTED>
 __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &it, uint32_t (*s_hist)[16 * BLOCK]) {
 	const size_t slot = it.slot;
 	uint32_t steps = 0; // chain steps replayed so far
+	bool early = false;
 	auto over_budget = [&]() { // (not LISTED) too long for this launch: leave it to the listed one
-		if (++steps <= ANDI_STITCH_BUDGET || LISTED) return false;
+		if (++steps <= ANDI_STITCH_FIRST || LISTED) return false;
+		// Past ANDI_STITCH_FIRST steps a replay leaves early if its wavefront is nearly empty by now -- but only if the
+		// list is going to be long anyway: a launch over a short list costs its longest replay (0.1 ms on the bench
+		// set, where the few stragglers ride along with the other wavefronts for nothing), a long one frees the
+		// wavefronts that one or two replays would hold for the whole budget (the realistic set: 11.8 -> 9.4 ms).
+		if (steps == ANDI_STITCH_FIRST + 1) early = atomicAdd(&a.restitch_count[ANDI_STRAGGLERS], 1u) >= ANDI_STITCH_MANY;
+		if (steps <= ANDI_STITCH_BUDGET && !(early && __builtin_popcountll(__ballot(1)) <= ANDI_STITCH_FEW)) return false;
 		a.defer_list[atomicAdd(a.defer_count, 1u)] = (unsigned long long)slot;
 		return true;
 	};
