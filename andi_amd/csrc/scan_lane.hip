@@ -202,9 +202,19 @@ __device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &
 	// place where the lanes of a wavefront extend matches, not two in a row.
 	// (Four occurrences per round trip -- one 16-byte load of positions, four windows in flight -- were measured:
 	// 12 more registers, a wavefront less per SIMD, pass A 7.4 -> 7.9 ms.)
-	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
+	// (The positions of a repeated K-mer are fetched two at a time: a trip of a wavefront's loop waits for each of these
+	// loads in turn, as often as its lane with the most occurrences needs.)
+	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0, nextPos = 0;
 	for (uint32_t i = 0; i < cnt; ++i) {
-		const uint32_t pos = kind == DEEP_SINGLE ? x : (uint32_t)E.SA[x + i];
+		uint32_t pos = x;
+		if (kind != DEEP_SINGLE) {
+			if (i & 1u) {
+				pos = nextPos;
+			} else {
+				const uint64_t two = ld_u64_unaligned((g_u8p)(E.SA + x + i)); // (SA is padded by eight entries)
+				pos = (uint32_t)two, nextPos = (uint32_t)(two >> 32);
+			}
+		}
 		if (kind != DEEP_SINGLE) STAT(ST_MULTI_CAND);
 		const uint32_t len = K + lane_extend(w, c, o + K, (int32_t)(pos - p), qrem - K);
 		if (len > bestLen) {
