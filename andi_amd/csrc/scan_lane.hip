@@ -260,7 +260,23 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 	const uint32_t tryS = st.lastS + advance;
 	uint4 tq = make_uint4(0, 0, 0, 0), ts = tq;
 	uint32_t tq0 = EMPTY;
-	if (tryS < n && gap <= c.thr) {
+	const bool lucky = tryS < n && gap <= c.thr;
+	// ONE place where the window around p is fetched, whatever it is wanted for: the lucky attempt (on the last
+	// anchor's diagonal, from the gap behind it on) or the K-mer of the probe -- a wavefront waits at every such
+	// place once per trip.  It is fetched so that it also holds the K-mer at p, should the attempt fail (lcp_window
+	// and lane_probe find what they need and fetch nothing).
+	{
+		const uint32_t K = (uint32_t)c.E.deepK, o = st.p - w.q0;
+		int32_t dg = lucky ? (int32_t)(tryS - st.p) : w.dg;
+		uint32_t back = lucky ? (gap < 16 ? gap : 16u) : 0u;
+		if (w.q0 == EMPTY || st.p < w.q0 || o + K > WNT || (lucky && w.dg != dg)) {
+			const uint32_t qa = (st.p - back) & ~1u;
+			if (dg != NO_DIAG && (uint32_t)((int32_t)qa + dg) >= n) dg = NO_DIAG; // (only without a lucky attempt: tryS < n)
+			win_load(w, c, qa, dg);
+			STAT(ST_LCP_RELOAD);
+		}
+	}
+	if (lucky) {
 		STAT(ST_LUCKY_TRY);
 		const uint32_t maxlen = c.qlen - st.p;
 		bool open;
