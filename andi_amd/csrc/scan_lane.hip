@@ -30,43 +30,15 @@ __device__ __forceinline__ void win_load(LWin &w, const PairCtx &c, uint32_t qa,
 	}
 }
 
-// lcp(Q + p, S + t, maxlen) (src/process.c:59-65) in two parts.  lcp_window answers from
-// the window: a window that has to be fetched starts `back` (<= 16) symbols before p,
-// where the gap since the last anchor begins, so that the gap's substitutions can be
-// counted from it too.  It returns the matching symbols inside the window and sets
-// `open` if the match runs on past the window's end; lcp_slide then follows it, moving
-// the window along (the caller counts the gap first, while the window still holds it).
-__device__ __forceinline__ uint32_t lcp_window(LWin &w, const PairCtx &c, uint32_t p, uint32_t t, uint32_t back,
-											   bool &open) {
-	const int32_t dg = (int32_t)(t - p);
-	uint32_t o = p - w.q0;
-	if (w.q0 == EMPTY || w.dg != dg || p < w.q0 || o >= WNT) {
-		if (back > 16) back = 16;
-		const uint32_t qa = (p - back) & ~1u;
-		win_load(w, c, qa, dg);
-		STAT(ST_LCP_RELOAD);
-		o = p - qa;
-	}
+// lcp(Q + p, S + t, maxlen) (src/process.c:59-65), the part the window answers: lane_step has fetched it on the
+// diagonal t - p, from `back` (<= 16) symbols before p on -- where the gap since the last anchor begins, so that the
+// gap's substitutions can be counted from it too.  Returns the matching symbols inside the window and sets `open` if
+// the match runs on past the window's end (lane_step then follows it in a window of its own).
+__device__ __forceinline__ uint32_t lcp_window(const LWin &w, uint32_t p, bool &open) {
+	const uint32_t o = p - w.q0;
 	const uint32_t f = first_from(neq32(w.q, w.s), o);
 	open = f >= WNT;
 	return f - o;
-}
-
-// Follows a match past the window, a window per round trip; the window is left on the piece where
-// the match ended.  (Pairs whose matches are long take pass A through k_lane_quad.  Before that kernel
-// existed a match that survived its second window was followed two windows per round trip -- a second
-// and a third place where windows are compared, which every wavefront paid for on nearly every trip.
-// Folding this loop and lcp_window into one loop with a conditional fetch was measured: slower.)
-__device__ __forceinline__ uint32_t lcp_slide(LWin &w, const PairCtx &c, uint32_t len, uint32_t maxlen) {
-	const int32_t dg = w.dg;
-	while (len < maxlen) {
-		win_load(w, c, w.q0 + WNT, dg);
-		STAT(ST_LCP_SLIDE);
-		const uint32_t f = first_from(neq32(w.q, w.s), 0);
-		len += f;
-		if (f < WNT) break;
-	}
-	return len;
 }
 
 // Common prefix of Q[q0 + from ..] and S[q0 + from + dg ..], at most lim, where the
@@ -149,7 +121,8 @@ __device__ __forceinline__ void lane_count_anchor(const PairCtx &c, Tally &t, ui
 
 // anchor() (src/process.c:113-123) through the probe table, as scan.hip's probe_step
 // (`cap`: the caller does not care about match lengths beyond it)
-__device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &w, uint32_t cap = ~0u) {
+// (`fetched`: the caller has made sure that the window holds the K-mer at p)
+__device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &w, uint32_t cap = ~0u, bool fetched = false) {
 	const EsaG &E = c.E;
 	const uint32_t qrem = c.qlen - p < cap ? c.qlen - p : cap, K = (uint32_t)E.deepK;
 	g_u8p q = c.Q + p;
@@ -161,7 +134,7 @@ __device__ __forceinline__ Probe lane_probe(const PairCtx &c, uint32_t p, LWin &
 		return r0;
 	}
 	uint32_t o = p - w.q0;
-	if (w.q0 == EMPTY || p < w.q0 || o + K > WNT) {
+	if (!fetched && (w.q0 == EMPTY || p < w.q0 || o + K > WNT)) {
 		const uint32_t qa = p & ~1u;
 		int32_t dg = w.dg; // stay on the diagonal the window was on while that is inside the text
 		if (dg != NO_DIAG && (uint32_t)((int32_t)qa + dg) >= (uint32_t)E.n) dg = NO_DIAG;
@@ -281,7 +254,7 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 		const uint32_t maxlen = c.qlen - st.p;
 		bool open;
 		curS = tryS;
-		curLen = lcp_window(w, c, st.p, tryS, gap, open);
+		curLen = lcp_window(w, st.p, open);
 		if (open && !KNOCK(c, 1)) {
 			const int32_t dg = w.dg;
 			uint32_t qa = w.q0;
@@ -303,7 +276,7 @@ __device__ __forceinline__ ChainState lane_step(const PairCtx &c, ChainState st,
 	}
 	// anchor, src/process.c:113-123
 	if (!found) {
-		Probe pr = lane_probe(c, st.p, w);
+		Probe pr = lane_probe(c, st.p, w, ~0u, true);
 		curS = pr.pos;
 		curLen = pr.len;
 		found = pr.unique && curLen >= c.thr;
