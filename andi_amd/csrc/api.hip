@@ -656,7 +656,7 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 		if (err == hipSuccess) err = x;
 	};
 	chk(dmalloc(&q->pool, pool_bytes));
-	chk(dmalloc(&q->nib, pool_bytes / 2 + 16));
+	chk(dmalloc(&q->nib, pool_bytes / 2 + 64));
 	chk(hipHostMalloc((void **)&q->h_foreign, sizeof(int32_t), hipHostMallocDefault));
 	int32_t *d_foreign = nullptr;
 	chk(dmalloc(&d_foreign, 1));
