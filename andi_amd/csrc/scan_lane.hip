@@ -1242,10 +1242,14 @@ hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N
 	return hipSuccess;
 }
 
-static int lane_occupancy() { // waves per SIMD pass A is compiled for (experiments: ANDI_LANE_OCC)
+static int lane_occupancy(bool per_pair) { // waves per SIMD pass A is compiled for (experiments: ANDI_LANE_OCC)
 	const char *e = getenv("ANDI_LANE_OCC");
 	int v = e ? atoi(e) : 0;
-	return (v == 6 || v == 7 || v == 8) ? v : 8; // 8 (64 registers, two spilled outside the loop): 6.29 ms against 6.41 at 7 and 6.6 at 6 on the bench set
+	if (v == 6 || v == 7 || v == 8) return v;
+	// per-pair segments: 8 (64 registers, two spilled outside the loop): 6.29 ms against 6.41 at 7 and 6.6 at 6 on the
+	// bench set.  One segment length (the query's base and length are per lane): seven registers would be spilled
+	// at 8 -- 7.69 against 6.90 ms at 7 (bench set, 4096-symbol segments), 2.67 against 2.50 (2000 x 16.5 kbp)
+	return per_pair ? 8 : 7;
 }
 
 template <bool EXACT>
@@ -1265,7 +1269,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	}
 	const bool stream = getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) != 0; // measured slower: an experiment
 	if (stream) { // (k_lane_stream knows no classes: it takes every pair)
-		switch (lane_occupancy()) {
+		switch (lane_occupancy(false)) {
 			case 4: k_lane_stream<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
 			case 6: k_lane_stream<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break;
 			default: k_lane_stream<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
@@ -1284,13 +1288,13 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 		if (side) (void)hipEventRecord(a.side_join, a.side_stream);
 	}
 	if (a.adaptive) {
-		switch (lane_occupancy()) {
+		switch (lane_occupancy(true)) {
 			case 6: k_lane_cold<EXACT, 6, true><<<grid, BLOCK, pad, st>>>(a); break;
 			case 7: k_lane_cold<EXACT, 7, true><<<grid, BLOCK, pad, st>>>(a); break;
 			default: k_lane_cold<EXACT, 8, true><<<grid, BLOCK, pad, st>>>(a); break;
 		}
 	} else {
-		switch (lane_occupancy()) {
+		switch (lane_occupancy(false)) {
 			case 6: k_lane_cold<EXACT, 6, false><<<grid, BLOCK, pad, st>>>(a); break;
 			case 7: k_lane_cold<EXACT, 7, false><<<grid, BLOCK, pad, st>>>(a); break;
 			default: k_lane_cold<EXACT, 8, false><<<grid, BLOCK, pad, st>>>(a); break;
