@@ -1270,9 +1270,8 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	const bool stream = getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) != 0; // measured slower: an experiment
 	if (stream) { // (k_lane_stream knows no classes: it takes every pair)
 		switch (lane_occupancy(false)) {
-			case 4: k_lane_stream<EXACT, 4><<<grid, BLOCK, pad, st>>>(a); break;
-			case 6: k_lane_stream<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break;
-			default: k_lane_stream<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
+			case 8: k_lane_stream<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
+			default: k_lane_stream<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break; // (6: as measured)
 		}
 		return hipGetLastError();
 	}
