@@ -22,6 +22,7 @@
 #include "andi_dev.h"
 #include "andi_hip.h"
 #include "bootstrap.h"
+#include "dev_arena.h"
 #include "esa_build.h"
 #include "sa_device.h"
 #include "scan.h"
@@ -140,7 +141,7 @@ int fail(andi_hip_ctx *ctx, const char *what, hipError_t e) {
 
 template <typename T>
 hipError_t dmalloc(T **p, size_t count) {
-	return hipMalloc((void **)p, count * sizeof(T));
+	return andi_arena::dev_malloc((void **)p, count * sizeof(T)); // (out of large chunks: dev_arena.h)
 }
 
 void resolve_events(andi_hip_ctx *ctx) {
@@ -269,6 +270,7 @@ int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t err
 	}
 	auto *ctx = new andi_hip_ctx;
 	ctx->device = device;
+	andi_arena::retain(device); // (released in andi_hip_ctx_destroy)
 	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming);
@@ -294,14 +296,14 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	resolve_events(ctx);
-	if (ctx->scratch) (void)hipFree(ctx->scratch);
-	if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
+	if (ctx->scratch) (void)andi_arena::dev_free(ctx->scratch);
+	if (ctx->desc_dev) (void)andi_arena::dev_free(ctx->desc_dev);
 	if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
-	if (ctx->d_fixups) (void)hipFree(ctx->d_fixups);
-	if (ctx->ib_dev) (void)hipFree(ctx->ib_dev);
+	if (ctx->d_fixups) (void)andi_arena::dev_free(ctx->d_fixups);
+	if (ctx->ib_dev) (void)andi_arena::dev_free(ctx->ib_dev);
 	if (ctx->ib_host) (void)hipHostFree(ctx->ib_host);
 	if (ctx->ib_done) (void)hipEventDestroy(ctx->ib_done);
-	if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
+	if (ctx->sa_ws) (void)andi_arena::dev_free(ctx->sa_ws);
 	if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
 	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
 	if (ctx->side_stream) {
@@ -311,6 +313,7 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
 	if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	andi_arena::release(ctx->device); // (the device's last context gives its free chunks back)
 	delete ctx;
 }
 
@@ -334,7 +337,7 @@ int andi_hip_dev_alloc(andi_hip_ctx *ctx, size_t bytes, void **dptr) {
 void andi_hip_dev_free(andi_hip_ctx *ctx, void *dptr) {
 	if (!ctx || !dptr) return;
 	(void)hipSetDevice(ctx->device);
-	(void)hipFree(dptr);
+	(void)andi_arena::dev_free(dptr);
 }
 
 int andi_hip_copy_to_host(andi_hip_ctx *ctx, void *dst, const void *src, size_t bytes) {
@@ -410,14 +413,14 @@ static int esa_sort_suffixes(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	const size_t need = andi_sa_device_workspace(e->n);
 	if (ctx->sa_ws_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
+		if (ctx->sa_ws) (void)andi_arena::dev_free(ctx->sa_ws);
 		ctx->sa_ws = nullptr, ctx->sa_ws_bytes = 0;
-		HIP_TRY(ctx, hipMalloc(&ctx->sa_ws, need));
+		HIP_TRY(ctx, andi_arena::dev_malloc(&ctx->sa_ws, need));
 		ctx->sa_ws_bytes = need;
 	}
 	if (!ctx->sa_pinned) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->sa_pinned, 2 * sizeof(int32_t), hipHostMallocDefault));
 	if (!e->rec && !getenv("ANDI_NO_SORTED_RECORDS")) { // (experiments: the index build then gathers from the text, as with a host-made suffix array)
-		HIP_TRY(ctx, hipMalloc((void **)&e->rec, (e->cap + 8) * sizeof(uint32_t)));
+		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec, (e->cap + 8) * sizeof(uint32_t)));
 		e->bytes += (e->cap + 8) * sizeof(uint32_t);
 	}
 	const auto t0 = std::chrono::steady_clock::now();
@@ -479,8 +482,8 @@ static int ensure_reference_buffers(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (e->LCP && e->ref_cap >= (size_t)e->n) return 0;
 	if (e->LCP) { // slot reused for a longer subject
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		(void)hipFree(e->LCP), (void)hipFree(e->CLD), (void)hipFree(e->FVC), (void)hipFree(e->tab);
-		(void)hipFree(e->min_scratch);
+		(void)andi_arena::dev_free(e->LCP), (void)andi_arena::dev_free(e->CLD), (void)andi_arena::dev_free(e->FVC), (void)andi_arena::dev_free(e->tab);
+		(void)andi_arena::dev_free(e->min_scratch);
 		e->LCP = e->CLD = nullptr, e->FVC = nullptr, e->tab = nullptr, e->min_scratch = nullptr;
 	}
 	const size_t n = e->cap;
@@ -532,7 +535,7 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (ctx->ib_cap < count) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (ctx->ib_dev) (void)hipFree(ctx->ib_dev);
+		if (ctx->ib_dev) (void)andi_arena::dev_free(ctx->ib_dev);
 		if (ctx->ib_host) (void)hipHostFree(ctx->ib_host);
 		ctx->ib_dev = ctx->ib_host = nullptr, ctx->ib_cap = 0;
 		const size_t cap = std::max<size_t>(count, 64);
@@ -608,16 +611,16 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 		(void)hipSetDevice(ctx->device);
 		(void)hipStreamSynchronize(ctx->stream);
 	}
-	(void)hipFree(e->S);
-	(void)hipFree(e->SA);
-	(void)hipFree(e->LCP);
-	(void)hipFree(e->CLD);
-	(void)hipFree(e->FVC);
-	(void)hipFree(e->tab);
-	(void)hipFree(e->deep);
-	(void)hipFree(e->Nraw);
-	(void)hipFree(e->rec);
-	(void)hipFree(e->min_scratch);
+	(void)andi_arena::dev_free(e->S);
+	(void)andi_arena::dev_free(e->SA);
+	(void)andi_arena::dev_free(e->LCP);
+	(void)andi_arena::dev_free(e->CLD);
+	(void)andi_arena::dev_free(e->FVC);
+	(void)andi_arena::dev_free(e->tab);
+	(void)andi_arena::dev_free(e->deep);
+	(void)andi_arena::dev_free(e->Nraw);
+	(void)andi_arena::dev_free(e->rec);
+	(void)andi_arena::dev_free(e->min_scratch);
 	if (e->h_flags) (void)hipHostFree(e->h_flags);
 	delete e;
 }
@@ -677,7 +680,7 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 	if (err == hipSuccess)
 		err = hipMemcpyAsync(q->h_foreign, d_foreign, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
 	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
-	(void)hipFree(d_foreign);
+	(void)andi_arena::dev_free(d_foreign);
 	if (err != hipSuccess) {
 		andi_hip_queries_free(ctx, q);
 		return fail(ctx, "andi_hip_queries_stage", err);
@@ -693,21 +696,21 @@ void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q) {
 		(void)hipSetDevice(ctx->device);
 		(void)hipStreamSynchronize(ctx->stream);
 	}
-	(void)hipFree(q->pool);
-	(void)hipFree(q->nib);
+	(void)andi_arena::dev_free(q->pool);
+	(void)andi_arena::dev_free(q->nib);
 	if (q->h_foreign) (void)hipHostFree(q->h_foreign);
-	(void)hipFree(q->d_off);
-	(void)hipFree(q->d_len);
-	(void)hipFree(q->d_qseg_start);
-	(void)hipFree(q->d_seg2query);
+	(void)andi_arena::dev_free(q->d_off);
+	(void)andi_arena::dev_free(q->d_len);
+	(void)andi_arena::dev_free(q->d_qseg_start);
+	(void)andi_arena::dev_free(q->d_seg2query);
 	delete q;
 }
 
 static int ensure_segmentation(andi_hip_ctx *ctx, andi_hip_queries *q, uint32_t seg) {
 	if (q->seg == seg && q->d_qseg_start) return 0;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	(void)hipFree(q->d_qseg_start);
-	(void)hipFree(q->d_seg2query);
+	(void)andi_arena::dev_free(q->d_qseg_start);
+	(void)andi_arena::dev_free(q->d_seg2query);
 	q->d_qseg_start = q->d_seg2query = nullptr;
 	std::vector<uint32_t> start(q->nq + 1);
 	uint64_t total = 0;
@@ -754,7 +757,7 @@ int andi_hip_match_positions(andi_hip_ctx *ctx, const andi_hip_esa *esa, const a
 		e = hipMemcpyAsync(out_host, d_out, count * sizeof(andi_hip_interval), hipMemcpyDeviceToHost,
 						   ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-	(void)hipFree(d_out);
+	(void)andi_arena::dev_free(d_out);
 	if (e != hipSuccess) return fail(ctx, "andi_hip_match_positions", e);
 	return 0;
 }
@@ -793,7 +796,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	const size_t desc_need = nsub * (sizeof(EsaDev) + sizeof(int64_t));
 	if (ctx->desc_bytes < desc_need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
+		if (ctx->desc_dev) (void)andi_arena::dev_free(ctx->desc_dev);
 		if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
 		ctx->desc_dev = ctx->desc_host = nullptr;
 		ctx->desc_bytes = 0;
@@ -867,10 +870,10 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 						(adaptive ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		if (ctx->scratch) (void)hipFree(ctx->scratch);
+		if (ctx->scratch) (void)andi_arena::dev_free(ctx->scratch);
 		ctx->scratch = nullptr;
 		ctx->scratch_bytes = 0;
-		HIP_TRY(ctx, hipMalloc(&ctx->scratch, need));
+		HIP_TRY(ctx, andi_arena::dev_malloc(&ctx->scratch, need));
 		ctx->scratch_bytes = need;
 	}
 
@@ -984,8 +987,8 @@ int andi_hip_bootstrap(andi_hip_ctx *ctx, const andi_hip_model *M, size_t n, uin
 		e = andi_launch_bootstrap(dM, dB, (uint32_t)n, (uint32_t)replicates, seed, ctx->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(B, dB, one * replicates, hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-	(void)hipFree(dM);
-	(void)hipFree(dB);
+	(void)andi_arena::dev_free(dM);
+	(void)andi_arena::dev_free(dB);
 	if (e != hipSuccess) return fail(ctx, "andi_hip_bootstrap", e);
 	return 0;
 }
@@ -1403,7 +1406,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			if (cm) (void)R.CommDestroy(cm);
 		if (d_full) {
 			(void)hipSetDevice(devs[0]);
-			(void)hipFree(d_full);
+			(void)andi_arena::dev_free(d_full);
 		}
 		if (!ok) { // RCCL unusable on this box: the rows are still in HBM -- copy every block to the host directly
 			snprintf(g_last_gather, sizeof g_last_gather, "direct (rccl: %.160s)", err.c_str());

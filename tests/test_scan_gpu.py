@@ -348,6 +348,38 @@ def test_realistic_divergence_structure(ctx, orc):
     _check_set(ctx, orc, joined, segments=(0, 700))
 
 
+def test_device_buffers_survive_churn(ctx, orc):
+    """The engine's device buffers are carved out of large chunks (andi_amd/csrc/dev_arena.h: first fit, coalescing,
+    shared by the contexts of a device).  Subjects and query sets of very different sizes are created and released
+    in interleaved order -- blocks are split, joined and handed out again -- and what is scanned afterwards, and
+    in between by a second context, is still bit-exact."""
+    import andi_amd
+    from andi_amd import synth
+    rng = np.random.default_rng(11)
+    seqs = [synth.to_bytes(synth.mutate_codes(synth.base_codes(60000, 3), 0.02, 50 + k)) for k in range(4)]
+    want = orc.dist_matrix(seqs, threads=4)
+    filler = [synth.to_bytes(synth.base_codes(int(n), 100 + i)) for i, n in enumerate(rng.integers(1000, 900000, 14))]
+    held = []
+    for round_ in range(3):
+        for i, f in enumerate(filler):
+            held.append(andi_amd.Esa(ctx, f))
+            if i % 3 == round_ % 3 and held:
+                held.pop(int(rng.integers(0, len(held)))).close()
+        Qf = andi_amd.Queries(ctx, filler[: 3 + round_])
+        got, _ = _gpu_rows(ctx, seqs)
+        assert (got == want).all(), round_
+        other = andi_amd.Context(0)  # a second context on the device shares the arena
+        got2, _ = _gpu_rows(other, seqs, segment=512)
+        other.close()
+        assert (got2 == want).all(), round_
+        Qf.close()
+        for e in held[::2]:
+            e.close()
+        held = held[1::2]
+    for e in held:
+        e.close()
+
+
 def test_fixups_in_pass_c(ctx, orc, monkeypatch):
     """Pass C stitches again, one after the other, the segments whose assumed entry state turned out wrong
     (k_scan_reduce): it looks for the failing checks 64 at a time and follows each stretch until the true chain
