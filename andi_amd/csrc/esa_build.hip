@@ -334,7 +334,9 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 // no divergent per-gap loops); a binary search over the gaps' offsets tells an entry
 // which gap it belongs to.
 #define PT_BLOCK 256
+#ifndef PT_GAPS
 #define PT_GAPS 2 /* gaps per thread: two independent gathers in flight per thread */
+#endif
 #define PT_TILE (PT_BLOCK * PT_GAPS)
 #define PT_WORDS (PT_TILE / 64) /* 64-bit ballots that cover the tile: gap i = u * PT_BLOCK + thread is bit i & 63 of word i >> 6 */
 #define PT_RANKED 2048          /* entries of a block whose owners are found by rank (the block's piece is seldom longer) */
