@@ -929,7 +929,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		a.max_passes = mp && atoi(mp) > 0 ? (uint32_t)atoi(mp) : 3u;
 		const char *qm = getenv("ANDI_QUAD_MATCH"); // experiments: mean match length from which a pair goes to k_lane_quad (0: all, -1: none)
 		a.quad_min_match = qm ? (uint32_t)atoi(qm) : 128u;
-		a.quad_all = 0;
+		a.quad_all = 0, a.quad_listed = 0;
 		a.side_stream = ctx->side_stream, a.side_fork = ctx->side_fork, a.side_join = ctx->side_join;
 		const char *kn = getenv("ANDI_KNOCK");
 		a.knock = kn ? (uint32_t)atoi(kn) : 0u;

@@ -127,8 +127,8 @@ __device__ __forceinline__ LaneItem lane_item_of_slot(const ScanArgs &a, unsigne
 // LAYOUT: 0 = whichever the call uses (a.adaptive), 1 = per-pair segments, 2 = one segment length.  A kernel compiled
 // for layout 1 knows that all lanes of a wavefront work on one pair: the query's base address and length stay in
 // scalar registers (five vector registers less per lane, query loads with a scalar base).
-template <int NT = BLOCK, int LAYOUT = 0> // NT: threads per block
-__device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
+template <int NT = BLOCK, int LAYOUT = 0> // NT: threads per block; `wave`: the wavefront to work as (per-pair segments), or ~0
+__device__ __forceinline__ LaneItem lane_item(const ScanArgs &a, uint32_t wave = ~0u) {
 	LaneItem it;
 	if (LAYOUT == 2 || (LAYOUT == 0 && !a.adaptive)) {
 		it.sub = blockIdx.y;
@@ -148,7 +148,7 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a) {
 		return it;
 	}
 	const uint32_t P = a.nsub * a.nq;
-	const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NT / 64) + (threadIdx.x >> 6)));
+	const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave != ~0u ? wave : blockIdx.x * (NT / 64) + (threadIdx.x >> 6)));
 	it.valid = false;
 	it.sub = it.qidx = it.seg_in_q = it.start = it.end = it.seg = it.cls = 0, it.slot = 0;
 	if (W >= a.pair_wave0[P]) return it;

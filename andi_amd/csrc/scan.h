@@ -88,6 +88,9 @@ struct ScanArgs {
 	// Pairs whose sampled mean match length is at least quad_min_match (per-pair segment lengths only) take pass A with
 	// the streams fetched by quads of lanes (scan_lane.hip: k_lane_quad), the others lane_step's; 0xffffffff: none do
 	uint32_t quad_min_match;
+	// the wavefronts of those pairs, listed by k_pair_offsets (in pass B's list, idle during pass A; their number
+	// at restitch_count[ANDI_QUAD_WAVES]): k_lane_quad's wavefronts take them in order
+	uint32_t quad_listed; // k_lane_quad takes its wavefronts from that list
 	uint32_t quad_all; // experiments (ANDI_LANE_STREAM=2): k_lane_quad takes every pair
 	// host side only: a second stream and two events, so that pass A's two kernels (k_lane_quad for the pairs with long
 	// matches, k_lane_cold for the others) share the device instead of each ending in a tail of its own
@@ -122,6 +125,7 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 #ifndef ANDI_STITCH_MANY
 #define ANDI_STITCH_MANY 4096
 #endif
+#define ANDI_QUAD_WAVES 13 /* restitch_count[this] during pass A: wavefronts on k_lane_quad's list */
 #define ANDI_STRAGGLERS 12 /* restitch_count[this]: replays of the call so far that went past ANDI_STITCH_FIRST steps */
 #ifndef ANDI_STITCH_BUDGET
 #define ANDI_STITCH_BUDGET 48

@@ -392,7 +392,15 @@ __global__ __launch_bounds__(1024) void k_pair_offsets(ScanArgs a) {
 	const uint32_t P = a.nsub * a.nq, i = blockIdx.x * 1024 + threadIdx.x;
 	const uint32_t v = i < P ? a.pair_waves[i] : 0u;
 	const uint32_t incl = block_scan_1024(v, s_part);
-	if (i < P) a.pair_wave0[i] = a.pair_bsum[blockIdx.x] + incl - v;
+	if (i < P) {
+		const uint32_t w0 = a.pair_bsum[blockIdx.x] + incl - v;
+		a.pair_wave0[i] = w0;
+		if ((a.pair_class[i] & 0x80u) && v) { // its wavefronts go on k_lane_quad's list
+			uint32_t *list = (uint32_t *)a.defer_list;
+			const uint32_t base = atomicAdd(&a.restitch_count[ANDI_QUAD_WAVES], v);
+			for (uint32_t k = 0; k < v; ++k) list[base + k] = w0 + k;
+		}
+	}
 }
 
 // ------------------------------------------------------------------ pass A
@@ -841,11 +849,23 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 }
 
 template <bool EXACT>
-__global__ __launch_bounds__(BLOCK, 4) void k_lane_quad(ScanArgs a) {
+__global__ __launch_bounds__(BLOCK, 4) void k_lane_quad(ScanArgs a) { // (4 wavefronts per SIMD, whatever the block)
 	__shared__ uint32_t s_hist[16 * BLOCK];
 	__shared__ uint4 s_stage[WAVES_PER_BLOCK * QUAD_STAGE];
 	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
-	LaneItem it = lane_item(a);
+	// a.quad_listed: the kernel's wavefronts take the list of those that have work here in order (k_pair_offsets made
+	// it), the others return at once; else (experiments) every wavefront of the call looks whether its pair is this
+	// kernel's.  The kernel runs beside k_lane_cold on a device that k_lane_cold's blocks fill; taking its own
+	// wavefronts in the call's order, its work trailed behind -- its blocks are large and find a place late -- and
+	// ended up running alone after k_lane_cold had finished (C4 shape: 4.5 of 41.7 ms).  From the list, all of it is
+	// dispatched first.
+	uint32_t wave = ~0u;
+	if (a.quad_listed) {
+		const uint32_t k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+		if (k >= a.restitch_count[ANDI_QUAD_WAVES]) return;
+		wave = ((const uint32_t *)a.defer_list)[k];
+	}
+	LaneItem it = lane_item(a, wave);
 	if (!a.quad_all && !lane_is_mine(a, it, true)) it.valid = false; // (a wavefront is one pair's: all or none)
 	if (!__any(it.valid)) return;
 	lane_cold_quad<EXACT>(a, it, s_hist, s_stage);
@@ -1275,6 +1295,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 		}
 		return hipGetLastError();
 	}
+	const bool blocks4 = getenv("ANDI_QUAD_UNLISTED") != nullptr; // (experiments: k_lane_quad's wavefronts in the call's order)
 	const bool quads = a.adaptive && a.quad_min_match != 0xffffffffu;
 	const bool side = quads && a.side_stream && !getenv("ANDI_NO_SIDE_STREAM");
 	if (quads) { // the pairs with long matches, beside the others
@@ -1283,7 +1304,9 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 			(void)hipEventRecord(a.side_fork, st);
 			(void)hipStreamWaitEvent(a.side_stream, a.side_fork, 0);
 		}
-		k_lane_quad<EXACT><<<grid, BLOCK, 0, side ? a.side_stream : st>>>(a);
+		ScanArgs b = a;
+		b.quad_listed = blocks4 ? 0 : 1;
+		k_lane_quad<EXACT><<<grid, BLOCK, 0, side ? a.side_stream : st>>>(b);
 		if (side) (void)hipEventRecord(a.side_join, a.side_stream);
 	}
 	if (a.adaptive) {
@@ -1305,6 +1328,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
 	const uint32_t P = a.nsub * a.nq;
+	(void)hipMemsetAsync(a.restitch_count + ANDI_QUAD_WAVES, 0, sizeof(uint32_t), st); // k_lane_quad's list is empty
 	k_pair_estimate<<<(P + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	const unsigned nb = (P + 1023) / 1024;
