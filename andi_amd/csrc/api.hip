@@ -71,6 +71,7 @@ struct andi_hip_ctx {
 	void *sa_ws = nullptr;
 	size_t sa_ws_bytes = 0;
 	int32_t *sa_pinned = nullptr;
+	uint32_t *h_quad_waves = nullptr; // pinned: the length of k_lane_quad's list of a scan call
 	std::vector<EventPair> pending;
 	andi_hip_timings acc{};
 };
@@ -278,6 +279,7 @@ int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t err
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_quad_waves, sizeof(uint32_t), hipHostMallocDefault);
 	if (e != hipSuccess) {
 		set_err(errbuf, errlen, "context setup: %s", hipGetErrorString(e));
 		andi_hip_ctx_destroy(ctx);
@@ -305,6 +307,7 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->ib_done) (void)hipEventDestroy(ctx->ib_done);
 	if (ctx->sa_ws) (void)andi_arena::dev_free(ctx->sa_ws);
 	if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
+	if (ctx->h_quad_waves) (void)hipHostFree(ctx->h_quad_waves);
 	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
 	if (ctx->side_stream) {
 		(void)hipStreamSynchronize(ctx->side_stream);
@@ -931,6 +934,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		a.quad_min_match = qm ? (uint32_t)atoi(qm) : 128u;
 		a.quad_all = 0, a.quad_listed = 0;
 		a.side_stream = ctx->side_stream, a.side_fork = ctx->side_fork, a.side_join = ctx->side_join;
+		a.h_quad_waves = ctx->h_quad_waves;
 		const char *kn = getenv("ANDI_KNOCK");
 		a.knock = kn ? (uint32_t)atoi(kn) : 0u;
 	}

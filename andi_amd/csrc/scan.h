@@ -91,6 +91,7 @@ struct ScanArgs {
 	// the wavefronts of those pairs, listed by k_pair_offsets (in pass B's list, idle during pass A; their number
 	// at restitch_count[ANDI_QUAD_WAVES]): k_lane_quad's wavefronts take them in order
 	uint32_t quad_listed; // k_lane_quad takes its wavefronts from that list
+	uint32_t *h_quad_waves; // pinned host word the list's length is copied to (host side only)
 	uint32_t quad_all; // experiments (ANDI_LANE_STREAM=2): k_lane_quad takes every pair
 	// host side only: a second stream and two events, so that pass A's two kernels (k_lane_quad for the pairs with long
 	// matches, k_lane_cold for the others) share the device instead of each ending in a tail of its own
@@ -111,6 +112,7 @@ int andi_scan_group(void);
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
+hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStream_t st); // k_lane_quad, one wavefront per block (scan_lane.hip compiled a second time)
 // Pass B again for the segments whose predecessor's true exit turned out not to be the assumed entry (a true
 // chain that runs on lucky anchors through a repeat in which cold chains find nothing unique): each round
 // settles one more segment of every such stretch, all stretches at once.  Rounds after one without any

@@ -1245,6 +1245,23 @@ __global__ __launch_bounds__(256) void k_pack_symbols_batch(const AndiIndexBatch
 
 } // namespace
 
+#ifdef ANDI_QUAD_TU
+// This file compiled a second time with one wavefront per block (-DANDI_QUAD_TU -DWAVES_PER_BLOCK=1) for k_lane_quad
+// alone: `count` blocks, block i = wavefront i of the list.  A block of four wavefronts holds its place until the
+// slowest of them is done, and the chains of this kernel differ much in length (C3-like set 3.0 -> 2.8 ms, genomes
+// 1e-5 apart 1.83 -> 1.55 ms).
+hipError_t andi_launch_lane_quad_small(const ScanArgs &a0, uint32_t count, hipStream_t st) { // per-pair segments only
+	if (count == 0) return hipSuccess;
+	ScanArgs a = a0;
+	a.quad_listed = 1;
+	if (a.exact_equal)
+		k_lane_quad<true><<<count, BLOCK, 0, st>>>(a);
+	else
+		k_lane_quad<false><<<count, BLOCK, 0, st>>>(a);
+	return hipGetLastError();
+}
+#else
+
 hipError_t andi_launch_pack_symbols_batch(const AndiIndexBatchItem *d_items, uint32_t count, size_t bytes, hipStream_t st) {
 	const int64_t pairs = (int64_t)((bytes + 15) / 16);
 	if (pairs == 0 || count == 0) return hipSuccess;
@@ -1298,16 +1315,23 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	const bool blocks4 = getenv("ANDI_QUAD_UNLISTED") != nullptr; // (experiments: k_lane_quad's wavefronts in the call's order)
 	const bool quads = a.adaptive && a.quad_min_match != 0xffffffffu;
 	const bool side = quads && a.side_stream && !getenv("ANDI_NO_SIDE_STREAM");
+	// With the side stream: k_lane_cold goes first, the host then reads how many wavefronts k_lane_quad's list has
+	// (four bytes over the side stream, while k_lane_cold runs: the device is never idle -- a wait for the layout
+	// BEFORE pass A cost it 0.1 ms) and launches k_lane_quad with exactly that many single-wavefront blocks, or
+	// not at all: blocks that only find out that they have nothing to do are not free either (bench set + 0.1 ms).
+	const bool counted = side && a.h_quad_waves && !blocks4 && !getenv("ANDI_QUAD_BLOCKS4");
 	if (quads) { // the pairs with long matches, beside the others
 		(void)hipMemsetAsync(a.first_pub, 0xff, (size_t)64 * a.max_waves * sizeof(unsigned long long), st);
 		if (side) {
 			(void)hipEventRecord(a.side_fork, st);
 			(void)hipStreamWaitEvent(a.side_stream, a.side_fork, 0);
 		}
-		ScanArgs b = a;
-		b.quad_listed = blocks4 ? 0 : 1;
-		k_lane_quad<EXACT><<<grid, BLOCK, 0, side ? a.side_stream : st>>>(b);
-		if (side) (void)hipEventRecord(a.side_join, a.side_stream);
+		if (!counted) { // blocks of four wavefronts over the whole grid: those beyond the list return at once
+			ScanArgs b = a;
+			b.quad_listed = blocks4 ? 0 : 1;
+			k_lane_quad<EXACT><<<grid, BLOCK, 0, side ? a.side_stream : st>>>(b);
+			if (side) (void)hipEventRecord(a.side_join, a.side_stream);
+		}
 	}
 	if (a.adaptive) {
 		switch (lane_occupancy(true)) {
@@ -1321,6 +1345,14 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 			case 7: k_lane_cold<EXACT, 7, false><<<grid, BLOCK, pad, st>>>(a); break;
 			default: k_lane_cold<EXACT, 8, false><<<grid, BLOCK, pad, st>>>(a); break;
 		}
+	}
+	if (counted) {
+		(void)hipMemcpyAsync(a.h_quad_waves, a.restitch_count + ANDI_QUAD_WAVES, sizeof(uint32_t), hipMemcpyDeviceToHost, a.side_stream);
+		hipError_t e = hipStreamSynchronize(a.side_stream);
+		if (e != hipSuccess) return e;
+		e = andi_launch_lane_quad_small(a, *a.h_quad_waves, a.side_stream);
+		if (e != hipSuccess) return e;
+		(void)hipEventRecord(a.side_join, a.side_stream);
 	}
 	if (side) (void)hipStreamWaitEvent(st, a.side_join, 0);
 	return hipGetLastError();
@@ -1408,3 +1440,4 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 	}
 	return hipGetLastError();
 }
+#endif // ANDI_QUAD_TU
