@@ -96,6 +96,12 @@ __device__ __forceinline__ void lane_count_gap(LWin &w, const PairCtx &c, Tally 
 }
 
 // model_count_equal (src/model.c:246-279) for the anchor Q[qpos..qpos+len)
+// k_pair_estimate keeps pairs with unrelated stretches away from k_lane_quad only while their mean match is below this:
+// with longer matches k_lane_cold's lane-by-lane following of matches that cover many segments costs more than
+// k_lane_quad's slow probing (genomes with structure 1e-5 ... 1e-4 apart: pass A 23.4 ms without the bound, 11.8 with)
+#ifndef ANDI_ISLAND_MEAN_MAX
+#define ANDI_ISLAND_MEAN_MAX 256u
+#endif
 template <bool EXACT>
 __device__ __forceinline__ void lane_count_anchor(const PairCtx &c, Tally &t, uint32_t qpos, uint32_t len) {
 	if constexpr (!EXACT) {
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
 	// k_lane_quad only if its short matches are no more than its mean explains (matches end at random: a fraction
 	// 1 - exp(-threshold / mean) of the positions sees less than the threshold), within two standard deviations.
 	bool islands = false;
-	if ((sum >> 6) >= a.quad_min_match && a.quad_min_match != 0) { // (wave-uniform)
+	if ((sum >> 6) >= a.quad_min_match && (sum >> 6) < ANDI_ISLAND_MEAN_MAX && a.quad_min_match != 0) { // (wave-uniform)
 		uint32_t shorts = r.len < c.thr ? 1u : 0u;
 		for (uint32_t k = 1; k < 4; ++k) {
 			const uint32_t pk = (uint32_t)(((uint64_t)(8 * lane + 2 * k + 1) * c.qlen) >> 9); // between the first samples
