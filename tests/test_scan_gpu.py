@@ -432,6 +432,12 @@ def test_pairs_with_long_matches_take_the_quad_kernel(ctx, orc, monkeypatch):
             monkeypatch.setenv(k, v)
         got, t = _gpu_rows(ctx, seqs)
         assert t["adaptive_calls"] >= 1 and (got == want).all(), env
+    for k in ("ANDI_QUAD_MATCH", "ANDI_NO_SIDE_STREAM"):
+        monkeypatch.delenv(k, raising=False)
+    for model in (3, 4):  # LogDet, ANI: equal runs counted per nucleotide, in k_lane_quad's single-wavefront blocks too
+        want_m = orc.dist_matrix(seqs, model=model, threads=0)
+        got, _ = _gpu_rows(ctx, seqs, model=model)
+        assert (got == want_m).all(), model
 
 
 def test_deeper_probe_table_for_many_queries(ctx, orc):
