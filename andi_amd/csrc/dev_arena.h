@@ -35,7 +35,7 @@ struct Arena {
 };
 
 inline Arena &of_device(int dev) {
-	static Arena arenas[64];
+	static Arena *arenas = new Arena[64]; // (never destroyed: a context may be released after the statics of this library)
 	return arenas[dev >= 0 && dev < 64 ? dev : 0];
 }
 
