@@ -425,14 +425,15 @@ def test_pairs_with_long_matches_take_the_quad_kernel(ctx, orc, monkeypatch):
     seqs = [synth.to_bytes(synth.mutate_codes(base, d, 20 + k)) for k, d in enumerate((0.0, 0.0002, 0.001, 0.004, 0.02, 0.06))]
     seqs.append(synth.join_contigs(seqs[1], 4, seed=9))
     want = orc.dist_matrix(seqs, threads=0)
-    for env in ({}, {"ANDI_QUAD_MATCH": "0"}, {"ANDI_QUAD_MATCH": "1000"}, {"ANDI_QUAD_MATCH": "-1"}, {"ANDI_NO_SIDE_STREAM": "1"}):
-        for k in ("ANDI_QUAD_MATCH", "ANDI_NO_SIDE_STREAM"):
+    for env in ({}, {"ANDI_QUAD_MATCH": "0"}, {"ANDI_QUAD_MATCH": "1000"}, {"ANDI_QUAD_MATCH": "-1"}, {"ANDI_NO_SIDE_STREAM": "1"},
+                {"ANDI_QUAD_UNLISTED": "1"}, {"ANDI_QUAD_BLOCKS4": "1"}, {"ANDI_QUAD_MATCH": "0", "ANDI_QUAD_BLOCKS4": "1"}):
+        for k in ("ANDI_QUAD_MATCH", "ANDI_NO_SIDE_STREAM", "ANDI_QUAD_UNLISTED", "ANDI_QUAD_BLOCKS4"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got, t = _gpu_rows(ctx, seqs)
         assert t["adaptive_calls"] >= 1 and (got == want).all(), env
-    for k in ("ANDI_QUAD_MATCH", "ANDI_NO_SIDE_STREAM"):
+    for k in ("ANDI_QUAD_MATCH", "ANDI_NO_SIDE_STREAM", "ANDI_QUAD_UNLISTED", "ANDI_QUAD_BLOCKS4"):
         monkeypatch.delenv(k, raising=False)
     for model in (3, 4):  # LogDet, ANI: equal runs counted per nucleotide, in k_lane_quad's single-wavefront blocks too
         want_m = orc.dist_matrix(seqs, model=model, threads=0)
