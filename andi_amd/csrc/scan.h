@@ -117,7 +117,9 @@ hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStr
 // chain that runs on lucky anchors through a repeat in which cold chains find nothing unique): each round
 // settles one more segment of every such stretch, all stretches at once.  Rounds after one without any
 // re-stitched segment return at once.
-#define ANDI_RESTITCH_ROUNDS 3
+#ifndef ANDI_RESTITCH_ROUNDS
+#define ANDI_RESTITCH_ROUNDS 3 /* 5 rounds: 582 -> 21 fix-ups on the realistic set, passes B/C 9.37 -> 9.25 ms: the rounds cost what pass C saves */
+#endif
 #ifndef ANDI_STITCH_FIRST
 #define ANDI_STITCH_FIRST 12
 #endif
