@@ -36,6 +36,8 @@
 // per-pair segment lengths: classes seg/2, seg, 2 seg, 4 seg of the call's length, as long as the scratch they
 // need (whole wavefronts per pair) stays a fraction of the device's memory
 #define ANDI_ADAPTIVE_MAX_PAIRS (1u << 22)
+// scratch per (subject, segment): three states, two count vectors, the marks, the exit position, a list slot, a published anchor
+#define ANDI_SLOT_BYTES (3 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4 + 8 + 8)
 
 static_assert(sizeof(andi_hip_model) == 68, "struct model must be 17 x u32 (src/model.h:52-57)");
 static_assert(sizeof(andi_hip_interval) == 16, "lcp_inter_t is 4 x int32 (src/esa.h:25-34)");
@@ -786,8 +788,21 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// segment == 0: the engine chooses.  With the lane scan and a moderate number of pairs
 	// the segment length is chosen per pair (scan_lane.hip: k_pair_estimate); otherwise one
 	// length for the call.
-	const bool want_adaptive = segment == 0 && andi_scan_group() == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
+	// Pass A with one wavefront per chain (scan_coop.hip): the lane scan's default for the models that split an
+	// anchor's length evenly, thresholds a 32-symbol window can decide.  One segment length for the call, long
+	// segments (a wavefront needs far fewer chains in flight than a lane): 32768 symbols while that leaves 2^14.
+	int coop = andi_scan_group() == 0 && andi_coop_enabled() && model <= ANDI_M_KIMURA;
+	for (size_t s = 0; s < nsub && coop; ++s)
+		if (!subjects[s] || subjects[s]->thr < 2 || subjects[s]->thr > 30) coop = 0;
+	const bool want_adaptive = !coop && segment == 0 && andi_scan_group() == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
 							   !getenv("ANDI_UNIFORM_SEGMENTS");
+	if (segment == 0 && coop) {
+		const uint64_t nt = q->total_nt * (uint64_t)nsub;
+		segment = 32768;
+		if (const char *cs = getenv("ANDI_COOP_SEG")) // experiments
+			if (atoi(cs) >= 64) segment = (uint32_t)atoi(cs);
+		while (segment > 2048 && nt / segment < (1u << 14)) segment /= 2;
+	}
 	if (segment == 0) {
 		uint64_t nt = q->total_nt * (uint64_t)nsub;
 		segment = ANDI_MIN_SEGMENT;
@@ -864,12 +879,12 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		used *= nsub;
 		size_t free_b = 0, total_b = 0;
 		const bool fits = max_waves < (1u << 26) &&
-						  (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)64 * max_waves * 348 < free_b / 2 + ctx->scratch_bytes);
+						  (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)64 * max_waves * ANDI_SLOT_BYTES < free_b / 2 + ctx->scratch_bytes);
 		if (!fits || (10 * used < 7 * 64 * max_waves && !getenv("ANDI_FORCE_ADAPTIVE"))) adaptive = false, max_waves = 0;
 	}
 	const size_t pairs_all = nsub * q->nq;
 	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
-	const size_t need = slots * (3 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4 + 8 + 8) + 128 +
+	const size_t need = slots * ANDI_SLOT_BYTES + 128 +
 						(adaptive ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -939,6 +954,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		a.knock = kn ? (uint32_t)atoi(kn) : 0u;
 	}
 	a.lanes = a.group == 0;
+	a.coop = coop && a.lanes && !a.adaptive;
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 
 	if (a.adaptive) {
@@ -1378,16 +1394,23 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			if (err.empty()) err = std::string(what) + ": " + R.GetErrorString(r);
 			return false;
 		};
-		// one process, one node: the communicators bootstrap over the loopback interface unless the caller chose one
-		setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+		// one process, one node: the communicators bootstrap over the loopback interface unless the caller chose one;
+		// the caller's environment is put back as it was (a later multi-node initialisation in this process must not
+		// inherit the loopback)
+		const bool had_ifname = getenv("NCCL_SOCKET_IFNAME") != nullptr;
+		if (!had_ifname) setenv("NCCL_SOCKET_IFNAME", "lo", 0);
 		bool ok = nccl_ok(R.CommInitAll(comms.data(), (int)ndev, devs.data()), "ncclCommInitAll");
+		if (!had_ifname) unsetenv("NCCL_SOCKET_IFNAME");
 		if (ok && hipSetDevice(devs[0]) != hipSuccess) ok = false, err = "hipSetDevice";
 		if (ok && hipMalloc((void **)&d_full, n * n * sizeof(andi_hip_model)) != hipSuccess) ok = false, err = "allocating the gathered matrix";
 		if (ok) {
 			ok = nccl_ok(R.GroupStart(), "ncclGroupStart");
 			for (size_t d = 1; d < ndev && ok; ++d) {
 				const size_t bytes = (last[d] - first[d]) * n * sizeof(andi_hip_model);
-				ok = nccl_ok(R.Send(dv[d].d_rows, bytes, ncclUint8, 0, comms[d], dv[d].ctx->stream), "ncclSend") &&
+				// (every call with the device of its communicator current)
+				ok = hipSetDevice(devs[d]) == hipSuccess &&
+					 nccl_ok(R.Send(dv[d].d_rows, bytes, ncclUint8, 0, comms[d], dv[d].ctx->stream), "ncclSend") &&
+					 hipSetDevice(devs[0]) == hipSuccess &&
 					 nccl_ok(R.Recv(d_full + first[d] * n, bytes, ncclUint8, (int)d, comms[0], dv[0].ctx->stream), "ncclRecv");
 			}
 			if (!nccl_ok(R.GroupEnd(), "ncclGroupEnd")) ok = false;

@@ -85,39 +85,42 @@ inline hipError_t dev_malloc(void **p, size_t bytes) {
 
 inline hipError_t dev_free(void *p) {
 	if (!p) return hipSuccess;
-	int dev = 0;
-	(void)hipGetDevice(&dev);
-	Arena &A = of_device(dev);
-	{
+	int cur = 0;
+	(void)hipGetDevice(&cur);
+	// the block's own arena: the current device's as a rule, but a handle may be freed while another device is current
+	for (int probe = 0; probe < 64; ++probe) {
+		const int dev = probe == 0 ? cur : (probe <= cur ? probe - 1 : probe);
+		Arena &A = of_device(dev);
 		std::unique_lock<std::mutex> lock(A.mu);
 		auto it = A.live.find(p);
-		if (it != A.live.end()) {
-			const size_t len = it->second;
-			A.live.erase(it);
-			lock.unlock();
-			(void)hipDeviceSynchronize(); // as hipFree: nothing in flight uses the block when it is handed out again
-			lock.lock();
-			for (Chunk &c : A.chunks) {
-				if ((char *)p < c.base || (char *)p >= c.base + c.size) continue;
-				size_t off = (size_t)((char *)p - c.base), n = len;
-				auto next = c.free_blocks.lower_bound(off);
-				if (next != c.free_blocks.end() && off + n == next->first) { // joins the free block behind it
-					n += next->second;
-					next = c.free_blocks.erase(next);
-				}
-				if (next != c.free_blocks.begin()) { // and the one before it
-					auto prev = std::prev(next);
-					if (prev->first + prev->second == off) {
-						off = prev->first, n += prev->second;
-						c.free_blocks.erase(prev);
-					}
-				}
-				c.free_blocks[off] = n;
-				c.used -= len;
-				return hipSuccess;
+		if (it == A.live.end()) continue;
+		const size_t len = it->second;
+		A.live.erase(it);
+		lock.unlock();
+		if (dev != cur) (void)hipSetDevice(dev);
+		(void)hipDeviceSynchronize(); // as hipFree: nothing in flight uses the block when it is handed out again
+		if (dev != cur) (void)hipSetDevice(cur);
+		lock.lock();
+		for (Chunk &c : A.chunks) {
+			if ((char *)p < c.base || (char *)p >= c.base + c.size) continue;
+			size_t off = (size_t)((char *)p - c.base), n = len;
+			auto next = c.free_blocks.lower_bound(off);
+			if (next != c.free_blocks.end() && off + n == next->first) { // joins the free block behind it
+				n += next->second;
+				next = c.free_blocks.erase(next);
 			}
-			return hipSuccess; // (unreachable: a live block lies in a chunk)
+			if (next != c.free_blocks.begin()) { // and the one before it
+				auto prev = std::prev(next);
+				if (prev->first + prev->second == off) {
+					off = prev->first, n += prev->second;
+					c.free_blocks.erase(prev);
+				}
+			}
+			c.free_blocks[off] = n;
+			c.used -= len;
+			return hipSuccess;
 		}
+		return hipSuccess; // (unreachable: a live block lies in a chunk)
 	}
 	return hipFree(p);
 }

@@ -194,7 +194,7 @@ hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *worksp
 		SA_TRY(hipMemcpyAsync(h_pinned2, d_count, 8, hipMemcpyDeviceToHost, st)); // open slots, foreign flag
 		SA_TRY(hipStreamSynchronize(st));
 		++rounds;
-		if (h_pinned2[1]) return hipErrorInvalidSymbol; // a byte outside the alphabet: the caller sorts on the host
+		if (h_pinned2[1]) return hipErrorInvalidSymbol; // a byte outside the alphabet: the caller reports it (the scan refuses such a text anyway)
 		m = (uint32_t)h_pinned2[0];
 		if (m == 0) break;
 		slots = slotB;

@@ -97,6 +97,7 @@ struct ScanArgs {
 	// matches, k_lane_cold for the others) share the device instead of each ending in a tail of its own
 	hipStream_t side_stream;
 	hipEvent_t side_fork, side_join;
+	int coop;            // pass A with one wavefront per chain (scan_coop.hip): one segment length, RAW/JC/Kimura, probe-table subjects
 	uint32_t knock;      // diagnostic builds (-DANDI_LANE_STATS): parts of pass A switched off to time them (results are then wrong)
 };
 
@@ -111,6 +112,9 @@ int andi_scan_group(void);
 // adaptive mode: sample every pair's match lengths, choose its segment length, lay out the slots
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
+// pass A with one wavefront per chain (scan_coop.hip); andi_coop_enabled(): 0 = off (ANDI_COOP=0), else the window's length in chunks of 2048 symbols
+int andi_coop_enabled(void);
+hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStream_t st); // k_lane_quad, one wavefront per block (scan_lane.hip compiled a second time)
 // Pass B again for the segments whose predecessor's true exit turned out not to be the assumed entry (a true
@@ -129,6 +133,7 @@ hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStr
 #ifndef ANDI_STITCH_MANY
 #define ANDI_STITCH_MANY 4096
 #endif
+static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at the front, defer_count at 8, ANDI_STRAGGLERS at 12, ANDI_QUAD_WAVES at 13");
 #define ANDI_QUAD_WAVES 13 /* restitch_count[this] during pass A: wavefronts on k_lane_quad's list */
 #define ANDI_STRAGGLERS 12 /* restitch_count[this]: replays of the call so far that went past ANDI_STITCH_FIRST steps */
 #ifndef ANDI_STITCH_BUDGET

@@ -1,0 +1,756 @@
+// scan_coop.hip -- pass A of the anchor scan (dist_anchor, src/process.c:141-214) with ONE WAVEFRONT PER CHAIN.
+//
+// scan_lane.hip gives every lane a cold chain of its own: 64 chains per wavefront stand at ten different places
+// of the step, a load instruction has 7 of 64 lanes active, and the wavefront executes the whole loop body once
+// per trip (profiles/r03e_pmc.txt).  Here the 64 lanes work on ONE chain -- the cold chain of one segment,
+// exactly the states and counts the sequential loop produces (what pass B stitches is unchanged) -- in two modes:
+//
+//   G  generic steps, one after the other: lucky_anchor (src/process.c:82-100) compares 2048 symbols per round
+//      trip (64 lanes x 32 symbols), anchor() (113-123) probes the next 64 query positions at once (the chain
+//      then hops through the answers: each step lands at most 64 positions on), the accounting of 157-190 counts
+//      a gap with all lanes.  The chain is in this mode until it has found a LUCKY anchor: two anchors in a row on
+//      one diagonal.
+//   W  a window of W = 2048 NCH query symbols along that diagonal, two fully coalesced 16-byte loads per lane and
+//      2048 symbols, turned into one bit per position (query symbol != subject symbol).  Behind a mismatch that is
+//      followed by >= threshold equal symbols the next step is a lucky anchor whose outcome the bits alone decide
+//      ("easy").  A mismatch followed by a shorter run but preceded by a long one is a HEAD: the chain arrives
+//      there in a known (canonical) state, so the walks from ALL heads of the window -- probe, step, probe ... until
+//      an anchor on the diagonal is found -- are independent and are taken by the lanes in parallel, speculatively
+//      (a lane that is done takes the next head).  The chain then hops from head to head; counts follow from the
+//      gap positions (all mismatches, and the stretch between a head and the anchor its walk lands on) and the
+//      anchors between them.  tests/coop_model.py restates this decomposition on the CPU and checks it against the
+//      plain loop; tests/test_coop_gpu.py checks this kernel against k_lane_cold slot by slot.
+//
+// Layout: one segment length for the call (slot = subject * total_segs + segment), wavefront w of subject
+// blockIdx.y takes segment w.  RAW/JC/Kimura only (LogDet and ANI count every anchor's nucleotides: scan_lane.hip).
+#include "lane_chain.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+constexpr uint32_t COOP_HCAP = 128; // heads of a window that are walked (more: the window ends at the first one dropped)
+constexpr uint32_t COOP_MAX_X = 3;  // anchors off the window's diagonal a walk follows before it gives up
+constexpr uint32_t NOPOS = 0xffffffffu;
+
+// -DANDI_COOP_STATS: how the kernel's work splits (diagnostic builds only; ANDI_COOP_STATS=1 prints)
+#ifdef ANDI_COOP_STATS
+__device__ unsigned long long g_coop_stats[24];
+#define CSTAT(k, v)                                                              \
+	do {                                                                         \
+		if (__lane_id() == 0) atomicAdd(&g_coop_stats[k], (unsigned long long)(v)); \
+	} while (0)
+#else
+#define CSTAT(k, v) ((void)0)
+#endif
+enum { CS_SEGMENTS, CS_G_STEPS, CS_BLOCKS, CS_LCP, CS_WINDOWS, CS_MOVED, CS_HEADS, CS_TRIPS, CS_LANE_STEPS, CS_PROBES, CS_ONPATH,
+	   CS_HOPS, CS_G_GAPS, CS_COVERED, CS_DROPPED, CS_X, CS_LCP_ROUNDS, CS_NODES };
+
+// how a head's walk ended
+enum : uint32_t { W_OK = 1, W_OPEN = 2, W_EXIT = 3, W_BREAK = 4, W_STATUS = 7u, W_HADX = 8u, W_LUCKY = 16u, W_NX_SHIFT = 8, W_ONPATH = 1u << 16 };
+
+template <int NCH>
+struct CoopLds {
+	uint32_t mbits[64 * NCH + 4]; // mismatch bits of the window, bit (x - wbase); the words behind it stay 0: nothing known there
+	uint32_t ebits[64 * NCH];     // positions counted as the gap behind a head: [head, landing)
+	uint32_t kbits[64 * NCH];     // the same stretch of a head whose walk met anchors off the diagonal: counted nowhere
+	uint32_t ha[COOP_HCAP];       // landing position of the head's walk
+	uint32_t hlen[COOP_HCAP];     // length of the anchor there (W_LUCKY: not known yet)
+	uint32_t hflag[COOP_HCAP];
+	uint16_t hpos[COOP_HCAP];     // the head's position - wbase
+	uint32_t pl[64], pp[64];      // the block of probes of mode G: length | unique << 31, position
+	uint32_t hist[16];
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { // a wave-uniform value: into a scalar register
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// the lanes of the wavefront exchange data through LDS: order this lane's accesses around the hand-over
+__device__ __forceinline__ void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) {
+	(void)__hip_atomic_fetch_or((lds_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+	for (int d = 32; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+#pragma unroll
+	for (int d = 32; d; d >>= 1) {
+		const uint32_t o = (uint32_t)__shfl_xor((int)v, d);
+		v = o < v ? o : v;
+	}
+	return v;
+}
+
+// 8 nibble flags (bit 4k + 3 of a word: symbols k differ) -> 8 bits
+__device__ __forceinline__ uint32_t squeeze8(uint32_t x) {
+	x = (x >> 3) & ONES;
+	x = (x | (x >> 3)) & 0x03030303u;
+	x = (x | (x >> 6)) & 0x000f000fu;
+	return (x | (x >> 12)) & 0xffu;
+}
+
+__device__ __forceinline__ uint32_t squeeze32(const uint4 &d) {
+	return squeeze8(d.x) | (squeeze8(d.y) << 8) | (squeeze8(d.z) << 16) | (squeeze8(d.w) << 24);
+}
+
+// 32 symbols of the subject from offset sa on (any sa >= -32; at and beyond the text's end: NUL, the padding's symbol)
+__device__ __forceinline__ uint4 ld_subject_guarded(const PairCtx &c, int64_t sa) {
+	if (sa >= (int64_t)c.E.n) return make_uint4(0x77777777u, 0x77777777u, 0x77777777u, 0x77777777u);
+	return ld_subject(c, (int32_t)sa);
+}
+
+struct Chain { // the chain of the wavefront: everything wave-uniform
+	ChainState st;
+	uint32_t quarter, rest; // model_count_equal's split (src/model.c:247-253), folded into the histogram at the end
+	uint32_t anchors;
+	uint32_t marked; // the mark behind the 2nd anchor has been written
+	uint32_t blk_base; // the block of probes in LDS answers positions blk_base ... blk_base + 63 (NOPOS: none)
+};
+
+// lcp(Q + p, S + s, maxlen) (src/process.c:59-65) with all lanes: 2048 symbols per round trip
+__device__ __forceinline__ uint32_t coop_lcp(const PairCtx &c, uint32_t p, uint32_t s, uint32_t maxlen) {
+	const uint32_t lane = __lane_id(), pe = p & ~1u, skip = p & 1u;
+	const int64_t dg = (int64_t)s - (int64_t)p;
+	CSTAT(CS_LCP, 1);
+	for (uint32_t base = 0;; base += 64 * WNT) {
+		const uint32_t x0 = pe + base + WNT * lane;
+		CSTAT(CS_LCP_ROUNDS, 1);
+		uint32_t f = 0; // first differing symbol of the lane's piece (a piece at or beyond the query's end: at once)
+		if (x0 < c.qlen) {
+			const uint4 d = neq32(ld_query(c, x0), ld_subject_guarded(c, (int64_t)x0 + dg));
+			f = first_from(d, base == 0 && lane == 0 ? skip : 0u);
+		}
+		const uint64_t hit = __ballot(f < WNT);
+		if (hit) {
+			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+			const uint32_t fl = (uint32_t)__shfl((int)f, (int)l);
+			const uint32_t len = pe + base + WNT * l + fl - p;
+			return len < maxlen ? len : maxlen;
+		}
+		if (base + 64 * WNT - skip >= maxlen) return maxlen;
+	}
+}
+
+// model_count (src/model.c:309-337) of Q[q..q+len) against S[s..s+len) with all lanes
+__device__ __forceinline__ void coop_count_gap(const PairCtx &c, lds_u32 *hist, uint32_t q, uint32_t s, uint32_t len) {
+	const uint32_t lane = __lane_id(), qe = q & ~1u, end = q + len;
+	const int64_t dg = (int64_t)s - (int64_t)q;
+	for (uint32_t base = qe; base < end; base += 64 * WNT) {
+		const uint32_t x0 = base + WNT * lane;
+		if (x0 >= end) continue;
+		const uint4 qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
+		const uint32_t lo = q > x0 ? q - x0 : 0u, hi = end - x0 < WNT ? end - x0 : WNT;
+		for (uint32_t j = lo >> 3; 8 * j < hi; ++j) {
+			const uint32_t a = lo > 8 * j ? lo - 8 * j : 0u, b = hi - 8 * j < 8 ? hi - 8 * j : 8u;
+			const uint32_t qw = pick(qv, j), sw = pick(sv, j), dw = neq8(qw, sw) >> 3;
+			const uint32_t ok = symbol_range(a, b) & ~(qw >> 2) & ~(sw >> 2); // both nucleotides, src/model.c:318-320
+			const uint32_t eq = ok & ~dw, b0 = qw, b1 = qw >> 1;
+			if (eq) {
+				lds_add(&hist[0], (uint32_t)__builtin_popcount(eq & ~(b0 | b1)));
+				lds_add(&hist[5], (uint32_t)__builtin_popcount(eq & b0 & ~b1));
+				lds_add(&hist[10], (uint32_t)__builtin_popcount(eq & b1 & ~b0));
+				lds_add(&hist[15], (uint32_t)__builtin_popcount(eq & b0 & b1));
+			}
+			for (uint32_t ne = ok & dw; ne; ne &= ne - 1) {
+				const uint32_t k = (uint32_t)__builtin_ctz(ne);
+				lds_add(&hist[(((sw >> k) & 3u) << 2) | ((qw >> k) & 3u)], 1u);
+			}
+		}
+	}
+}
+
+// first mismatch bit of the window at or after position x (x >= wbase), NOPOS if the window shows none
+template <int NCH>
+__device__ __forceinline__ uint32_t coop_next_mismatch(const CoopLds<NCH> &L, uint32_t wbase, uint32_t x) {
+	const uint32_t lane = __lane_id(), o = x - wbase;
+	for (uint32_t w0 = o >> 5; w0 < 64 * NCH; w0 += 64) {
+		const uint32_t w = w0 + lane;
+		uint32_t v = w < 64 * NCH ? L.mbits[w] : 0u;
+		if (w == (o >> 5)) v &= ~0u << (o & 31u);
+		const uint64_t hit = __ballot(v != 0);
+		if (hit) {
+			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+			const uint32_t vl = (uint32_t)__shfl((int)v, (int)l);
+			return wbase + 32 * (w0 + l) + (uint32_t)__builtin_ctz(vl);
+		}
+	}
+	return NOPOS;
+}
+
+// last mismatch bit of the window before position x (x > wbase), NOPOS if none
+template <int NCH>
+__device__ __forceinline__ uint32_t coop_prev_mismatch(const CoopLds<NCH> &L, uint32_t wbase, uint32_t x) {
+	const uint32_t lane = __lane_id(), o = x - wbase; // bits 0 .. o - 1
+	if (o == 0) return NOPOS;
+	const uint32_t top = (o - 1) >> 5;
+	for (int32_t w0 = (int32_t)top; w0 >= 0; w0 -= 64) {
+		const int32_t w = w0 - (int32_t)lane;
+		uint32_t v = w >= 0 && w < 64 * NCH ? L.mbits[w] : 0u;
+		if (w == (int32_t)top && ((o - 1) & 31u) != 31u) v &= (2u << ((o - 1) & 31u)) - 1u;
+		const uint64_t hit = __ballot(v != 0);
+		if (hit) {
+			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
+			const uint32_t vl = (uint32_t)__shfl((int)v, (int)l);
+			return wbase + 32 * (uint32_t)(w0 - (int32_t)l) + 31u - (uint32_t)__builtin_clz(vl);
+		}
+	}
+	return NOPOS;
+}
+
+// the record of an anchor (scan.h: the cold chain's first anchor, the state and counts right after its second)
+template <int NCH>
+__device__ __forceinline__ void coop_note_anchor(const ScanArgs &a, size_t slot, Chain &ch, const CoopLds<NCH> &L) {
+	const uint32_t lane = __lane_id();
+	ColdMark *m = a.marks + slot * ANDI_COLD_MARKS;
+	++ch.anchors;
+	if (ch.anchors == 1 && lane == 0) *(uint4 *)m->first = make_uint4(ch.st.lastQ, ch.st.lastS, ch.st.lastLen, 0);
+	if (ch.anchors == 2) {
+		ch.marked = 1;
+		if (lane == 0) {
+			ChainState ms = ch.st;
+			ms.pad[0] = 1, ms.pad[1] = ms.pad[2] = 0;
+			m->st = ms;
+		}
+		if (lane < 16) {
+			uint32_t v = L.hist[lane];
+			if (lane == 0 || lane == 5 || lane == 10 || lane == 15) v += ch.quarter;
+			if (lane == 15) v += ch.rest;
+			m->counts[lane] = v;
+		}
+	}
+}
+
+// What an anchor at subject offset curS found at query offset st.p does to the counts (src/process.c:157-190)
+template <int NCH>
+__device__ __forceinline__ void coop_account(const PairCtx &c, Chain &ch, CoopLds<NCH> &L, uint32_t curS) {
+	ChainState &st = ch.st;
+	const uint32_t endS = st.lastS + st.lastLen, endQ = st.lastQ + st.lastLen;
+	if (curS > endS && st.p - endQ == curS - endS && (curS < c.border) == (st.lastS < c.border)) {
+		ch.quarter += st.lastLen >> 2, ch.rest += st.lastLen & 3u;
+		coop_count_gap(c, (lds_u32 *)L.hist, endQ, endS, st.p - endQ);
+		CSTAT(CS_G_GAPS, 1);
+		st.lwra = 1;
+	} else {
+		if (st.lwra || st.lastLen >= 2 * c.thr) ch.quarter += st.lastLen >> 2, ch.rest += st.lastLen & 3u;
+		st.lwra = 0;
+	}
+}
+
+// ------------------------------------------------------------------ mode W
+// The chain stands at a canonical state of diagonal dg: st.p = e0 + 1 behind the anchor [lastQ, e0), e0 a mismatch
+// of the diagonal.  Returns true if the chain moved; st is a genuine loop-top state either way.
+template <int NCH>
+__device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c, Chain &ch, CoopLds<NCH> &L, uint32_t end) {
+	const uint32_t lane = __lane_id(), thr = c.thr, n = (uint32_t)c.E.n;
+	ChainState &st = ch.st;
+	const int64_t dg = (int64_t)st.lastS - (int64_t)st.lastQ;
+	const uint32_t e0 = st.lastQ + st.lastLen;
+	const uint32_t wbase = e0 & ~31u;
+	constexpr uint32_t W = 2048 * NCH;
+
+	// ---- the bits: position x of the window against subject position x + dg
+#pragma unroll
+	for (int ck = 0; ck < NCH; ++ck) {
+		const uint32_t x0 = wbase + 2048 * ck + WNT * lane;
+		uint32_t m = ~0u; // positions at and beyond the query's end: lcp() stops there
+		if (x0 < c.qlen) {
+			m = squeeze32(neq32(ld_query(c, x0), ld_subject_guarded(c, (int64_t)x0 + dg)));
+			if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0);
+		}
+		if (x0 <= e0 && e0 - x0 < WNT) m &= ~0u << (e0 - x0); // (what lies before the anchor is none of the window's business)
+		if (x0 + WNT <= e0) m = 0;
+		L.mbits[64 * ck + lane] = m, L.ebits[64 * ck + lane] = 0, L.kbits[64 * ck + lane] = 0;
+	}
+	if (lane < 4) L.mbits[64 * NCH + lane] = 0;
+	wave_sync();
+
+	// ---- heads: a mismatch with fewer than thr equal symbols behind it and at least thr before it.  Lane l looks
+	// at the NCH words of positions 32 NCH l ...; a word together with its neighbours, thr < 32
+	uint32_t hmask[NCH], nh = 0;
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) {
+		const uint32_t w = NCH * lane + j;
+		const uint32_t cur = L.mbits[w], nxt = L.mbits[w + 1], prv = w ? L.mbits[w - 1] : 0u;
+		// a mismatch among the next thr positions / among the thr positions before: smear the bits over thr - 1 more
+		// positions (doubling, then the remainder), then shift by one
+		uint64_t up = ((uint64_t)nxt << 32) | cur, dn = ((uint64_t)cur << 32) | prv;
+		uint32_t have = 1;
+		while (2 * have <= thr) up |= up >> have, dn |= dn << have, have *= 2;
+		if (have < thr) up |= up >> (thr - have), dn |= dn << (thr - have);
+		const uint32_t soon = (uint32_t)(up >> 1), before = (uint32_t)((dn << 1) >> 32);
+		uint32_t live = ~0u; // a chain that stands behind position x >= end - 1 has left the segment
+		const uint32_t x0 = wbase + 32 * w;
+		if (x0 + 1 >= end) live = 0;
+		else if (end - 1 - x0 < 32) live = (1u << (end - 1 - x0)) - 1u;
+		hmask[j] = cur & soon & ~before & live;
+		nh += (uint32_t)__builtin_popcount(hmask[j]);
+	}
+	uint32_t hbase = nh; // exclusive prefix sum over the lanes
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = (uint32_t)__shfl_up((int)hbase, d);
+		if (lane >= (uint32_t)d) hbase += o;
+	}
+	const uint32_t nheads_all = uni((uint32_t)__shfl((int)hbase, 63));
+	hbase -= nh;
+	uint32_t dropped = NOPOS; // the first head beyond the list's capacity: nothing is decided from there on
+#pragma unroll
+	for (int j = 0; j < NCH; ++j)
+		for (uint32_t hm = hmask[j]; hm; hm &= hm - 1) {
+			const uint32_t off = 32 * (NCH * lane + j) + (uint32_t)__builtin_ctz(hm);
+			if (hbase < COOP_HCAP)
+				L.hpos[hbase] = (uint16_t)off;
+			else if (dropped == NOPOS)
+				dropped = wbase + off;
+			++hbase;
+		}
+	const uint32_t nheads = nheads_all < COOP_HCAP ? nheads_all : COOP_HCAP;
+	CSTAT(CS_WINDOWS, 1);
+	CSTAT(CS_HEADS, nheads);
+	CSTAT(CS_DROPPED, nheads_all - nheads);
+	const uint32_t f_cap = nheads_all > COOP_HCAP ? uni(wave_min(dropped)) : NOPOS;
+	wave_sync();
+
+	// ---- the walks, one lane each; a lane that is done takes the next head
+	{
+		uint32_t hk = NOPOS, e = 0, p = 0, Xq = 0, Xs = 0, Xl = 0, nX = 0, next_head = 0;
+		LWin w;
+		w.q0 = EMPTY, w.dg = NO_DIAG;
+		for (;;) {
+			const uint64_t idle = __ballot(hk == NOPOS);
+			if (idle && next_head < nheads) {
+				const uint32_t my = next_head + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+				if (hk == NOPOS && my < nheads) hk = my, e = wbase + L.hpos[my], p = e + 1, Xl = 0, nX = 0;
+				next_head += (uint32_t)__builtin_popcountll(idle);
+			}
+			if (!__any(hk != NOPOS)) break;
+#ifdef ANDI_COOP_STATS
+			{
+				const uint64_t on = __ballot(hk != NOPOS);
+				if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
+					atomicAdd(&g_coop_stats[CS_TRIPS], 1ull);
+					atomicAdd(&g_coop_stats[CS_LANE_STEPS], (unsigned long long)__builtin_popcountll(on));
+				}
+			}
+#endif
+			if (hk == NOPOS) continue;
+			uint32_t res = 0, ra = 0, rlen = 0;
+			if (p >= end) {
+				res = Xl ? W_BREAK : W_EXIT;
+			} else if (p - wbase >= W) {
+				res = Xl ? W_BREAK : W_OPEN; // the walk has left the window
+			} else if (Xl == 0) {
+				if ((int64_t)p + dg < (int64_t)n && p - e <= thr) { // lucky_anchor applies on the diagonal: the bits answer
+					const uint32_t o = p - wbase, wi = o >> 5;
+					{
+						const uint32_t lo = L.mbits[wi], hi = L.mbits[wi + 1];
+						const uint32_t v = (o & 31u) ? (lo >> (o & 31u)) | (hi << (32u - (o & 31u))) : lo;
+						const uint32_t r = v ? (uint32_t)__builtin_ctz(v) : 32u; // equal symbols from p on, as far as 32 bits show
+						if (o + r < W) { // a mismatch of the window ends the run (r < 32: thr < 32)
+							if (r >= thr) res = W_OK | W_LUCKY, ra = p;
+						} else if (W - o >= thr) { // thr equal symbols and more: an anchor; where it ends is settled later
+							res = W_OK | W_LUCKY, ra = p;
+						} else {
+							res = W_OPEN;
+						}
+					}
+				}
+			} else { // lucky_anchor on the diagonal of the anchor off the window's: compare
+				const uint32_t adv = p - Xq;
+				if (Xs + adv < n && adv - Xl <= thr) {
+					const uint32_t qa = p & ~1u;
+					const uint4 d = neq32(ld_query(c, qa), ld_subject_guarded(c, (int64_t)qa + ((int64_t)Xs - (int64_t)Xq)));
+					uint32_t l = first_from(d, p & 1u) - (p & 1u);
+					if (l > c.qlen - p) l = c.qlen - p;
+					if (l >= thr) res = W_BREAK; // the chain really changes its diagonal: not this window's business
+				}
+			}
+			if (!res) {
+				const Probe pr = lane_probe(c, p, w);
+#ifdef ANDI_COOP_STATS
+				atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
+#endif
+				if (pr.unique && pr.len >= thr) {
+					if ((int64_t)pr.pos == (int64_t)p + dg) { // on the diagonal
+						// a right anchor of the anchor before the head only on the same strand (src/process.c:162)
+						const bool same_side = ((int64_t)p + dg < (int64_t)c.border) == ((int64_t)e + dg <= (int64_t)c.border);
+						if (!same_side || (Xl && Xl >= 2 * thr))
+							res = W_BREAK;
+						else
+							res = W_OK | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT), ra = p, rlen = pr.len;
+					} else {
+						const uint32_t endS = Xs + Xl, endQ = Xq + Xl;
+						if (Xl && ((pr.pos > endS && p - endQ == pr.pos - endS && (pr.pos < c.border) == (Xs < c.border)) || Xl >= 2 * thr))
+							res = W_BREAK; // a right anchor off the diagonal (its gap is not in the window), or an anchor that is counted by itself
+						else if (++nX > COOP_MAX_X)
+							res = W_BREAK;
+						else
+							Xq = p, Xs = pr.pos, Xl = pr.len;
+					}
+				}
+				if (!res) p += pr.len + 1;
+			}
+			if (res) {
+				if ((res & W_LUCKY) && ((int64_t)ra + dg < (int64_t)c.border) != ((int64_t)e + dg <= (int64_t)c.border)) res = W_BREAK;
+				L.ha[hk] = ra, L.hlen[hk] = rlen, L.hflag[hk] = res;
+				hk = NOPOS;
+			}
+		}
+	}
+	wave_sync();
+
+	// ---- the chain hops from head to head; between them every mismatch is followed by a lucky anchor.
+	// Nearly every head is on the chain's path and is followed by the next one: the lanes work out, head by head,
+	// where its walk's anchor ends and whether anything is unusual about it (the next head lies inside the walk's
+	// span; the walk did not land; a position at which the window's knowledge ends comes first); the chain is then
+	// followed from one unusual head to the next with ballots -- a few trips per window, not one per head.
+	uint32_t F = coop_prev_mismatch(L, wbase, wbase + W); // behind the last mismatch nothing is known
+	if (f_cap < F) F = f_cap;
+	{
+		const int64_t b = (int64_t)c.border - dg; // '#': the next anchor lies on the other strand, no right anchor (src/process.c:162)
+		if (b >= (int64_t)e0 && b < (int64_t)F) F = (uint32_t)b;
+		if (end - 1 < F) { // a chain that stands behind a position >= end - 1 has left the segment
+			const uint32_t fe = coop_next_mismatch(L, wbase, end - 1 > e0 ? end - 1 : e0);
+			if (fe != NOPOS && fe < F) F = fe;
+		}
+	}
+	if (e0 >= F) return false;
+	uint32_t cur = e0, kcur = 0, hop = NOPOS; // hop: the last head the chain hopped from
+	bool done = false;
+	for (uint32_t base = 0; base < nheads && !done; base += 64) {
+		const uint32_t k = base + lane;
+		const bool valid = k < nheads;
+		const uint32_t pos = valid ? wbase + L.hpos[k] : NOPOS, fl = valid ? L.hflag[k] : 0u;
+		uint32_t endk = NOPOS; // where the anchor the walk landed on ends: the chain's next stand
+		if ((fl & W_STATUS) == W_OK) {
+			const uint32_t la = L.ha[k];
+			if (fl & W_LUCKY) {
+				const uint32_t o = la - wbase;
+				uint32_t wi = o >> 5, v = L.mbits[wi] & (~0u << (o & 31u));
+				while (v == 0 && wi + 1 < 64 * NCH) v = L.mbits[++wi];
+				if (v) endk = wbase + 32 * wi + (uint32_t)__builtin_ctz(v);
+			} else {
+				endk = la + L.hlen[k];
+			}
+		}
+		const bool hop_ok = endk != NOPOS;
+		uint32_t nxtpos = (uint32_t)__shfl_down((int)pos, 1);
+		if (lane == 63) nxtpos = k + 1 < nheads ? wbase + L.hpos[k + 1] : NOPOS;
+		const bool unusual = valid && (!hop_ok || pos >= F || nxtpos < endk || endk >= F);
+		bool onpath = false;
+		if (kcur < base) kcur = base;
+		{ // heads the chain has jumped over already
+			const uint64_t at = __ballot(valid && pos >= cur);
+			const uint32_t first = at ? (uint32_t)__builtin_ctzll(at) : 64u;
+			if (base + first > kcur) kcur = base + first;
+		}
+		while (!done && kcur < base + 64 && kcur < nheads) {
+			CSTAT(CS_HOPS, 1);
+			const uint32_t lo = kcur - base;
+			const uint64_t ev = __ballot(unusual) & (~0ull << lo);
+			const uint32_t j = ev ? (uint32_t)__builtin_ctzll(ev) : 64u; // every head before it: hopped, on to the next
+			if (lane >= lo && lane < j && valid) onpath = true;
+			if (j > lo) {
+				const uint32_t last = (j < 64 ? j : 64u) - 1u;
+				const uint32_t lastv = nheads - base - 1u < last ? nheads - base - 1u : last;
+				hop = base + lastv, cur = uni((uint32_t)__shfl((int)endk, (int)lastv));
+			}
+			if (j >= 64) {
+				kcur = base + 64;
+				break;
+			}
+			const uint32_t pj = uni((uint32_t)__shfl((int)pos, (int)j)), ej = uni((uint32_t)__shfl((int)endk, (int)j));
+			if (pj >= F) { // the chain reaches a position where the window's knowledge ends before this head
+				cur = F, done = true;
+			} else if (ej == NOPOS) { // its walk did not land (or where the anchor ends is not in the window): the chain stops at the head
+				cur = pj, done = true;
+			} else { // hopped; the chain stands where the anchor ends
+				if (lane == j) onpath = true;
+				hop = base + j, cur = ej;
+				if (ej >= F) {
+					done = true;
+				} else {
+					const uint64_t at = __ballot(valid && pos >= ej) & (~0ull << j);
+					kcur = base + (at ? (uint32_t)__builtin_ctzll(at) : 64u);
+				}
+			}
+		}
+		if (valid) {
+			L.hlen[k] = endk;
+			if (onpath) L.hflag[k] = fl | W_ONPATH;
+		}
+#ifdef ANDI_COOP_STATS
+		{
+			const uint64_t on = __ballot(onpath), ox = __ballot(onpath && (fl & W_HADX));
+			CSTAT(CS_ONPATH, __builtin_popcountll(on));
+			CSTAT(CS_X, __builtin_popcountll(ox));
+		}
+#endif
+	}
+	if (!done) cur = F; // past the last head: lucky anchors up to where the window's knowledge ends
+	if (cur == e0) return false;
+	CSTAT(CS_MOVED, 1);
+	CSTAT(CS_COVERED, cur - e0);
+	wave_sync();
+	// the anchor that ends at cur: the one the last hop landed on, or the one behind the mismatch before cur
+	uint32_t aQ, lw = 1;
+	if (hop != NOPOS && uni(L.hlen[hop]) == cur) {
+		aQ = uni(L.ha[hop]), lw = (uni(L.hflag[hop]) & W_HADX) ? 0u : 1u;
+	} else {
+		aQ = coop_prev_mismatch(L, wbase, cur) + 1;
+	}
+	// Heads whose walk met anchors off the diagonal (rare): nothing pairs up across such a stretch; the anchor
+	// before the head is counted only if it was a right anchor itself or is long (src/process.c:176-186)
+	uint32_t extra_anchors = 0;
+	for (uint32_t base = 0; base < nheads; base += 64) {
+		const uint32_t k = base + lane;
+		const uint32_t fl = k < nheads ? L.hflag[k] : 0u;
+		for (uint64_t bx = __ballot((fl & W_ONPATH) && (fl & W_HADX)); bx; bx &= bx - 1) {
+			const uint32_t kk = base + (uint32_t)__builtin_ctzll(bx);
+			const uint32_t pk = wbase + uni(L.hpos[kk]);
+			uint32_t a_before = NOPOS, lw_before = 1;
+			if (pk == e0) {
+				a_before = st.lastQ, lw_before = st.lwra;
+			} else {
+				for (uint32_t b2 = 0; b2 < nheads && a_before == NOPOS; b2 += 64) { // a hop that landed right before this head?
+					const uint32_t k2 = b2 + lane;
+					const bool m = k2 < nheads && (L.hflag[k2] & W_ONPATH) && L.hlen[k2] == pk;
+					const uint64_t bm = __ballot(m);
+					if (bm) {
+						const uint32_t kp = b2 + (uint32_t)__builtin_ctzll(bm);
+						a_before = uni(L.ha[kp]), lw_before = (uni(L.hflag[kp]) & W_HADX) ? 0u : 1u;
+					}
+				}
+				if (a_before == NOPOS) a_before = coop_prev_mismatch(L, wbase, pk) + 1;
+			}
+			if (lw_before || pk - a_before >= 2 * thr) ch.quarter += (pk - a_before) >> 2, ch.rest += (pk - a_before) & 3u;
+			extra_anchors += (uni(L.hflag[kk]) >> W_NX_SHIFT) & 7u;
+		}
+	}
+	wave_sync();
+
+	// ---- the stretches behind the heads the chain came by: gap positions (ebits) or counted nowhere (kbits);
+	// their symbols are counted here, by the lane of the head (model_count, src/model.c:309-337)
+	{
+		Tally tl;
+		tl.hist = (lds_u32 *)L.hist, tl.hs = 1, tl.quarter = tl.rest = 0;
+		tl.same[0] = tl.same[1] = tl.same[2] = tl.same[3] = 0;
+		LWin w;
+		w.q0 = EMPTY, w.dg = NO_DIAG;
+		for (uint32_t b = 0; b < nheads; b += 64) {
+			const uint32_t i = b + lane;
+			const uint32_t fl = i < nheads ? L.hflag[i] : 0u;
+			if (!(fl & W_ONPATH)) continue;
+			const uint32_t o0 = L.hpos[i], o1 = L.ha[i] - wbase; // [o0, o1)
+			uint32_t *dst = (fl & W_HADX) ? L.kbits : L.ebits;
+			for (uint32_t wd = o0 >> 5; 32 * wd < o1; ++wd) {
+				uint32_t m = ~0u;
+				if (wd == (o0 >> 5)) m &= ~0u << (o0 & 31u);
+				if (32 * wd + 32 > o1) m &= (1u << (o1 & 31u)) - 1u;
+				lds_or(&dst[wd], m);
+			}
+			if (!(fl & W_HADX)) lane_count_gap(w, c, tl, wbase + o0, (uint32_t)((int64_t)(wbase + o0) + dg), o1 - o0);
+		}
+	}
+	wave_sync();
+
+	// ---- the mismatches behind which a lucky anchor follows at once (all that are in no such stretch), and the
+	// anchors: one ends at every position that starts a gap.  Positions e0 ... cur - 1.
+	uint32_t q_acc = 0, r_acc = 0, n_acc = 0;
+	uint32_t carry = st.lastQ - 1; // the last position so far that is in no anchor (- 1: the anchor before e0 starts at lastQ)
+	uint32_t last_word = (cur - 1 - wbase) >> 5; // (a landing beyond the window: nothing but that anchor out there)
+	if (last_word > 64 * NCH - 1) last_word = 64 * NCH - 1;
+	for (uint32_t ck = 0; 64 * ck <= last_word; ++ck) {
+		const uint32_t wi = 64 * ck + lane, x0 = wbase + 32 * wi;
+		uint32_t rm = ~0u; // positions e0 ... cur - 1
+		if (x0 + WNT <= e0 || x0 >= cur) rm = 0;
+		if (rm && e0 > x0) rm &= ~0u << (e0 - x0);
+		if (rm && cur - x0 < WNT) rm &= (1u << (cur - x0)) - 1u;
+		const uint32_t m = L.mbits[wi] & rm, eb = L.ebits[wi] & rm, kb = L.kbits[wi] & rm;
+		const uint32_t u = m | eb | kb;
+		// the last position of u before each lane's word
+		const uint32_t mine = u ? x0 + 31u - (uint32_t)__builtin_clz(u) + 2u : 0u; // (+ 2: 0 = none; positions from -1 on)
+		uint32_t scan = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = (uint32_t)__shfl_up((int)scan, d);
+			if (lane >= (uint32_t)d && o > scan) scan = o;
+		}
+		uint32_t before = (uint32_t)__shfl_up((int)scan, 1);
+		if (lane == 0) before = 0;
+		const uint32_t cin = carry + 2u;
+		if (cin > before) before = cin;
+		const uint32_t all = (uint32_t)__shfl((int)scan, 63);
+		if (all > cin) carry = uni(all) - 2u;
+		// gap starts: a bit of u whose predecessor is none
+		const uint32_t prev_top = wi ? ((L.mbits[wi - 1] | L.ebits[wi - 1] | L.kbits[wi - 1]) >> 31) : 0u;
+		const uint32_t prev_in = (x0 > e0) ? prev_top : 0u; // (what lies before e0 is the anchor)
+		uint32_t gs = u & ~((u << 1) | prev_in);
+		n_acc += (uint32_t)__builtin_popcount(gs);
+		for (; gs; gs &= gs - 1) {
+			const uint32_t b = (uint32_t)__builtin_ctz(gs);
+			const uint32_t below = u & ((1u << b) - 1u);
+			uint32_t pv; // the last position before x0 + b that is in no anchor
+			if (below)
+				pv = x0 + 31u - (uint32_t)__builtin_clz(below);
+			else
+				pv = before - 2u;
+			const uint32_t len = x0 + b - 1u - pv; // (pv may be lastQ - 1 = -1: unsigned wrap is fine)
+			// (the anchor before a stretch that is counted nowhere: the hop above has dealt with it, src/process.c:176-186)
+			if (!((kb >> b) & 1u)) q_acc += len >> 2, r_acc += len & 3u;
+		}
+		// mismatches in no head's stretch: single-position gaps
+		uint32_t singles = m & ~eb & ~kb;
+		if (__any(singles != 0)) {
+			uint4 qv = make_uint4(0, 0, 0, 0), sv = qv;
+			if (singles) qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
+			for (; singles; singles &= singles - 1) {
+				const uint32_t b = (uint32_t)__builtin_ctz(singles), sh = 4 * (b & 7u);
+				const uint32_t qn = (pick(qv, b >> 3) >> sh) & 15u, sn = (pick(sv, b >> 3) >> sh) & 15u;
+				if (!((qn | sn) & 4u)) lds_add((lds_u32 *)&L.hist[((sn & 3u) << 2) | (qn & 3u)], 1u);
+			}
+		}
+	}
+	ch.quarter += wave_sum(q_acc), ch.rest += wave_sum(r_acc);
+	ch.anchors += wave_sum(n_acc) + extra_anchors;
+	{
+		const uint32_t nodes = wave_sum(n_acc);
+		(void)nodes;
+		CSTAT(CS_NODES, nodes);
+	}
+	st.p = cur + 1, st.lastS = (uint32_t)((int64_t)aQ + dg), st.lastQ = aQ, st.lastLen = cur - aQ, st.lwra = lw;
+	return true;
+}
+
+// ------------------------------------------------------------------ the kernel
+template <int NCH>
+__global__ __launch_bounds__(BLOCK, 5) void k_coop_cold(ScanArgs a) {
+	__shared__ CoopLds<NCH> s_lds[WAVES_PER_BLOCK];
+	CoopLds<NCH> &L = s_lds[threadIdx.x >> 6];
+	const uint32_t lane = __lane_id();
+	const uint32_t sub = blockIdx.y;
+	if (a.subjects[sub].mode != ANDI_MODE_PROBE) return;
+	const uint32_t wseg = uni(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+	if (wseg >= a.total_segs) return;
+	const uint32_t qidx = uni(a.seg2query[wseg]);
+	if (a.self[sub] == (int64_t)qidx) return;
+	const uint32_t seg_in_q = wseg - uni(a.qseg_start[qidx]);
+	PairCtx c = make_ctx(a, sub, qidx);
+	const uint32_t start = seg_in_q * a.seg, end = start + a.seg < c.qlen ? start + a.seg : c.qlen;
+	const size_t slot = (size_t)sub * a.total_segs + wseg;
+	const uint32_t n = (uint32_t)c.E.n, thr = c.thr;
+
+	if (lane < 16) L.hist[lane] = 0;
+	Chain ch;
+	ch.st = seg_in_q == 0 ? initial_state() : cold_state(start, n);
+	ch.quarter = ch.rest = ch.anchors = ch.marked = 0, ch.blk_base = NOPOS;
+	ChainState &st = ch.st;
+	wave_sync();
+
+	CSTAT(CS_SEGMENTS, 1);
+	while (st.p < end) {
+		CSTAT(CS_G_STEPS, 1);
+		// ---- one step of mode G (src/process.c:153-197)
+		bool found = false, lucky = false;
+		uint32_t curS = 0, curLen = 0;
+		if (lucky_applies(st, n, thr)) {
+			curS = st.lastS + (st.p - st.lastQ);
+			curLen = coop_lcp(c, st.p, curS, c.qlen - st.p);
+			found = lucky = curLen >= thr;
+		}
+		if (!found) {
+			if (ch.blk_base == NOPOS || st.p < ch.blk_base || st.p - ch.blk_base >= 64) { // the next 64 positions' answers at once
+				const uint32_t p = st.p + lane;
+				CSTAT(CS_BLOCKS, 1);
+				Probe pr;
+				pr.len = 0, pr.pos = 0, pr.unique = false;
+				if (p < c.qlen) {
+					LWin w;
+					w.q0 = EMPTY, w.dg = NO_DIAG;
+					pr = lane_probe(c, p, w);
+				}
+				wave_sync();
+				L.pl[lane] = pr.len | (pr.unique ? 0x80000000u : 0u), L.pp[lane] = pr.pos;
+				ch.blk_base = st.p;
+				wave_sync();
+			}
+			const uint32_t v = uni(L.pl[st.p - ch.blk_base]);
+			curLen = v & 0x7fffffffu, curS = uni(L.pp[st.p - ch.blk_base]);
+			found = (v >> 31) && curLen >= thr;
+		}
+		if (found) {
+			coop_account(c, ch, L, curS);
+			st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
+		}
+		st.p += curLen + 1;
+		if (found) {
+			wave_sync();
+			coop_note_anchor(a, slot, ch, L);
+		}
+		// ---- windows one after the other while the chain stays canonical on the diagonal and moves
+		if (found && lucky)
+			while (st.p < end && st.lastQ + st.lastLen < c.qlen && coop_window<NCH>(a, c, ch, L, end)) {
+			}
+	}
+
+	// ---- what pass B reads (scan.h)
+	wave_sync();
+	if (lane == 0) {
+		ColdMark *m = a.marks + slot * ANDI_COLD_MARKS;
+		if (!ch.marked) m->st.pad[0] = 0; // unused mark
+		ChainState out = st;
+		out.pad[0] = 0, out.pad[1] = ch.anchors < 255 ? ch.anchors : 255, out.pad[2] = 0;
+		a.cold_exit[slot] = out;
+		a.exit_p[slot] = st.p;
+	}
+	if (lane < 16) {
+		uint32_t v = L.hist[lane];
+		if (lane == 0 || lane == 5 || lane == 10 || lane == 15) v += ch.quarter;
+		if (lane == 15) v += ch.rest;
+		a.cold_counts[slot * 16 + lane] = v;
+	}
+}
+
+} // namespace
+
+int andi_coop_enabled(void) { // ANDI_COOP=n: pass A with one wavefront per chain, windows of 2048 n symbols (n = 2, 4, 8); unset or 0: one lane per chain (scan_lane.hip)
+	const char *e = getenv("ANDI_COOP");
+	if (!e) return 0; // (measured slower so far: DESIGN.md 3.6)
+	const int v = atoi(e);
+	return v == 2 || v == 4 || v == 8 ? v : (v == 0 ? 0 : 4);
+}
+
+hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one segment length for the call, RAW/JC/Kimura
+	const dim3 grid((a.total_segs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.nsub);
+	switch (andi_coop_enabled()) {
+		case 2: k_coop_cold<2><<<grid, BLOCK, 0, st>>>(a); break;
+		case 8: k_coop_cold<8><<<grid, BLOCK, 0, st>>>(a); break;
+		default: k_coop_cold<4><<<grid, BLOCK, 0, st>>>(a); break;
+	}
+#ifdef ANDI_COOP_STATS
+	if (getenv("ANDI_COOP_STATS")) {
+		static const char *names[24] = {"segments", "G steps", "probe blocks", "coop_lcp calls", "windows", "windows that moved", "heads", "walk trips",
+										"walk lane-steps", "walk probes", "heads on the path", "hops", "gaps counted in G", "positions covered by windows",
+										"heads dropped", "walks with anchors off the diagonal", "coop_lcp rounds", "nodes", "", "", "", "", "", ""};
+		unsigned long long h[24];
+		(void)hipStreamSynchronize(st);
+		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_coop_stats), sizeof h);
+		for (int k = 0; k < 18; ++k) fprintf(stderr, "coop_stats %-36s %llu\n", names[k], h[k]);
+		memset(h, 0, sizeof h);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), h, sizeof h);
+	}
+#endif
+	return hipGetLastError();
+}

@@ -425,7 +425,7 @@ __device__ __forceinline__ void lane_cold_quad(const ScanArgs &a, const LaneItem
 			const unsigned long long pub = __hip_atomic_load(a.first_pub + slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			nbQ = pub != ~0ull ? it.end : EMPTY, nbS = (uint32_t)(pub >> 32), nbLen = (uint32_t)pub;
 		}
-		if (at_end && (has_nb || it.end < c.qlen) && nbQ == it.end && nbS - nbQ == curS - st.p) {
+		if (at_end && it.end < c.qlen && nbQ == it.end && nbS - nbQ == curS - st.p) { // (it.end < qlen: the lane to the right may hold another query's first segment)
 			curLen = (it.end - st.p) + nbLen, nb_end = true;
 			STAT(ST_FINAL_SA); // (diagnostic builds count the matches ended by the neighbour in this slot)
 		}

@@ -310,9 +310,13 @@ int main(int argc, char *argv[]) {
 	andi_hip_default_opts(&opts);
 	long procs = sysconf(_SC_NPROCESSORS_ONLN);
 	opts.host_threads = procs > 0 ? (int)procs : 1;
-	/* the rows of the matrix are tiled over all visible GPUs (ANDI_HIP_GPUS=k: the first k) */
-	opts.num_gpus = -1;
-	if (getenv("ANDI_HIP_GPUS") && atoi(getenv("ANDI_HIP_GPUS")) > 0) opts.num_gpus = atoi(getenv("ANDI_HIP_GPUS"));
+	/* one GPU unless asked: ANDI_HIP_GPUS=k tiles the rows of the matrix over the first k visible GPUs, ANDI_HIP_GPUS=all over
+	 * all of them (the gather between distinct devices has not run on hardware yet: opt-in until it has) */
+	opts.num_gpus = 1;
+	if (getenv("ANDI_HIP_GPUS")) {
+		if (!strcmp(getenv("ANDI_HIP_GPUS"), "all")) opts.num_gpus = -1;
+		else if (atoi(getenv("ANDI_HIP_GPUS")) > 0) opts.num_gpus = atoi(getenv("ANDI_HIP_GPUS"));
+	}
 	int verbose = 0, join = 0, truncate = 0;
 	unsigned long bootstrap = 0;
 	enum { P_AUTO, P_NEVER, P_ALWAYS } progress = P_AUTO;

@@ -66,5 +66,27 @@ def ctx():
     c.close()
 
 
+def verify_suffix_array(text: bytes, sa) -> None:
+    """O(n) proof that `sa` is THE suffix array of `text` (unsigned byte order, the terminator excluded, src/esa.c:294-304):
+    a permutation of 0..n-1, and every suffix smaller than its successor -- by the first byte, or, the first bytes being
+    equal, by the ranks of the two suffixes one position on (the empty suffix ranks lowest).  With this the oracle may be
+    fed the product's suffix array and still be an independent check of everything built on it."""
+    n = len(text)
+    sa = np.asarray(sa, dtype=np.int64)
+    assert sa.shape == (n,)
+    seen = np.zeros(n, dtype=bool)
+    assert sa.min() >= 0 and sa.max() < n
+    seen[sa] = True
+    assert seen.all(), "not a permutation"
+    rank = np.empty(n + 1, dtype=np.int64)
+    rank[sa] = np.arange(n)
+    rank[n] = -1  # the empty suffix
+    t = np.frombuffer(text, dtype=np.uint8)
+    a, b = sa[:-1], sa[1:]
+    ta, tb = t[a], t[b]
+    ok = (ta < tb) | ((ta == tb) & (rank[a + 1] < rank[b + 1]))
+    assert ok.all(), "suffixes out of order at ranks %s" % np.nonzero(~ok)[0][:5].tolist()
+
+
 def rand_dna(rng, n, alphabet=b"ACGT"):
     return rng.choice(np.frombuffer(alphabet, np.uint8), n).tobytes()

@@ -5,7 +5,19 @@ in seconds, and through size-independent properties at full size."""
 import numpy as np
 import pytest
 
+from tests.conftest import verify_suffix_array
+
 pytestmark = pytest.mark.gpu
+
+
+def _oracle_on_product_sa(orc, seq, esa):
+    """The oracle's arrays on the suffix array the product built on the device -- after an O(n) proof that it IS the
+    suffix array of RS (permutation + order of neighbours), so that the check stays independent of the product."""
+    sa = esa.SA
+    assert b"!" not in seq
+    RS = seq[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")) + b"#" + seq  # src/sequence.c:177-190, without the product
+    verify_suffix_array(RS, sa)
+    return orc.OracleEsa(seq, sa=sa)
 
 
 def _star_set(n, length, d_lo, d_hi, seed, ragged=0.0):
@@ -65,7 +77,7 @@ def test_c4_full_length_rows_choose_segments_per_pair(ctx, orc):
     assert (got[:, :, 16][got[:, :, 16] != 9] == n).all()
     cov = got[:, :, :16].sum(axis=2) / n
     assert (cov[got[:, :, 16] == n] > 0.9).all() and (cov <= 1.0).all()
-    O = orc.OracleEsa(seqs[17], sa=esas[1].SA)  # the oracle's own arrays on the product's suffix array
+    O = _oracle_on_product_sa(orc, seqs[17], esas[1])
     for j in (0, 5, 16, 18, 39):
         assert (got[1, j] == O.dist_anchor(seqs[j])).all(), j
     assert got[1, 17, 0] == 9 and got[1, 17, 16] == 9
@@ -104,7 +116,7 @@ def test_c3_full_length_pair_kimura(ctx, orc):
     Q = andi_amd.Queries(ctx, [a, b])
     E = andi_amd.Esa(ctx, a)
     got = andi_amd.scan_rows(ctx, [E], [0], Q, andi_amd.M_KIMURA)
-    O = orc.OracleEsa(a, sa=E.SA)
+    O = _oracle_on_product_sa(orc, a, E)
     assert (got[0, 1] == O.dist_anchor(b, model=orc.M_KIMURA)).all()
     d = andi_amd.estimate(got[0, 1], andi_amd.M_KIMURA)
     assert abs(d - 0.0044) < 0.0004
@@ -130,7 +142,7 @@ def test_c5_index_of_1e8_characters(ctx, orc):
     got = andi_amd.scan_rows(ctx, [E], [0], Q)
     got2 = andi_amd.scan_rows(ctx, [E], [0], Q, segment=1 << 16)
     assert (got == got2).all()
-    O = orc.OracleEsa(a, sa=E.SA)
+    O = _oracle_on_product_sa(orc, a, E)
     assert O.threshold == E.threshold
     want = O.dist_anchor(b)
     assert (got[0, 1] == want).all()

@@ -1,0 +1,69 @@
+"""Pass A with one wavefront per chain (andi_amd/csrc/scan_coop.hip) against the oracle and against the lane scan
+(ANDI_COOP=0), through the C-ABI: 17 x u32 per ordered pair, bit-exact, for every window length."""
+import os
+
+import numpy as np
+import pytest
+
+import andi_amd
+from andi_amd import synth
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _matrix(seqs, model, coop, segment=0):
+    old = os.environ.get("ANDI_COOP")
+    os.environ["ANDI_COOP"] = str(coop)
+    try:
+        return andi_amd.dist_matrix(seqs, model=model, segment=segment)
+    finally:
+        if old is None:
+            del os.environ["ANDI_COOP"]
+        else:
+            os.environ["ANDI_COOP"] = old
+
+
+def _revcomp(b: bytes) -> bytes:
+    return bytes(b[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")))
+
+
+@pytest.mark.parametrize("coop", [2, 4, 8])
+def test_divergence_ladder(coop):
+    base = synth.base_codes(300000, 5)
+    seqs = [synth.to_bytes(synth.mutate_codes(base, d, 10 + k)) for k, d in enumerate((0.0, 0.0005, 0.005, 0.02, 0.05, 0.15))]
+    want = orc.dist_matrix(seqs, model=orc.M_JC, threads=4)
+    for segment in (0, 4096, 1000):
+        got = _matrix(seqs, andi_amd.M_JC, coop, segment)
+        assert (got == want).all(), "window of %d chunks, segment %d" % (coop, segment)
+
+
+def test_structured_genomes_equal_lane_scan_and_oracle():
+    seqs, _ = synth.realistic_set(5, 400000, 0.002, 0.04, seed=23)
+    want = orc.dist_matrix(seqs, model=orc.M_KIMURA, threads=5)
+    lane = _matrix(seqs, andi_amd.M_KIMURA, 0)
+    assert (lane == want).all()
+    for segment in (0, 8192, 700):
+        assert (_matrix(seqs, andi_amd.M_KIMURA, 4, segment) == want).all(), "segment %d" % segment
+
+
+def test_strands_contigs_edges():
+    base = synth.base_codes(120000, 9)
+    s = synth.to_bytes(base)
+    seqs = [s, _revcomp(synth.to_bytes(synth.mutate_codes(base, 0.02, 3))),  # reverse strand
+            _revcomp(s)[-40000:] + s[:40000],  # across the '#' of RS
+            synth.join_contigs(synth.to_bytes(synth.mutate_codes(base, 0.01, 4)), 9),  # '!' separators
+            s, synth.unrelated(90000, 77), s[:700]]  # identical, unrelated, short
+    want = orc.dist_matrix(seqs, model=orc.M_RAW, threads=4)
+    for coop in (2, 4):
+        for segment in (0, 2048, 300):
+            got = _matrix(seqs, andi_amd.M_RAW, coop, segment)
+            assert (got == want).all(), "window of %d chunks, segment %d: pairs %s" % (
+                coop, segment, np.argwhere((got != want).any(axis=2))[:8].tolist())
+
+
+def test_headline_pair_full_length():
+    """one pair at BASELINE's genome length, both directions, against the lane scan (itself pinned to the oracle)"""
+    seqs, _ = synth.genome_set(3, 4_900_000, 0.0004, 0.03, seed=1729)
+    lane = _matrix(seqs, andi_amd.M_JC, 0)
+    assert (_matrix(seqs, andi_amd.M_JC, 4) == lane).all()

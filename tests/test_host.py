@@ -115,3 +115,23 @@ def test_estimators_and_printer_match_oracle(orc):
     M3[1, 2, :16] = M3[2, 1, :16] = 0
     text3, warn3, flags3 = lib.format_distances(M3, names, lib.M_JC)
     assert "nan" in text3 and "reported as nan" in warn3 and flags3 & 1
+
+
+def test_suffix_array_verifier():
+    """tests/conftest.py: verify_suffix_array accepts the suffix array and nothing else (it is what lets the oracle run on the
+    product's device-built array at 2-50 Mbp and stay an independent check)."""
+    import numpy as np
+    from conftest import verify_suffix_array
+    from oracle import orc
+    rng = np.random.default_rng(5)
+    for text in (b"TGCAACGT#ACGTTGCA", rng.choice(np.frombuffer(b"ACGT", np.uint8), 5000).tobytes() + b"#" + b"A" * 300 + b";CCGT"):
+        sa = orc.suffix_array(text)
+        verify_suffix_array(text, sa)
+        bad = sa.copy()
+        bad[[3, 4]] = bad[[4, 3]]
+        with pytest.raises(AssertionError):
+            verify_suffix_array(text, bad)
+        dup = sa.copy()
+        dup[7] = dup[8]
+        with pytest.raises(AssertionError):
+            verify_suffix_array(text, dup)

@@ -8,11 +8,14 @@ from conftest import rand_dna
 pytestmark = pytest.mark.gpu
 
 
+_SA_MODE = None  # None: the subjects' suffix arrays by the host sorter; "device": built on the device (the seam's default)
+
+
 def _gpu_rows(ctx, seqs, subjects=None, model=1, segment=0, p_value=0.025):
     import andi_amd
     subjects = list(range(len(seqs))) if subjects is None else subjects
     Q = andi_amd.Queries(ctx, seqs)
-    esas = [andi_amd.Esa(ctx, seqs[i], p_value) for i in subjects]
+    esas = [andi_amd.Esa(ctx, seqs[i], p_value, sa=_SA_MODE) for i in subjects]
     out = andi_amd.scan_rows(ctx, esas, subjects, Q, model, segment)
     t = ctx.timings()
     for e in esas:
@@ -163,6 +166,17 @@ def test_repeats_and_models(ctx, orc):
     h = synth.to_bytes(synth.mutate_codes(codes, 0.02, 4))
     for model in (0, 1, 2, 3, 4):  # Raw, JC, Kimura; LogDet and ANI count anchors per nucleotide
         _check_set(ctx, orc, [g, h], segments=(0, 512), model=model)
+
+
+def test_edge_cases_on_device_built_suffix_arrays(ctx, orc, monkeypatch):
+    """The edge-case suite once more with the suffix arrays built on the device (sa_device.hip), as the one-call
+    seam stages its subjects: identical / unrelated / short sequences, joined contigs and reverse strands, repeats
+    under every model."""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "_SA_MODE", "device")
+    test_identical_unrelated_short(ctx, orc)
+    test_join_mode_and_revcomp(ctx, orc)
+    test_repeats_and_models(ctx, orc)
 
 
 def test_anchor_significance_parameter(ctx, orc):
