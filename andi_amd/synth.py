@@ -50,6 +50,47 @@ def genome_set(n, length, d_lo, d_hi, seed=1729):
     return [to_bytes(mutate_codes(b, float(ds[k]), seed + 1 + k)) for k in range(n)], [float(x) for x in ds]
 
 
+def tree_set(n, length, d_max=2.6e-2, d_min=4.4e-4, seed=1729):
+    """n genomes at the tips of a random ultrametric tree instead of a star: every pair is as far apart as twice the height
+    of its last common ancestor, so pairwise distances range from d_min (sister tips) to d_max (pairs that meet at the
+    root) -- the range the manual reports for the 29 E. coli/Shigella genomes (docs/manual/andi-manual.tex:316-320: 4.4e-4
+    ... 2.6e-2), where a star from a common base makes every pair about d_i + d_j.  Substitutions only, as genome_set.
+    Returns (list of bytes, n x n matrix of the expected pairwise distances)."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x7EE))
+    root = base_codes(length, seed)
+    seqs = [None] * n
+    height_of_lca = np.zeros((n, n))
+    counter = [0]
+
+    def grow(codes, h, tips):  # a node of height h (expected distance to each of its tips) carrying `codes`
+        for a in tips:
+            for b in tips:
+                if a != b and height_of_lca[a, b] == 0:
+                    height_of_lca[a, b] = h  # (overwritten by every lower common ancestor below)
+        if len(tips) == 1:
+            counter[0] += 1
+            seqs[tips[0]] = to_bytes(mutate_codes(codes, h, seed + 17 * counter[0]))
+            return
+        k = int(rng.integers(1, len(tips)))
+        for part in (tips[:k], tips[k:]):
+            # the child: a tip's branch is h long; an inner node lies lower, never below d_min / 2 (sister tips are d_min apart)
+            hc = 0.0 if len(part) == 1 else max(d_min / 2, h * float(rng.uniform(0.25, 0.85)))
+            counter[0] += 1
+            child = mutate_codes(codes, h - hc, seed + 17 * counter[0]) if len(part) > 1 else codes
+            if len(part) == 1:
+                grow(codes, h, part)
+            else:
+                for a in part:
+                    for b in part:
+                        height_of_lca[a, b] = 0.0
+                grow(child, hc, part)
+
+    order = [int(x) for x in rng.permutation(n)]
+    grow(root, d_max / 2, order)
+    np.fill_diagonal(height_of_lca, 0.0)
+    return seqs, 2.0 * height_of_lca
+
+
 def unrelated(length, seed):
     return to_bytes(base_codes(length, seed))
 

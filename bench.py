@@ -48,10 +48,13 @@ def parse():
     ap.add_argument("--dlo", type=float, default=0.0004)
     ap.add_argument("--dhi", type=float, default=0.03)
     ap.add_argument("--segment", type=int, default=0)
-    ap.add_argument("--set", choices=("star", "realistic"), default="star",
+    ap.add_argument("--set", choices=("star", "realistic", "tree"), default="star",
                     help="star: substitutions only (the reference's generator, test/test_fasta.cxx); realistic: repeats on "
-                         "both strands, indels, inversions, unrelated islands (andi_amd/synth.py: realistic_set)")
+                         "both strands, indels, inversions, unrelated islands (andi_amd/synth.py: realistic_set); tree: "
+                         "substitutions along a random tree, pairwise distances 4.4e-4 ... 2.6e-2 (tree_set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (structured genomes, tree-structured set)")
+    ap.add_argument("--seam-child", default="", help=argparse.SUPPRESS)  # internal: the multi-GPU seam in a process of its own
     ap.add_argument("--seed", type=int, default=1729)
     return ap.parse_args()
 
@@ -99,8 +102,95 @@ def cpu_baseline(seqs, p_value, model):
     }
 
 
+def make_set(kind, G, length, dlo, dhi, seed):
+    from andi_amd import synth
+    if kind == "realistic":
+        return synth.realistic_set(G, length, dlo, dhi, seed=seed)[0]
+    if kind == "tree":
+        return synth.tree_set(G, length, seed=seed)[0]
+    return synth.genome_set(G, length, dlo, dhi, seed=seed)[0]
+
+
+def workload_name(kind, G, S, length, dlo, dhi, seed, world):
+    """what the set really is: the C2 name only for C2's shape (29 genomes of 4.9 Mbp per GPU tile)"""
+    import andi_amd.shard as shard
+    c2 = length == 4_900_000 and G == shard.weak_scaling_set_size(world) and (kind != "star" or (dlo, dhi) == (0.0004, 0.03))
+    tag = {"star": "synth", "realistic": "realistic", "tree": "tree"}[kind]
+    what = {"star": "d~U[%g,%g] from a common base (star)" % (dlo, dhi),
+            "realistic": "d~U[%g,%g] from a common base, with repeats, indels, inversions, 10%% unrelated sequence" % (dlo, dhi),
+            "tree": "substitutions along a random tree, pairwise d 4.4e-4 ... 2.6e-2"}[kind]
+    return "%s: %d genomes x %d nt, %s, JC, seed %d; %s rows block-partitioned over %d GPU(s)" % (
+        ("C2-" + tag) if c2 else ("synthetic " + tag + " set"), G, length, what, seed,
+        "all" if S == G else "the first %d subject" % S, world)
+
+
+def secondary(kind, args, model, p_value):
+    """The same step on another kind of set (one GPU, after the headline's timed region): structured genomes and the
+    tree-structured variant, reported beside -- never instead of -- the star headline."""
+    import andi_amd
+    from andi_amd import lib
+    G, L = 29, args.length
+    seqs = make_set(kind, G, L, args.dlo, args.dhi, args.seed)
+    ctx = andi_amd.Context(0)
+    ctx.expect_queries(G - 1)
+    Q = andi_amd.Queries(ctx, seqs)
+    esas = [andi_amd.Esa(ctx, s, p_value, build=False, sa="device") for s in seqs]
+    M = ctx.alloc(G * G * 68)
+    selfs = list(range(G))
+
+    def step():
+        lib.build_indexes(ctx, esas)
+        lib.scan_rows_dev(ctx, esas, selfs, Q, model, args.segment, M)
+        ctx.sync()
+
+    step()
+    ctx.timings_reset()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    el = time.perf_counter() - t0
+    tm = ctx.timings()
+    scan_ms = tm["scan_ms"] / max(int(tm["scan_launches"]), 1)
+    alg = 2.0 * tm["scan_query_nt"] / max(int(tm["scan_launches"]), 1)
+    out = {"workload": workload_name(kind, G, G, L, args.dlo, args.dhi, args.seed, 1),
+           "pairs_per_s": G * (G - 1) / (el / steps), "ms_per_step": 1e3 * el / steps,
+           "roofline_frac": alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if scan_ms > 0 else None,
+           "index_build_ms": tm["build_ms"] / steps, "scan_cold_pass_ms": tm["scan_ms"] / steps,
+           "scan_stitch_reduce_ms": tm["stitch_ms"] / steps, "fixups_per_step": int(tm["fixups"]) // steps}
+    ctx.free(M)
+    for e in esas:
+        e.close()
+    Q.close()
+    ctx.close()
+    return out
+
+
+def seam_child(spec):
+    """--seam-child: the whole job through the product's one-call seam on all GPUs of the node -- andi_hip_dist_matrix with
+    num_gpus = N: a driver thread and a context per device, the RCCL gather of the row blocks behind the C-ABI -- in a
+    process of its own (the library loads ROCm's librccl, which must not meet the copy PyTorch carries)."""
+    import numpy as np
+    import andi_amd
+    from andi_amd import lib
+    kind, G, length, dlo, dhi, seed, gpus, path = spec.split(",")
+    seqs = make_set(kind, int(G), int(length), float(dlo), float(dhi), int(seed))
+    out = {"gpus_visible": lib.device_count()}
+    try:
+        t0 = time.time()
+        M = andi_amd.dist_matrix(seqs, model=andi_amd.M_JC, num_gpus=int(gpus))
+        out["seam_multi_gpu_s"] = time.time() - t0
+        out["gather"] = lib.last_gather()
+        np.save(path, M)
+    except Exception as e:  # the exact error string is the evidence
+        out["error"] = str(e)
+    print("SEAM " + json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.seam_child:
+        return seam_child(args.seam_child)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,10 +225,7 @@ def main():
     model = andi_amd.M_JC
     p_value = 0.025
     t_gen = time.time()
-    if args.set == "realistic":
-        seqs, ds = synth.realistic_set(G, args.length, args.dlo, args.dhi, seed=args.seed)
-    else:
-        seqs, ds = synth.genome_set(G, args.length, args.dlo, args.dhi, seed=args.seed)
+    seqs = make_set(args.set, G, args.length, args.dlo, args.dhi, args.seed)
     t_gen = time.time() - t_gen
 
     S = args.subjects if 0 < args.subjects <= G else G  # subject rows of the job
@@ -232,7 +319,8 @@ def main():
         copy_gbps = 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
-    scan_kernel = "k_lane_cold" if os.environ.get("ANDI_SCAN_G", "0") == "0" else "k_scan_cold"
+    scan_kernel = "k_scan_cold" if os.environ.get("ANDI_SCAN_G", "0") != "0" else (
+        "k_coop_cold" if os.environ.get("ANDI_COOP", "0") not in ("", "0") else "k_lane_cold")
     out = None
     if rank == 0:
         full = gathered[0] if use_dist else shard.gather_matrix(block, G, rows=S)
@@ -242,11 +330,7 @@ def main():
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C2-%s: %d genomes x %d nt, d~U[%g,%g] from a common base, JC, "
-                                   "seed %d; %s rows block-partitioned over %d GPU(s)"
-                                   % ("synth" if args.set == "star" else "realistic (repeats, indels, inversions, 10 %% unrelated)",
-                                      G, args.length, args.dlo, args.dhi, args.seed,
-                                      "all" if S == G else "the first %d subject" % S, world),
+            "config": {"workload": workload_name(args.set, G, S, args.length, args.dlo, args.dhi, args.seed, world),
                        "genomes": G, "subjects": S, "length": args.length, "model": "JC", "pairs": pairs_total,
                        "segment": args.segment or "auto (chosen per pair from its sampled match lengths: 2048 ... 16384 for this set)"},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -289,9 +373,34 @@ def main():
             "dist_matrix_e2e_s": e2e, "dist_matrix_pairs_per_s": pairs_total / e2e,
             "dist_matrix_e2e_s_suffix_arrays_on_host": e2e_host, "host_cores": os.cpu_count(),
             "dist_matrix_equals_step": bool((M1 == full).all() and (M2 == full).all())})
+    if rank == 0 and world > 1:
+        # the product's own multi-GPU path (api.hip: andi_hip_dist_matrix with num_gpus = N, RCCL gather behind the C-ABI) on
+        # the same set, in a child process, after the timed region; the other ranks wait at the barrier below
+        import subprocess
+        import tempfile
+        path = os.path.join(tempfile.gettempdir(), "andi_seam_%d.npy" % os.getpid())
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+               and not k.startswith("TORCHELASTIC") and not k.startswith("TORCH_NCCL")}
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        spec = ",".join(str(x) for x in (args.set, G, args.length, args.dlo, args.dhi, args.seed, world, path))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--seam-child", spec], env=env, cwd=ROOT,
+                               capture_output=True, text=True, timeout=900)
+            line = [l for l in r.stdout.splitlines() if l.startswith("SEAM ")]
+            res = json.loads(line[-1][5:]) if line else {"error": "no result; rc %d; %s" % (r.returncode, r.stderr[-600:])}
+            if os.path.exists(path):
+                res["equals_gathered_matrix"] = bool((np.load(path)[:S] == full).all())
+                os.remove(path)
+        except Exception as e:
+            res = {"error": repr(e)}
+        out["end_to_end"]["seam_multi_gpu"] = res
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and world == 1 and not args.no_extra and args.set == "star" and not args.subjects:
+        out["extra"] = {"realistic": secondary("realistic", args, model, p_value),
+                        "tree_structured": secondary("tree", args, model, p_value)}
     if rank == 0:
         print(json.dumps(out))
 

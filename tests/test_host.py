@@ -135,3 +135,19 @@ def test_suffix_array_verifier():
         dup[7] = dup[8]
         with pytest.raises(AssertionError):
             verify_suffix_array(text, dup)
+
+
+def test_tree_structured_generator():
+    """andi_amd/synth.py: tree_set -- the observed mismatch fractions follow the tree's pairwise distances, which span
+    d_min ... d_max (docs/manual/andi-manual.tex:316-320)."""
+    import math
+    import numpy as np
+    from andi_amd import synth
+    seqs, D = synth.tree_set(12, 300000, seed=3)
+    iu = np.triu_indices(12, 1)
+    assert abs(D[iu].max() - 2.6e-2) < 1e-9 and 4.4e-4 - 1e-9 <= D[iu].min() < 2.6e-3 and (D == D.T).all()
+    a = [np.frombuffer(x, np.uint8) for x in seqs]
+    for i, j in zip(*iu):
+        p = float((a[i] != a[j]).mean())
+        want = 0.75 - 0.75 * math.exp(-4.0 * D[i, j] / 3.0)
+        assert abs(p - want) < 0.15 * want + 1.5e-4, (i, j, p, want)

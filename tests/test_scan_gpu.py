@@ -179,6 +179,20 @@ def test_edge_cases_on_device_built_suffix_arrays(ctx, orc, monkeypatch):
     test_repeats_and_models(ctx, orc)
 
 
+def test_tree_structured_set(ctx, orc):
+    """Genomes at the tips of a tree (andi_amd/synth.py: tree_set): pairwise distances from 4.4e-4 to 2.6e-2 in one
+    matrix, as the manual reports for real E. coli sets (docs/manual/andi-manual.tex:316-320) -- pairs of very different
+    divergence share a call, every segment-length class and both pass A kernels are in use."""
+    import andi_amd
+    from andi_amd import synth
+    seqs, D = synth.tree_set(10, 150000, seed=77)
+    _check_set(ctx, orc, seqs, segments=(0, 2048))
+    got, _ = _gpu_rows(ctx, seqs)
+    for i, j in ((0, 1), (2, 7), (4, 9)):
+        d = andi_amd.estimate(np.minimum(got[i, j].astype(np.uint64) + got[j, i], 0xFFFFFFFF).astype(np.uint32), andi_amd.M_JC)
+        assert abs(d - D[i, j]) < 0.25 * D[i, j] + 2e-4, (i, j, d, D[i, j])
+
+
 def test_anchor_significance_parameter(ctx, orc):
     from andi_amd import synth
     a, b = synth.pair(80000, 0.05, seed=12)
