@@ -252,7 +252,9 @@ int andi_hip_device_count(void) {
 	return hipGetDeviceCount(&count) == hipSuccess && count > 0 ? count : 0;
 }
 
-int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errlen) {
+// high_priority: the context's streams are served before those of other contexts on the device (the staging stage of
+// andi_hip_dist_matrix: its short kernels must not queue behind the workgroups of a scan that fills the device)
+static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errlen, bool high_priority) {
 	if (!out) return 1;
 	*out = nullptr;
 	int count = 0;
@@ -274,8 +276,13 @@ int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t err
 	auto *ctx = new andi_hip_ctx;
 	ctx->device = device;
 	andi_arena::retain(device); // (released in andi_hip_ctx_destroy)
-	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking);
+	int prio = 0;
+	if (high_priority) {
+		int least = 0, greatest = 0;
+		if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) prio = greatest;
+	}
+	e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
+	if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming);
@@ -289,6 +296,10 @@ int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t err
 	}
 	*out = ctx;
 	return 0;
+}
+
+int andi_hip_ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errlen) {
+	return ctx_create(out, device, errbuf, errlen, false);
 }
 
 void andi_hip_ctx_expect_queries(andi_hip_ctx *ctx, size_t queries) {
@@ -612,20 +623,10 @@ int andi_hip_esa_download_index(andi_hip_ctx *ctx, const andi_hip_esa *e, uint32
 
 void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!e) return;
-	if (ctx) {
-		(void)hipSetDevice(ctx->device);
-		(void)hipStreamSynchronize(ctx->stream);
-	}
-	(void)andi_arena::dev_free(e->S);
-	(void)andi_arena::dev_free(e->SA);
-	(void)andi_arena::dev_free(e->LCP);
-	(void)andi_arena::dev_free(e->CLD);
-	(void)andi_arena::dev_free(e->FVC);
-	(void)andi_arena::dev_free(e->tab);
-	(void)andi_arena::dev_free(e->deep);
-	(void)andi_arena::dev_free(e->Nraw);
-	(void)andi_arena::dev_free(e->rec);
-	(void)andi_arena::dev_free(e->min_scratch);
+	if (ctx) (void)hipSetDevice(ctx->device);
+	(void)hipDeviceSynchronize(); // once for the handle's ten buffers: nothing in flight uses them when they are handed out again
+	void *bufs[] = {e->S, e->SA, e->LCP, e->CLD, e->FVC, e->tab, e->deep, e->Nraw, e->rec, e->min_scratch};
+	for (void *b : bufs) (void)andi_arena::dev_free(b, false);
 	if (e->h_flags) (void)hipHostFree(e->h_flags);
 	delete e;
 }
@@ -697,17 +698,11 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 
 void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q) {
 	if (!q) return;
-	if (ctx) {
-		(void)hipSetDevice(ctx->device);
-		(void)hipStreamSynchronize(ctx->stream);
-	}
-	(void)andi_arena::dev_free(q->pool);
-	(void)andi_arena::dev_free(q->nib);
+	if (ctx) (void)hipSetDevice(ctx->device);
+	(void)hipDeviceSynchronize();
+	void *bufs[] = {q->pool, q->nib, q->d_off, q->d_len, q->d_qseg_start, q->d_seg2query};
+	for (void *b : bufs) (void)andi_arena::dev_free(b, false);
 	if (q->h_foreign) (void)hipHostFree(q->h_foreign);
-	(void)andi_arena::dev_free(q->d_off);
-	(void)andi_arena::dev_free(q->d_len);
-	(void)andi_arena::dev_free(q->d_qseg_start);
-	(void)andi_arena::dev_free(q->d_seg2query);
 	delete q;
 }
 
@@ -1264,12 +1259,15 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		return p;
 	};
 
-	// ---- one driver per device
+	// ---- one driver per device.  Two stages, two contexts (streams) and two sets of subject slots per device: while the
+	// scan of one batch of subjects runs, a second thread stages the next -- upload, suffix arrays, index builds -- as
+	// the reference's threads build one subject's index while others scan (src/dist_hack.h:46-52).
 	struct Dev {
-		andi_hip_ctx *ctx = nullptr;
+		andi_hip_ctx *ctx = nullptr;  // scans, row copies
+		andi_hip_ctx *prep = nullptr; // uploads, suffix arrays, index builds
 		andi_hip_queries *Q = nullptr;
 		andi_hip_model *d_rows = nullptr; // rccl: the whole row block; direct: one batch of rows
-		std::vector<andi_hip_esa *> slots;
+		std::vector<andi_hip_esa *> slots; // sets x batch
 	};
 	std::vector<Dev> dv(ndev);
 
@@ -1279,19 +1277,21 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	auto drive = [&](size_t d) {
 		Dev &D = dv[d];
 		char eb[256] = "";
-		double t_last = now_ms(), acc_take = 0, acc_upload = 0, acc_sort = 0, acc_scan = 0, acc_copy = 0;
+		double t_last = now_ms(), acc_wait = 0, acc_scan = 0, acc_copy = 0;
 		auto lap = [&](double &acc) {
 			const double t = now_ms();
 			acc += t - t_last, t_last = t;
 		};
 		double t_ctx = 0, t_queries = 0, t_slots = 0;
-		auto bail = [&](const char *what) {
+		auto bail = [&](const char *what, andi_hip_ctx *cx) {
 			char msg[512];
-			snprintf(msg, sizeof msg, "%s (device %d): %s", what, devs[d], D.ctx ? andi_hip_last_error(D.ctx) : eb);
+			snprintf(msg, sizeof msg, "%s (device %d): %s", what, devs[d], cx ? andi_hip_last_error(cx) : eb);
 			fail_all(msg);
 		};
-		if (andi_hip_ctx_create(&D.ctx, devs[d], eb, sizeof eb)) return bail("creating a context");
+		if (andi_hip_ctx_create(&D.ctx, devs[d], eb, sizeof eb)) return bail("creating a context", nullptr);
+		if (ctx_create(&D.prep, devs[d], eb, sizeof eb, true)) return bail("creating a context", nullptr);
 		andi_hip_ctx_expect_queries(D.ctx, n - 1);
+		andi_hip_ctx_expect_queries(D.prep, n - 1);
 		lap(t_ctx);
 		const size_t rows = last[d] - first[d];
 		// Subject slots: device buffers sized for the longest genome, reused batch after batch (no
@@ -1302,63 +1302,128 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
 				const size_t per_slot = 10 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap, D.ctx->queries_hint))) + (1 << 20);
-				while (batch > 1 && batch * per_slot > free_b / (2 * ndev)) batch /= 2;
+				while (batch > 1 && 2 * batch * per_slot > free_b / (2 * ndev)) batch /= 2;
 			}
 		}
 		if (batch > rows) batch = rows;
-		D.slots.assign(batch, nullptr);
-		if (andi_hip_queries_stage(D.ctx, seqs, n, &D.Q)) return bail("staging queries");
+		const size_t nbatches = (rows + batch - 1) / batch;
+		const size_t sets = (nbatches > 1 && !o.low_memory) ? 2 : 1; // (low_memory: one index resident at a time)
+		D.slots.assign(sets * batch, nullptr);
+		if (andi_hip_queries_stage(D.ctx, seqs, n, &D.Q)) return bail("staging queries", D.ctx);
 		lap(t_queries);
-		for (size_t b = 0; b < batch; ++b)
-			if (esa_reserve(D.ctx, rs_cap, &D.slots[b])) return bail("allocating subject slots");
-		if (andi_hip_dev_alloc(D.ctx, (use_rccl ? rows : batch) * n * sizeof(andi_hip_model), (void **)&D.d_rows)) return bail("row buffer");
+		for (size_t b = 0; b < sets * batch; ++b)
+			if (esa_reserve(D.prep, rs_cap, &D.slots[b])) return bail("allocating subject slots", D.prep);
+		if (andi_hip_sync(D.prep)) return bail("allocating subject slots", D.prep);
+		if (andi_hip_dev_alloc(D.ctx, (use_rccl ? rows : batch) * n * sizeof(andi_hip_model), (void **)&D.d_rows)) return bail("row buffer", D.ctx);
 		lap(t_slots);
 
-		std::vector<int64_t> self(batch);
-		for (size_t i0 = first[d]; i0 < last[d]; i0 += batch) {
-			const size_t nb = std::min(batch, last[d] - i0);
-			for (size_t b = 0; b < nb; ++b) {
-				Prepared *p = take(i0 + b);
-				if (!p) return;
-				lap(acc_take);
-				bool ok = true;
-				if (p->rc) {
-					char msg[96];
-					snprintf(msg, sizeof msg, "Failed to create index for sequence %zu.", i0 + b); // src/dist_hack.h:53
-					fail_all(msg);
-					ok = false;
-				}
-				if (ok && esa_upload(D.ctx, D.slots[b], p->RS, o.sa_on_host ? p->SA.data() : nullptr, p->n, p->thr)) bail("staging subject"), ok = false;
-				lap(acc_upload);
-				if (ok && !o.sa_on_host && esa_sort_suffixes(D.ctx, D.slots[b])) bail("suffix array"), ok = false;
-				lap(acc_sort);
-				self[b] = (int64_t)(i0 + b);
-				andi_hip_free(p->RS);
-				delete p;
+		// hand-over between the two stages
+		std::mutex pm;
+		std::condition_variable pcv;
+		size_t prepared = 0, scanned = 0; // batches staged / scanned so far
+		bool prep_failed = false;
+		double p_take = 0, p_upload = 0, p_sort = 0, p_build = 0;
+
+		auto stage = [&]() { // the staging thread of this device
+			(void)hipSetDevice(devs[d]);
+			double tl = now_ms();
+			auto plap = [&](double &acc) {
+				const double t = now_ms();
+				acc += t - tl, tl = t;
+			};
+			auto give_up = [&]() {
+				std::lock_guard<std::mutex> lk(pm);
+				prep_failed = true;
+				pcv.notify_all();
+			};
+			for (size_t k = 0; k < nbatches; ++k) {
 				{
-					std::lock_guard<std::mutex> lk(mu);
-					++consumed;
+					std::unique_lock<std::mutex> lk(pm);
+					pcv.wait(lk, [&] { return k < scanned + sets || prep_failed; }); // its set of slots is free again
+					if (prep_failed) return;
 				}
-				cv.notify_all();
-				if (!ok) return;
+				tl = now_ms();
+				const size_t i0 = first[d] + k * batch, nb = std::min(batch, last[d] - i0);
+				andi_hip_esa **set = D.slots.data() + (k % sets) * batch;
+				for (size_t b = 0; b < nb; ++b) {
+					Prepared *p = take(i0 + b);
+					if (!p) return give_up();
+					plap(p_take);
+					bool ok = true;
+					if (p->rc) {
+						char msg[96];
+						snprintf(msg, sizeof msg, "Failed to create index for sequence %zu.", i0 + b); // src/dist_hack.h:53
+						fail_all(msg);
+						ok = false;
+					}
+					if (ok && esa_upload(D.prep, set[b], p->RS, o.sa_on_host ? p->SA.data() : nullptr, p->n, p->thr)) bail("staging subject", D.prep), ok = false;
+					plap(p_upload);
+					if (ok && !o.sa_on_host && esa_sort_suffixes(D.prep, set[b])) bail("suffix array", D.prep), ok = false;
+					plap(p_sort);
+					andi_hip_free(p->RS);
+					delete p;
+					{
+						std::lock_guard<std::mutex> lk(mu);
+						++consumed;
+					}
+					cv.notify_all();
+					if (!ok) return give_up();
+				}
+				if (andi_hip_esa_build_index_batch(D.prep, set, nb) || andi_hip_sync(D.prep)) {
+					bail("index build", D.prep);
+					return give_up();
+				}
+				plap(p_build);
+				{
+					std::lock_guard<std::mutex> lk(pm);
+					prepared = k + 1;
+				}
+				pcv.notify_all();
 			}
-			if (andi_hip_esa_build_index_batch(D.ctx, D.slots.data(), nb)) return bail("index build");
+		};
+		std::thread stager(stage);
+
+		std::vector<int64_t> self(batch);
+		bool failed = false;
+		t_last = now_ms();
+		for (size_t k = 0; k < nbatches && !failed; ++k) {
+			{
+				std::unique_lock<std::mutex> lk(pm);
+				pcv.wait(lk, [&] { return prepared > k || prep_failed; });
+				if (prepared <= k) break; // (the staging thread has reported why)
+			}
+			lap(acc_wait);
+			const size_t i0 = first[d] + k * batch, nb = std::min(batch, last[d] - i0);
+			andi_hip_esa **set = D.slots.data() + (k % sets) * batch;
+			for (size_t b = 0; b < nb; ++b) self[b] = (int64_t)(i0 + b);
 			andi_hip_model *dst = use_rccl ? D.d_rows + (i0 - first[d]) * n : D.d_rows;
-			if (andi_hip_scan_rows(D.ctx, D.slots.data(), self.data(), nb, D.Q, o.model, o.segment, dst)) return bail("scan");
-			if (trace) (void)andi_hip_sync(D.ctx);
+			if (andi_hip_scan_rows(D.ctx, set, self.data(), nb, D.Q, o.model, o.segment, dst)) bail("scan", D.ctx), failed = true;
+			if (!failed && trace) (void)andi_hip_sync(D.ctx);
 			lap(acc_scan);
-			if (!use_rccl && andi_hip_copy_to_host(D.ctx, M + i0 * n, dst, nb * n * sizeof(andi_hip_model))) return bail("row copy");
-			if (use_rccl && andi_hip_sync(D.ctx)) return bail("scan"); // the slots are reused by the next batch
+			if (!failed && !use_rccl && andi_hip_copy_to_host(D.ctx, M + i0 * n, dst, nb * n * sizeof(andi_hip_model))) bail("row copy", D.ctx), failed = true;
+			if (!failed && use_rccl && andi_hip_sync(D.ctx)) bail("scan", D.ctx), failed = true; // the slots are reused
 			lap(acc_copy);
-			if (o.progress) {
+			{
+				std::lock_guard<std::mutex> lk(pm);
+				scanned = k + 1;
+				if (failed) prep_failed = true;
+			}
+			pcv.notify_all();
+			if (!failed && o.progress) {
 				std::lock_guard<std::mutex> lk(mu);
 				rows_done += nb;
 				o.progress(rows_done * (n - 1), n * n - n, o.ud);
 			}
 		}
+		{
+			std::lock_guard<std::mutex> lk(pm);
+			if (scanned < nbatches) prep_failed = true; // (release the staging thread)
+		}
+		pcv.notify_all();
+		stager.join();
 		if (trace && d == 0)
-			fprintf(stderr, "andi_hip_dist_matrix trace (ms): context %.1f, queries %.1f, slots %.1f, waiting for the host pool %.1f, subject uploads %.1f, suffix arrays %.1f, index builds + scans %.1f, row copies %.1f; driver total %.1f\n",
-					t_ctx, t_queries, t_slots, acc_take, acc_upload, acc_sort, acc_scan, acc_copy, now_ms() - t_call);
+			fprintf(stderr, "andi_hip_dist_matrix trace (ms): contexts %.1f, queries %.1f, slots %.1f | staging thread: waiting for the host pool %.1f, subject uploads %.1f, suffix arrays %.1f, index builds %.1f | scan thread: waiting for staged subjects %.1f, scans %.1f, row copies %.1f; driver total %.1f (%zu batches of %zu, %zu slot sets)\n",
+					t_ctx, t_queries, t_slots, p_take, p_upload, p_sort, p_build, acc_wait, acc_scan, acc_copy, now_ms() - t_call, nbatches, batch, sets);
 	};
 
 	std::vector<std::thread> pool, drivers;
@@ -1447,11 +1512,15 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	if (rc) set_err(errbuf, errlen, "%s", first_error.empty() ? "andi_hip_dist_matrix failed" : first_error.c_str());
 
 	for (auto &D : dv) {
-		if (!D.ctx) continue;
+		if (!D.ctx) {
+			if (D.prep) andi_hip_ctx_destroy(D.prep);
+			continue;
+		}
 		for (auto *e : D.slots)
 			if (e) andi_hip_esa_free(D.ctx, e);
 		if (D.d_rows) andi_hip_dev_free(D.ctx, D.d_rows);
 		if (D.Q) andi_hip_queries_free(D.ctx, D.Q);
+		if (D.prep) andi_hip_ctx_destroy(D.prep);
 		andi_hip_ctx_destroy(D.ctx);
 	}
 	if (trace) fprintf(stderr, "andi_hip_dist_matrix trace: call total %.1f ms\n", now_ms() - t_call);

@@ -83,7 +83,8 @@ inline hipError_t dev_malloc(void **p, size_t bytes) {
 	return hipMalloc(p, bytes);
 }
 
-inline hipError_t dev_free(void *p) {
+// dev_free(p, false): the caller has waited for the device already (a handle's buffers are freed together: one wait, not ten)
+inline hipError_t dev_free(void *p, bool wait = true) {
 	if (!p) return hipSuccess;
 	int cur = 0;
 	(void)hipGetDevice(&cur);
@@ -97,9 +98,11 @@ inline hipError_t dev_free(void *p) {
 		const size_t len = it->second;
 		A.live.erase(it);
 		lock.unlock();
-		if (dev != cur) (void)hipSetDevice(dev);
-		(void)hipDeviceSynchronize(); // as hipFree: nothing in flight uses the block when it is handed out again
-		if (dev != cur) (void)hipSetDevice(cur);
+		if (wait) {
+			if (dev != cur) (void)hipSetDevice(dev);
+			(void)hipDeviceSynchronize(); // as hipFree: nothing in flight uses the block when it is handed out again
+			if (dev != cur) (void)hipSetDevice(cur);
+		}
 		lock.lock();
 		for (Chunk &c : A.chunks) {
 			if ((char *)p < c.base || (char *)p >= c.base + c.size) continue;
