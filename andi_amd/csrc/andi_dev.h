@@ -49,6 +49,7 @@ struct EsaDev {
 	int32_t thr;
 	int32_t deepK;
 	int32_t mode; // ANDI_MODE_*
+	int32_t deep_ext; // the entries of K-mers that occur once carry the nucleotides behind the occurrence (DEEP_SINGLE)
 };
 
 #define ANDI_MODE_PROBE 0     /* probe table + suffix-array search (true longest match) */
@@ -56,7 +57,7 @@ struct EsaDev {
 
 // probe-table entry: x = payload, y = kind | unique << 2 | l << 8
 #define DEEP_FINAL 0u  /* K-mer absent: match length l < K; x = SA index of the one suffix if unique */
-#define DEEP_SINGLE 1u /* K-mer occurs once: x = its position in RS; y >> 2 & 15 = v <= 13 nucleotides follow it, y >> 6 = their 2-bit codes (first in the low bits) */
+#define DEEP_SINGLE 1u /* K-mer occurs once: x = its position in RS; in the extended form (EsaDev.deep_ext) y >> 2 & 15 = v <= 13 nucleotides follow it, y >> 6 = their 2-bit codes (first in the low bits) */
 #define DEEP_MULTI 2u  /* K-mer occurs more than once: x = first SA index, y >> 8 = run length - 1 */
 #define DEEP_SEARCH 3u /* (run too long to encode) search the whole suffix array */
 
@@ -75,7 +76,7 @@ struct EsaG {
 	g_i4p tab;
 	g_u2p deep;
 	g_u8p N0, N1;
-	int32_t n, thr, deepK, mode;
+	int32_t n, thr, deepK, mode, deep_ext;
 };
 
 __device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
@@ -84,7 +85,7 @@ __device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
 	g.FVC = (g_u8p)e.FVC, g.tab = (g_i4p)e.tab;
 	g.deep = (g_u2p)e.deep;
 	g.N0 = (g_u8p)e.N0, g.N1 = (g_u8p)e.N1;
-	g.n = e.n, g.thr = e.thr, g.deepK = e.deepK, g.mode = e.mode;
+	g.n = e.n, g.thr = e.thr, g.deepK = e.deepK, g.mode = e.mode, g.deep_ext = e.deep_ext;
 	return g;
 }
 

@@ -99,6 +99,7 @@ struct andi_hip_esa {
 	size_t ref_cap = 0; // same for the reference arrays
 	bool ref_built = false;   // LCP, CLD, FVC, tab valid
 	bool index_built = false; // deep, flags valid
+	bool deep_ext = false;    // the table's entries of K-mers that occur once are in the extended form
 	size_t bytes = 0;
 };
 
@@ -195,7 +196,7 @@ EsaDev esa_view(const andi_hip_esa *e, int mode) {
 	v.S = e->S, v.SA = e->SA, v.LCP = e->LCP, v.CLD = e->CLD, v.FVC = e->FVC, v.tab = e->tab;
 	v.deep = e->deep, v.flags = e->flags;
 	v.N0 = e->N0, v.N1 = e->N1;
-	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.mode = mode;
+	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.mode = mode, v.deep_ext = e->deep_ext ? 1 : 0;
 	return v;
 }
 
@@ -539,7 +540,7 @@ int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	hipError_t err = andi_launch_index_build(build_args(e), ctx->stream);
 	t.stop();
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index", err);
-	e->index_built = true;
+	e->index_built = true, e->deep_ext = andi_index_single_ext() != 0;
 	return 0;
 }
 
@@ -581,7 +582,7 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 	if (err == hipSuccess) err = andi_launch_index_build_batch((const AndiIndexBatchItem *)ctx->ib_dev, (uint32_t)count, max_n, ctx->stream);
 	t.stop();
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index_batch", err);
-	for (size_t k = 0; k < count; ++k) esas[k]->index_built = true;
+	for (size_t k = 0; k < count; ++k) esas[k]->index_built = true, esas[k]->deep_ext = andi_index_single_ext() != 0;
 	return 0;
 }
 

@@ -40,6 +40,8 @@ struct AndiIndexBatchItem {
 };
 
 size_t andi_min_tree_entries(int32_t n);
+// 1: the index builds launched now write the extended entries of K-mers that occur once (andi_dev.h: DEEP_SINGLE)
+int andi_index_single_ext(void);
 // the scan indexes of `count` subjects (device array of items) in two launches; max_n = the longest text
 hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, hipStream_t st);
 // (scan_lane.hip) packed symbols of the items' texts, `bytes` source bytes each at most (shorter texts stop at their own end)

@@ -31,7 +31,10 @@
 
 namespace {
 
-constexpr uint32_t COOP_HCAP = 128; // heads of a window that are walked (more: the window ends at the first one dropped)
+#define COOP_HCAP (32u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
+constexpr int COOP_WAVES = 2; // wavefronts per block: each has a window's worth of LDS, small blocks fill a CU more evenly
+constexpr uint32_t COOP_KCAP = 32; // stretches of a window that are counted nowhere (more: the window ends before the next one)
+constexpr uint32_t COOP_PARK = 16; // parked lanes (their probe needs lane_probe) that are served together
 constexpr uint32_t COOP_MAX_X = 3;  // anchors off the window's diagonal a walk follows before it gives up
 constexpr uint32_t NOPOS = 0xffffffffu;
 
@@ -42,11 +45,23 @@ __device__ unsigned long long g_coop_stats[24];
 	do {                                                                         \
 		if (__lane_id() == 0) atomicAdd(&g_coop_stats[k], (unsigned long long)(v)); \
 	} while (0)
+// wave-cycles (s_memtime) spent per phase: TICK(t) starts the clock, TOCK(t, phase) charges the time since to `phase`
+__device__ unsigned long long g_coop_cycles[8];
+#define TICK(t) unsigned long long t = __builtin_readcyclecounter()
+#define TOCK(t, ph)                                                                        \
+	do {                                                                                   \
+		const unsigned long long now_ = __builtin_readcyclecounter();                      \
+		if (__lane_id() == 0) atomicAdd(&g_coop_cycles[ph], now_ - t);                     \
+		t = now_;                                                                          \
+	} while (0)
 #else
 #define CSTAT(k, v) ((void)0)
+#define TICK(t) ((void)0)
+#define TOCK(t, ph) ((void)0)
 #endif
+enum { PH_G, PH_STREAM, PH_HEADS, PH_WALKS, PH_HOPS, PH_STRETCH, PH_FINAL };
 enum { CS_SEGMENTS, CS_G_STEPS, CS_BLOCKS, CS_LCP, CS_WINDOWS, CS_MOVED, CS_HEADS, CS_TRIPS, CS_LANE_STEPS, CS_PROBES, CS_ONPATH,
-	   CS_HOPS, CS_G_GAPS, CS_COVERED, CS_DROPPED, CS_X, CS_LCP_ROUNDS, CS_NODES };
+	   CS_HOPS, CS_G_GAPS, CS_COVERED, CS_DROPPED, CS_X, CS_LCP_ROUNDS, CS_NODES, CS_SERVICE, CS_SERVICE_LANES, CS_WHY_PRE, CS_WHY_MULTI, CS_WHY_LONG, CS_WHY_OTHER };
 
 // how a head's walk ended
 enum : uint32_t { W_OK = 1, W_OPEN = 2, W_EXIT = 3, W_BREAK = 4, W_STATUS = 7u, W_HADX = 8u, W_LUCKY = 16u, W_NX_SHIFT = 8, W_ONPATH = 1u << 16 };
@@ -54,12 +69,14 @@ enum : uint32_t { W_OK = 1, W_OPEN = 2, W_EXIT = 3, W_BREAK = 4, W_STATUS = 7u, 
 template <int NCH>
 struct CoopLds {
 	uint32_t mbits[64 * NCH + 4]; // mismatch bits of the window, bit (x - wbase); the words behind it stay 0: nothing known there
-	uint32_t ebits[64 * NCH];     // positions counted as the gap behind a head: [head, landing)
-	uint32_t kbits[64 * NCH];     // the same stretch of a head whose walk met anchors off the diagonal: counted nowhere
+	uint32_t ebits[64 * NCH];     // the stretches behind the heads the chain came by, [head, landing): counted as gaps -- except
+	uint32_t kpos[COOP_KCAP];     // those that start at one of these positions (the walk met anchors off the diagonal): counted nowhere
+	uint32_t nhadx;               // walks of the window that ended that way (at most COOP_KCAP: the others give up)
 	uint32_t ha[COOP_HCAP];       // landing position of the head's walk
 	uint32_t hlen[COOP_HCAP];     // length of the anchor there (W_LUCKY: not known yet)
 	uint32_t hflag[COOP_HCAP];
 	uint16_t hpos[COOP_HCAP];     // the head's position - wbase
+	uint32_t q2[128 * NCH + 4];   // the window's query symbols as 2-bit codes, 16 per word, symbol k of a word at bits 2k, 2k + 1
 	uint32_t pl[64], pp[64];      // the block of probes of mode G: length | unique << 31, position
 	uint32_t hist[16];
 };
@@ -136,7 +153,7 @@ __device__ __forceinline__ uint32_t coop_lcp(const PairCtx &c, uint32_t p, uint3
 		if (hit) {
 			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
 			const uint32_t fl = (uint32_t)__shfl((int)f, (int)l);
-			const uint32_t len = pe + base + WNT * l + fl - p;
+			const uint32_t len = uni(pe + base + WNT * l + fl - p);
 			return len < maxlen ? len : maxlen;
 		}
 		if (base + 64 * WNT - skip >= maxlen) return maxlen;
@@ -183,7 +200,7 @@ __device__ __forceinline__ uint32_t coop_next_mismatch(const CoopLds<NCH> &L, ui
 		if (hit) {
 			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
 			const uint32_t vl = (uint32_t)__shfl((int)v, (int)l);
-			return wbase + 32 * (w0 + l) + (uint32_t)__builtin_ctz(vl);
+			return uni(wbase + 32 * (w0 + l) + (uint32_t)__builtin_ctz(vl));
 		}
 	}
 	return NOPOS;
@@ -203,10 +220,125 @@ __device__ __forceinline__ uint32_t coop_prev_mismatch(const CoopLds<NCH> &L, ui
 		if (hit) {
 			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
 			const uint32_t vl = (uint32_t)__shfl((int)v, (int)l);
-			return wbase + 32 * (uint32_t)(w0 - (int32_t)l) + 31u - (uint32_t)__builtin_clz(vl);
+			return uni(wbase + 32 * (uint32_t)(w0 - (int32_t)l) + 31u - (uint32_t)__builtin_clz(vl));
 		}
 	}
 	return NOPOS;
+}
+
+// 8 nibbles -> 8 x 2 bits, first symbol in the low bits (the symbols must be nucleotides)
+__device__ __forceinline__ uint32_t squeeze_codes(uint32_t x) {
+	x &= 0x33333333u;
+	x = (x | (x >> 2)) & 0x0f0f0f0fu;
+	x = (x | (x >> 4)) & 0x00ff00ffu;
+	return (x | (x >> 8)) & 0x0000ffffu;
+}
+
+// anchor() (src/process.c:113-123) for a walk's position p inside the window, the part that ONE dependent load
+// answers: the K-mer and the symbols behind it come from the window's 2-bit codes in LDS (no load of the query), the
+// table's entry settles an absent K-mer, and one that occurs once unless the match is longer than the 13 nucleotides
+// its extended entry carries.  Returns false for everything else -- K-mers with several occurrences, long matches,
+// windows with separators: the lane then waits until enough lanes of its wavefront need lane_probe, and they take it
+// together (a path one lane in ten takes is otherwise executed on nine trips in ten).
+// (on_diag: the K-mer occurs once, at p + dg -- on the window's diagonal: the match is the run of equal symbols the bits show)
+// (multi_x, multi_n, multi_q: the K-mer occurs multi_n <= 4 times, at SA[multi_x ...]; multi_q = the 16 symbols behind it)
+template <int NCH>
+__device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<NCH> &L, uint32_t wbase, bool clean, uint32_t p, int64_t dg, Probe &r, bool &on_diag,
+												uint32_t &multi_x, uint32_t &multi_n, uint32_t &multi_q) {
+	on_diag = false, multi_n = 0;
+	const EsaG &E = c.E;
+	const uint32_t K = (uint32_t)E.deepK, qrem = c.qlen - p, o = p - wbase;
+#ifdef ANDI_COOP_STATS
+#define WHY(k) atomicAdd(&g_coop_stats[k], 1ull)
+#else
+#define WHY(k) ((void)0)
+#endif
+	if (!(clean && E.deep_ext && o + 32 <= 2048 * NCH && p + 32 <= c.qlen)) {
+		WHY(CS_WHY_PRE);
+		return false;
+	}
+	const uint32_t j = o >> 4, sh = 2 * (o & 15u);
+	const uint32_t w0 = L.q2[j], w1 = L.q2[j + 1], w2 = L.q2[j + 2];
+	const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+	uint32_t y = __brev(lo); // first symbol on top, the bits of a pair swapped
+	y = ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
+	const uint32_t code = y >> (32 - 2 * K);
+	const uint32_t behind = (uint32_t)((((uint64_t)hi << 32) | lo) >> (2 * K)); // the 16 symbols behind the K-mer
+	const uint64_t raw = ld_u64_unaligned((g_u8p)(E.deep + code));
+	const uint32_t x = (uint32_t)raw, ty = (uint32_t)(raw >> 32), kind = ty & 3u;
+	if (kind == DEEP_FINAL) {
+		r.len = ty >> 8, r.unique = (ty >> 2) & 1u, r.pos = 0;
+		return !(r.unique && r.len >= (uint32_t)E.thr); // (only texts so short that K >= thr: the position is one more load)
+	}
+	if (kind != DEEP_SINGLE) {
+		if (kind == DEEP_MULTI) WHY(CS_WHY_MULTI); else WHY(CS_WHY_OTHER);
+		if (kind == DEEP_MULTI && (ty >> 8) < 4) multi_x = x, multi_n = (ty >> 8) + 1, multi_q = behind;
+		return false;
+	}
+	if ((int64_t)x == (int64_t)p + dg) {
+		on_diag = true;
+		return true;
+	}
+	const uint32_t nval = (ty >> 2) & 15u, ext = ty >> 6;
+	const uint32_t diff = (behind ^ ext) & 0x03ffffffu;
+	const uint32_t m = diff ? (uint32_t)__builtin_ctz(diff) >> 1 : 16u; // first differing nucleotide
+	const uint32_t lim = nval < qrem - K ? nval : qrem - K;
+	r.unique = true, r.pos = x;
+	if (m < lim) {
+		r.len = K + m; // settled by the entry
+	} else if (K + lim >= qrem) {
+		r.len = qrem; // the query ends inside the match
+	} else if (lim == nval && nval < 13) {
+		r.len = K + lim; // the text has a separator (or its end) there, the query a nucleotide
+	} else {
+		WHY(CS_WHY_LONG);
+		return false; // all that could be compared matches: the occurrence has to be followed
+	}
+	return true;
+}
+
+// The probe of a parked lane whose K-mer occurs n <= 4 times (at SA[x ...]): the longest match is the best of the
+// occurrences' own matches, unique iff one attains it (as lane_probe).  The occurrence on the window's diagonal, if
+// there is one, is the run of equal symbols the bits show (*diag_run; *diag_seen: a mismatch of the window ends it);
+// the others are compared 16 symbols deep, two per round trip.  false: a match goes deeper than that -- lane_probe's.
+__device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, int64_t dg, uint32_t x, uint32_t n, uint32_t behind,
+												 uint32_t diag_run, bool diag_seen, Probe &r, bool &on_diag_long) {
+	const EsaG &E = c.E;
+	const uint32_t K = (uint32_t)E.deepK, qrem = c.qlen - p;
+	const uint4 pos4 = ld_u128_unaligned((g_u8p)(E.SA + x)); // (SA is padded by eight entries)
+	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
+	bool deep = false;
+	on_diag_long = false;
+	for (uint32_t i = 0; i < n; i += 2) { // two occurrences per round trip
+		const uint32_t pa = i == 0 ? pos4.x : pos4.z, pb = i == 0 ? pos4.y : pos4.w;
+		const uint4 sa = ld_subject(c, (int32_t)(pa + K));
+		uint4 sb = sa;
+		if (i + 1 < n) sb = ld_subject(c, (int32_t)(pb + K));
+		for (uint32_t h = 0; h < 2 && i + h < n; ++h) {
+			const uint4 sv = h ? sb : sa;
+			const uint32_t ps = h ? pb : pa;
+			uint32_t len;
+			if ((int64_t)ps == (int64_t)p + dg) { // the diagonal's occurrence
+				len = diag_run;
+				if (!diag_seen) len = 0x40000000u, on_diag_long = true; // (longer than anything 16 symbols can show)
+			} else {
+				const uint32_t bad_lo = sv.x & 0x44444444u, bad_hi = sv.y & 0x44444444u; // separators, the text's end
+				const uint32_t stop = bad_lo ? (uint32_t)__builtin_ctz(bad_lo) >> 2 : (bad_hi ? 8u + ((uint32_t)__builtin_ctz(bad_hi) >> 2) : 16u);
+				const uint32_t diff = behind ^ (squeeze_codes(sv.x) | (squeeze_codes(sv.y) << 16));
+				uint32_t m = diff ? (uint32_t)__builtin_ctz(diff) >> 1 : 16u;
+				if (stop < m) m = stop;
+				if (m >= 16 && K + 16 < qrem) deep = true;
+				len = K + m;
+				if (len > qrem) len = qrem;
+			}
+			if (len > bestLen)
+				bestLen = len, bestCnt = 1, bestPos = ps;
+			else if (len == bestLen)
+				++bestCnt;
+		}
+	}
+	r.len = bestLen, r.unique = bestCnt == 1, r.pos = bestPos;
+	return !deep;
 }
 
 // the record of an anchor (scan.h: the cold chain's first anchor, the state and counts right after its second)
@@ -260,27 +392,38 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	const uint32_t wbase = e0 & ~31u;
 	constexpr uint32_t W = 2048 * NCH;
 
-	// ---- the bits: position x of the window against subject position x + dg
-#pragma unroll
+	TICK(tph);
+	// ---- the bits: position x of the window against subject position x + dg; the query's symbols as 2-bit codes
+	uint32_t dirty = 0; // a query symbol of the window that is no nucleotide ('!' of joined contigs): the walks then read the query itself
+#pragma unroll 2
 	for (int ck = 0; ck < NCH; ++ck) {
 		const uint32_t x0 = wbase + 2048 * ck + WNT * lane;
 		uint32_t m = ~0u; // positions at and beyond the query's end: lcp() stops there
+		uint2 codes = make_uint2(0, 0);
 		if (x0 < c.qlen) {
-			m = squeeze32(neq32(ld_query(c, x0), ld_subject_guarded(c, (int64_t)x0 + dg)));
-			if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0);
+			const uint4 qv = ld_query(c, x0);
+			m = squeeze32(neq32(qv, ld_subject_guarded(c, (int64_t)x0 + dg)));
+			codes = make_uint2(squeeze_codes(qv.x) | (squeeze_codes(qv.y) << 16), squeeze_codes(qv.z) | (squeeze_codes(qv.w) << 16));
+			uint32_t bad = squeeze32(make_uint4(qv.x << 1, qv.y << 1, qv.z << 1, qv.w << 1)); // bit 2 of a symbol: no nucleotide
+			if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0), bad &= ~(~0u << (c.qlen - x0));
+			dirty |= bad;
 		}
 		if (x0 <= e0 && e0 - x0 < WNT) m &= ~0u << (e0 - x0); // (what lies before the anchor is none of the window's business)
 		if (x0 + WNT <= e0) m = 0;
-		L.mbits[64 * ck + lane] = m, L.ebits[64 * ck + lane] = 0, L.kbits[64 * ck + lane] = 0;
+		L.mbits[64 * ck + lane] = m;
+		*(uint2 *)&L.q2[2 * (64 * ck + lane)] = codes;
 	}
+	const bool clean = !__any(dirty != 0);
+	if (lane < 4) L.q2[128 * NCH + lane] = 0;
+	if (lane == 0) L.nhadx = 0;
 	if (lane < 4) L.mbits[64 * NCH + lane] = 0;
 	wave_sync();
 
+	TOCK(tph, PH_STREAM);
 	// ---- heads: a mismatch with fewer than thr equal symbols behind it and at least thr before it.  Lane l looks
 	// at the NCH words of positions 32 NCH l ...; a word together with its neighbours, thr < 32
-	uint32_t hmask[NCH], nh = 0;
-#pragma unroll
-	for (int j = 0; j < NCH; ++j) {
+	uint32_t nh = 0;
+	for (uint32_t j = 0; j < (uint32_t)NCH; ++j) {
 		const uint32_t w = NCH * lane + j;
 		const uint32_t cur = L.mbits[w], nxt = L.mbits[w + 1], prv = w ? L.mbits[w - 1] : 0u;
 		// a mismatch among the next thr positions / among the thr positions before: smear the bits over thr - 1 more
@@ -294,8 +437,9 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		const uint32_t x0 = wbase + 32 * w;
 		if (x0 + 1 >= end) live = 0;
 		else if (end - 1 - x0 < 32) live = (1u << (end - 1 - x0)) - 1u;
-		hmask[j] = cur & soon & ~before & live;
-		nh += (uint32_t)__builtin_popcount(hmask[j]);
+		const uint32_t hm = cur & soon & ~before & live;
+		L.ebits[w] = hm; // (parked there: the stretches are set much later, and the words are cleared below)
+		nh += (uint32_t)__builtin_popcount(hm);
 	}
 	uint32_t hbase = nh; // exclusive prefix sum over the lanes
 #pragma unroll
@@ -306,16 +450,19 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	const uint32_t nheads_all = uni((uint32_t)__shfl((int)hbase, 63));
 	hbase -= nh;
 	uint32_t dropped = NOPOS; // the first head beyond the list's capacity: nothing is decided from there on
-#pragma unroll
-	for (int j = 0; j < NCH; ++j)
-		for (uint32_t hm = hmask[j]; hm; hm &= hm - 1) {
-			const uint32_t off = 32 * (NCH * lane + j) + (uint32_t)__builtin_ctz(hm);
+	for (uint32_t j = 0; j < (uint32_t)NCH; ++j) {
+		const uint32_t w = NCH * lane + j;
+		uint32_t hm = L.ebits[w];
+		L.ebits[w] = 0;
+		for (; hm; hm &= hm - 1) {
+			const uint32_t off = 32 * w + (uint32_t)__builtin_ctz(hm);
 			if (hbase < COOP_HCAP)
 				L.hpos[hbase] = (uint16_t)off;
 			else if (dropped == NOPOS)
 				dropped = wbase + off;
 			++hbase;
 		}
+	}
 	const uint32_t nheads = nheads_all < COOP_HCAP ? nheads_all : COOP_HCAP;
 	CSTAT(CS_WINDOWS, 1);
 	CSTAT(CS_HEADS, nheads);
@@ -323,48 +470,82 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	const uint32_t f_cap = nheads_all > COOP_HCAP ? uni(wave_min(dropped)) : NOPOS;
 	wave_sync();
 
-	// ---- the walks, one lane each; a lane that is done takes the next head
+	TOCK(tph, PH_HEADS);
+	// ---- the walks, one lane each; a lane that is done takes the next head.  A lane whose probe needs more than the
+	// table's entry is parked; the parked lanes take lane_probe together once there are enough of them (or nothing else
+	// is left to do).
 	{
 		uint32_t hk = NOPOS, e = 0, p = 0, Xq = 0, Xs = 0, Xl = 0, nX = 0, next_head = 0;
+		uint32_t mx = 0, mn = 0, mq = 0; // a parked lane's K-mer, if it occurs a few times: first suffix-array index, occurrences, the 16 symbols behind it
+		bool parked = false;
+		// equal symbols from p on along the diagonal as far as 32 bits of the window show; seen: a mismatch of the window ends them
+		auto run_ahead = [&](uint32_t pp, bool &seen) {
+			const uint32_t o = pp - wbase, wi = o >> 5;
+			const uint32_t lo = L.mbits[wi], hi = L.mbits[wi + 1];
+			const uint32_t v = (o & 31u) ? (lo >> (o & 31u)) | (hi << (32u - (o & 31u))) : lo;
+			const uint32_t r = v ? (uint32_t)__builtin_ctz(v) : 32u;
+			seen = v != 0 && o + r < W;
+			return r;
+		};
 		LWin w;
 		w.q0 = EMPTY, w.dg = NO_DIAG;
 		for (;;) {
 			const uint64_t idle = __ballot(hk == NOPOS);
 			if (idle && next_head < nheads) {
 				const uint32_t my = next_head + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-				if (hk == NOPOS && my < nheads) hk = my, e = wbase + L.hpos[my], p = e + 1, Xl = 0, nX = 0;
+				if (hk == NOPOS && my < nheads) hk = my, e = wbase + L.hpos[my], p = e + 1, Xl = 0, nX = 0, parked = false;
 				next_head += (uint32_t)__builtin_popcountll(idle);
 			}
-			if (!__any(hk != NOPOS)) break;
+			const uint64_t busy = __ballot(hk != NOPOS), waiting = __ballot(hk != NOPOS && parked);
+			if (!busy) break;
+			// the parked lanes' turn?
+			const bool service = waiting && ((uint32_t)__builtin_popcountll(waiting) >= COOP_PARK || waiting == busy);
 #ifdef ANDI_COOP_STATS
-			{
-				const uint64_t on = __ballot(hk != NOPOS);
-				if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
-					atomicAdd(&g_coop_stats[CS_TRIPS], 1ull);
-					atomicAdd(&g_coop_stats[CS_LANE_STEPS], (unsigned long long)__builtin_popcountll(on));
-				}
+			if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
+				atomicAdd(&g_coop_stats[service ? CS_SERVICE : CS_TRIPS], 1ull);
+				atomicAdd(&g_coop_stats[service ? CS_SERVICE_LANES : CS_LANE_STEPS], (unsigned long long)__builtin_popcountll(service ? waiting : busy & ~waiting));
 			}
 #endif
-			if (hk == NOPOS) continue;
+			if (hk == NOPOS || parked != service) continue;
 			uint32_t res = 0, ra = 0, rlen = 0;
-			if (p >= end) {
+			Probe pr;
+			pr.len = 0, pr.pos = 0, pr.unique = false;
+			bool have = false; // pr is the answer for p
+			if (service) {
+				bool long_diag = false;
+				if (mn) {
+					bool seen;
+					const uint32_t r = run_ahead(p, seen);
+					have = coop_probe_multi(c, p, dg, mx, mn, mq, r, seen, pr, long_diag);
+				}
+				if (!have) pr = lane_probe(c, p, w), long_diag = false;
+				have = true, parked = false;
+#ifdef ANDI_COOP_STATS
+				atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
+#endif
+				if (long_diag && pr.unique) { // the diagonal's occurrence is the longest, longer than the bits at hand show
+					if (wbase + W - p >= 32) {
+						const bool same_side = ((int64_t)p + dg < (int64_t)c.border) == ((int64_t)e + dg <= (int64_t)c.border);
+						res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
+						ra = p;
+					} else {
+						pr = lane_probe(c, p, w); // (the window's end)
+					}
+				}
+			} else if (p >= end) {
 				res = Xl ? W_BREAK : W_EXIT;
 			} else if (p - wbase >= W) {
 				res = Xl ? W_BREAK : W_OPEN; // the walk has left the window
 			} else if (Xl == 0) {
 				if ((int64_t)p + dg < (int64_t)n && p - e <= thr) { // lucky_anchor applies on the diagonal: the bits answer
-					const uint32_t o = p - wbase, wi = o >> 5;
-					{
-						const uint32_t lo = L.mbits[wi], hi = L.mbits[wi + 1];
-						const uint32_t v = (o & 31u) ? (lo >> (o & 31u)) | (hi << (32u - (o & 31u))) : lo;
-						const uint32_t r = v ? (uint32_t)__builtin_ctz(v) : 32u; // equal symbols from p on, as far as 32 bits show
-						if (o + r < W) { // a mismatch of the window ends the run (r < 32: thr < 32)
-							if (r >= thr) res = W_OK | W_LUCKY, ra = p;
-						} else if (W - o >= thr) { // thr equal symbols and more: an anchor; where it ends is settled later
-							res = W_OK | W_LUCKY, ra = p;
-						} else {
-							res = W_OPEN;
-						}
+					bool seen;
+					const uint32_t r = run_ahead(p, seen);
+					if (seen) { // a mismatch of the window ends the run (r < 32: thr < 32)
+						if (r >= thr) res = W_OK | W_LUCKY, ra = p;
+					} else if (wbase + W - p >= thr) { // thr equal symbols and more: an anchor; where it ends is settled later
+						res = W_OK | W_LUCKY, ra = p;
+					} else {
+						res = W_OPEN;
 					}
 				}
 			} else { // lucky_anchor on the diagonal of the anchor off the window's: compare
@@ -377,11 +558,29 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 					if (l >= thr) res = W_BREAK; // the chain really changes its diagonal: not this window's business
 				}
 			}
-			if (!res) {
-				const Probe pr = lane_probe(c, p, w);
+			if (!res && !have) {
+				bool on_diag;
+				have = coop_probe_fast<NCH>(c, L, wbase, clean, p, dg, pr, on_diag, mx, mn, mq);
+				if (!have) parked = true; // (the lucky attempt above has failed or does not apply: it is not repeated)
+				if (on_diag) { // the K-mer's one occurrence is the diagonal's: the bits know the match
+					bool seen;
+					const uint32_t r = run_ahead(p, seen);
+					pr.unique = true, pr.pos = (uint32_t)((int64_t)p + dg), pr.len = r;
+					if (!seen) { // longer than the bits at hand show: an anchor (thr < 32) whose end is settled later -- if 32 bits were at hand
+						if (wbase + W - p >= 32) {
+							const bool same_side = ((int64_t)p + dg < (int64_t)c.border) == ((int64_t)e + dg <= (int64_t)c.border);
+							res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
+							ra = p;
+						} else {
+							have = false, parked = true; // (the window's end: lane_probe follows the occurrence)
+						}
+					}
+				}
 #ifdef ANDI_COOP_STATS
-				atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
+				if (have) atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
 #endif
+			}
+			if (!res && have) {
 				if (pr.unique && pr.len >= thr) {
 					if ((int64_t)pr.pos == (int64_t)p + dg) { // on the diagonal
 						// a right anchor of the anchor before the head only on the same strand (src/process.c:162)
@@ -404,6 +603,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			}
 			if (res) {
 				if ((res & W_LUCKY) && ((int64_t)ra + dg < (int64_t)c.border) != ((int64_t)e + dg <= (int64_t)c.border)) res = W_BREAK;
+				if ((res & W_STATUS) == W_OK && (res & W_HADX) && atomicAdd(&L.nhadx, 1u) >= COOP_KCAP) res = W_BREAK; // (the list of such stretches is full)
 				L.ha[hk] = ra, L.hlen[hk] = rlen, L.hflag[hk] = res;
 				hk = NOPOS;
 			}
@@ -411,6 +611,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	}
 	wave_sync();
 
+	TOCK(tph, PH_WALKS);
 	// ---- the chain hops from head to head; between them every mismatch is followed by a lucky anchor.
 	// Nearly every head is on the chain's path and is followed by the next one: the lanes work out, head by head,
 	// where its walk's anchor ends and whether anything is unusual about it (the next head lies inside the walk's
@@ -513,7 +714,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	}
 	// Heads whose walk met anchors off the diagonal (rare): nothing pairs up across such a stretch; the anchor
 	// before the head is counted only if it was a right anchor itself or is long (src/process.c:176-186)
-	uint32_t extra_anchors = 0;
+	uint32_t extra_anchors = 0, kn = 0; // kn: stretches counted nowhere, listed in L.kpos
 	for (uint32_t base = 0; base < nheads; base += 64) {
 		const uint32_t k = base + lane;
 		const uint32_t fl = k < nheads ? L.hflag[k] : 0u;
@@ -537,11 +738,14 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			}
 			if (lw_before || pk - a_before >= 2 * thr) ch.quarter += (pk - a_before) >> 2, ch.rest += (pk - a_before) & 3u;
 			extra_anchors += (uni(L.hflag[kk]) >> W_NX_SHIFT) & 7u;
+			if (lane == 0) L.kpos[kn] = pk;
+			++kn;
 		}
 	}
 	wave_sync();
 
-	// ---- the stretches behind the heads the chain came by: gap positions (ebits) or counted nowhere (kbits);
+	TOCK(tph, PH_HOPS);
+	// ---- the stretches behind the heads the chain came by: gap positions (ebits), unless listed in kpos (counted nowhere);
 	// their symbols are counted here, by the lane of the head (model_count, src/model.c:309-337)
 	{
 		Tally tl;
@@ -554,7 +758,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			const uint32_t fl = i < nheads ? L.hflag[i] : 0u;
 			if (!(fl & W_ONPATH)) continue;
 			const uint32_t o0 = L.hpos[i], o1 = L.ha[i] - wbase; // [o0, o1)
-			uint32_t *dst = (fl & W_HADX) ? L.kbits : L.ebits;
+			uint32_t *dst = L.ebits;
 			for (uint32_t wd = o0 >> 5; 32 * wd < o1; ++wd) {
 				uint32_t m = ~0u;
 				if (wd == (o0 >> 5)) m &= ~0u << (o0 & 31u);
@@ -566,20 +770,31 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	}
 	wave_sync();
 
+	TOCK(tph, PH_STRETCH);
 	// ---- the mismatches behind which a lucky anchor follows at once (all that are in no such stretch), and the
 	// anchors: one ends at every position that starts a gap.  Positions e0 ... cur - 1.
 	uint32_t q_acc = 0, r_acc = 0, n_acc = 0;
 	uint32_t carry = st.lastQ - 1; // the last position so far that is in no anchor (- 1: the anchor before e0 starts at lastQ)
 	uint32_t last_word = (cur - 1 - wbase) >> 5; // (a landing beyond the window: nothing but that anchor out there)
 	if (last_word > 64 * NCH - 1) last_word = 64 * NCH - 1;
+	auto fetch = [&](uint32_t ck, uint4 &qv, uint4 &sv) { // the symbols of the lane's word of chunk ck, if it has mismatches to count
+		const uint32_t wi = 64 * ck + lane, x0 = wbase + 32 * wi;
+		qv = sv = make_uint4(0, 0, 0, 0);
+		if (64 * ck <= last_word && x0 < cur && x0 + WNT > e0 && (L.mbits[wi] & ~L.ebits[wi]))
+			qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
+	};
+	uint4 qnext, snext;
+	fetch(0, qnext, snext);
 	for (uint32_t ck = 0; 64 * ck <= last_word; ++ck) {
 		const uint32_t wi = 64 * ck + lane, x0 = wbase + 32 * wi;
+		const uint4 qv = qnext, sv = snext;
+		fetch(ck + 1, qnext, snext); // (in flight while this chunk is counted: one wait per window, not one per chunk)
 		uint32_t rm = ~0u; // positions e0 ... cur - 1
 		if (x0 + WNT <= e0 || x0 >= cur) rm = 0;
 		if (rm && e0 > x0) rm &= ~0u << (e0 - x0);
 		if (rm && cur - x0 < WNT) rm &= (1u << (cur - x0)) - 1u;
-		const uint32_t m = L.mbits[wi] & rm, eb = L.ebits[wi] & rm, kb = L.kbits[wi] & rm;
-		const uint32_t u = m | eb | kb;
+		const uint32_t m = L.mbits[wi] & rm, eb = L.ebits[wi] & rm;
+		const uint32_t u = m | eb;
 		// the last position of u before each lane's word
 		const uint32_t mine = u ? x0 + 31u - (uint32_t)__builtin_clz(u) + 2u : 0u; // (+ 2: 0 = none; positions from -1 on)
 		uint32_t scan = mine;
@@ -595,7 +810,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		const uint32_t all = (uint32_t)__shfl((int)scan, 63);
 		if (all > cin) carry = uni(all) - 2u;
 		// gap starts: a bit of u whose predecessor is none
-		const uint32_t prev_top = wi ? ((L.mbits[wi - 1] | L.ebits[wi - 1] | L.kbits[wi - 1]) >> 31) : 0u;
+		const uint32_t prev_top = wi ? ((L.mbits[wi - 1] | L.ebits[wi - 1]) >> 31) : 0u;
 		const uint32_t prev_in = (x0 > e0) ? prev_top : 0u; // (what lies before e0 is the anchor)
 		uint32_t gs = u & ~((u << 1) | prev_in);
 		n_acc += (uint32_t)__builtin_popcount(gs);
@@ -609,20 +824,18 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 				pv = before - 2u;
 			const uint32_t len = x0 + b - 1u - pv; // (pv may be lastQ - 1 = -1: unsigned wrap is fine)
 			// (the anchor before a stretch that is counted nowhere: the hop above has dealt with it, src/process.c:176-186)
-			if (!((kb >> b) & 1u)) q_acc += len >> 2, r_acc += len & 3u;
+			bool nowhere = false;
+			for (uint32_t t = 0; t < kn; ++t) nowhere |= L.kpos[t] == x0 + b;
+			if (!nowhere) q_acc += len >> 2, r_acc += len & 3u;
 		}
 		// mismatches in no head's stretch: single-position gaps
-		uint32_t singles = m & ~eb & ~kb;
-		if (__any(singles != 0)) {
-			uint4 qv = make_uint4(0, 0, 0, 0), sv = qv;
-			if (singles) qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
-			for (; singles; singles &= singles - 1) {
-				const uint32_t b = (uint32_t)__builtin_ctz(singles), sh = 4 * (b & 7u);
-				const uint32_t qn = (pick(qv, b >> 3) >> sh) & 15u, sn = (pick(sv, b >> 3) >> sh) & 15u;
-				if (!((qn | sn) & 4u)) lds_add((lds_u32 *)&L.hist[((sn & 3u) << 2) | (qn & 3u)], 1u);
-			}
+		for (uint32_t singles = m & ~eb; singles; singles &= singles - 1) {
+			const uint32_t b = (uint32_t)__builtin_ctz(singles), sh = 4 * (b & 7u);
+			const uint32_t qn = (pick(qv, b >> 3) >> sh) & 15u, sn = (pick(sv, b >> 3) >> sh) & 15u;
+			if (!((qn | sn) & 4u)) lds_add((lds_u32 *)&L.hist[((sn & 3u) << 2) | (qn & 3u)], 1u);
 		}
 	}
+	TOCK(tph, PH_FINAL);
 	ch.quarter += wave_sum(q_acc), ch.rest += wave_sum(r_acc);
 	ch.anchors += wave_sum(n_acc) + extra_anchors;
 	{
@@ -636,13 +849,13 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 
 // ------------------------------------------------------------------ the kernel
 template <int NCH>
-__global__ __launch_bounds__(BLOCK, 5) void k_coop_cold(ScanArgs a) {
-	__shared__ CoopLds<NCH> s_lds[WAVES_PER_BLOCK];
+__global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 5 : 4) void k_coop_cold(ScanArgs a) {
+	__shared__ CoopLds<NCH> s_lds[COOP_WAVES];
 	CoopLds<NCH> &L = s_lds[threadIdx.x >> 6];
 	const uint32_t lane = __lane_id();
 	const uint32_t sub = blockIdx.y;
 	if (a.subjects[sub].mode != ANDI_MODE_PROBE) return;
-	const uint32_t wseg = uni(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+	const uint32_t wseg = uni(blockIdx.x * COOP_WAVES + (threadIdx.x >> 6));
 	if (wseg >= a.total_segs) return;
 	const uint32_t qidx = uni(a.seg2query[wseg]);
 	if (a.self[sub] == (int64_t)qidx) return;
@@ -660,6 +873,7 @@ __global__ __launch_bounds__(BLOCK, 5) void k_coop_cold(ScanArgs a) {
 	wave_sync();
 
 	CSTAT(CS_SEGMENTS, 1);
+	TICK(tall);
 	while (st.p < end) {
 		CSTAT(CS_G_STEPS, 1);
 		// ---- one step of mode G (src/process.c:153-197)
@@ -705,6 +919,7 @@ __global__ __launch_bounds__(BLOCK, 5) void k_coop_cold(ScanArgs a) {
 			}
 	}
 
+	TOCK(tall, 7);
 	// ---- what pass B reads (scan.h)
 	wave_sync();
 	if (lane == 0) {
@@ -729,27 +944,37 @@ int andi_coop_enabled(void) { // ANDI_COOP=n: pass A with one wavefront per chai
 	const char *e = getenv("ANDI_COOP");
 	if (!e) return 0; // (measured slower so far: DESIGN.md 3.6)
 	const int v = atoi(e);
-	return v == 2 || v == 4 || v == 8 ? v : (v == 0 ? 0 : 4);
+	return v == 2 || v == 4 || v == 8 || v == 16 ? v : (v == 0 ? 0 : 4);
 }
 
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one segment length for the call, RAW/JC/Kimura
-	const dim3 grid((a.total_segs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, a.nsub);
+	const dim3 grid((a.total_segs + COOP_WAVES - 1) / COOP_WAVES, a.nsub);
 	switch (andi_coop_enabled()) {
-		case 2: k_coop_cold<2><<<grid, BLOCK, 0, st>>>(a); break;
-		case 8: k_coop_cold<8><<<grid, BLOCK, 0, st>>>(a); break;
-		default: k_coop_cold<4><<<grid, BLOCK, 0, st>>>(a); break;
+		case 2: k_coop_cold<2><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
+		case 8: k_coop_cold<8><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
+		case 16: k_coop_cold<16><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
+		default: k_coop_cold<4><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 	}
 #ifdef ANDI_COOP_STATS
 	if (getenv("ANDI_COOP_STATS")) {
 		static const char *names[24] = {"segments", "G steps", "probe blocks", "coop_lcp calls", "windows", "windows that moved", "heads", "walk trips",
 										"walk lane-steps", "walk probes", "heads on the path", "hops", "gaps counted in G", "positions covered by windows",
-										"heads dropped", "walks with anchors off the diagonal", "coop_lcp rounds", "nodes", "", "", "", "", "", ""};
+										"heads dropped", "walks with anchors off the diagonal", "coop_lcp rounds", "nodes", "service trips (lane_probe)", "lanes served", "parked: window edge / separators / plain table", "parked: K-mer occurs several times", "parked: long match off the diagonal", "parked: other"};
 		unsigned long long h[24];
 		(void)hipStreamSynchronize(st);
 		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_coop_stats), sizeof h);
-		for (int k = 0; k < 18; ++k) fprintf(stderr, "coop_stats %-36s %llu\n", names[k], h[k]);
+		for (int k = 0; k < 24; ++k) fprintf(stderr, "coop_stats %-36s %llu\n", names[k], h[k]);
 		memset(h, 0, sizeof h);
 		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), h, sizeof h);
+		unsigned long long cy[8];
+		(void)hipMemcpyFromSymbol(cy, HIP_SYMBOL(g_coop_cycles), sizeof cy);
+		static const char *ph[7] = {"(mode G: the rest)", "window: bits", "window: heads", "window: walks", "window: hops", "window: stretches", "window: counting"};
+		unsigned long long in_w = 0;
+		for (int k = 1; k < 7; ++k) in_w += cy[k];
+		for (int k = 1; k < 7; ++k) fprintf(stderr, "coop_cycles %-24s %6.2f %%\n", ph[k], 100.0 * (double)cy[k] / (double)cy[7]);
+		fprintf(stderr, "coop_cycles %-24s %6.2f %%\n", ph[0], 100.0 * (double)(cy[7] - in_w) / (double)cy[7]);
+		memset(cy, 0, sizeof cy);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_coop_cycles), cy, sizeof cy);
 	}
 #endif
 	return hipGetLastError();
