@@ -243,7 +243,7 @@ __device__ __forceinline__ uint32_t squeeze_codes(uint32_t x) {
 // (on_diag: the K-mer occurs once, at p + dg -- on the window's diagonal: the match is the run of equal symbols the bits show)
 // (multi_x, multi_n, multi_q: the K-mer occurs multi_n <= 4 times, at SA[multi_x ...]; multi_q = the 16 symbols behind it)
 template <int NCH>
-__device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<NCH> &L, uint32_t wbase, bool clean, uint32_t p, int64_t dg, Probe &r, bool &on_diag,
+__device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<NCH> &L, uint32_t wbase, bool clean, uint32_t p, uint32_t sd, Probe &r, bool &on_diag,
 												uint32_t &multi_x, uint32_t &multi_n, uint32_t &multi_q) {
 	on_diag = false, multi_n = 0;
 	const EsaG &E = c.E;
@@ -275,7 +275,7 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 		if (kind == DEEP_MULTI && (ty >> 8) < 4) multi_x = x, multi_n = (ty >> 8) + 1, multi_q = behind;
 		return false;
 	}
-	if ((int64_t)x == (int64_t)p + dg) {
+	if (x == p + sd) {
 		on_diag = true;
 		return true;
 	}
@@ -301,7 +301,7 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 // occurrences' own matches, unique iff one attains it (as lane_probe).  The occurrence on the window's diagonal, if
 // there is one, is the run of equal symbols the bits show (*diag_run; *diag_seen: a mismatch of the window ends it);
 // the others are compared 16 symbols deep, two per round trip.  false: a match goes deeper than that -- lane_probe's.
-__device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, int64_t dg, uint32_t x, uint32_t n, uint32_t behind,
+__device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, uint32_t sd, uint32_t x, uint32_t n, uint32_t behind,
 												 uint32_t diag_run, bool diag_seen, Probe &r, bool &on_diag_long) {
 	const EsaG &E = c.E;
 	const uint32_t K = (uint32_t)E.deepK, qrem = c.qlen - p;
@@ -318,7 +318,7 @@ __device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, i
 			const uint4 sv = h ? sb : sa;
 			const uint32_t ps = h ? pb : pa;
 			uint32_t len;
-			if ((int64_t)ps == (int64_t)p + dg) { // the diagonal's occurrence
+			if (ps == p + sd) { // the diagonal's occurrence
 				len = diag_run;
 				if (!diag_seen) len = 0x40000000u, on_diag_long = true; // (longer than anything 16 symbols can show)
 			} else {
@@ -388,6 +388,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	const uint32_t lane = __lane_id(), thr = c.thr, n = (uint32_t)c.E.n;
 	ChainState &st = ch.st;
 	const int64_t dg = (int64_t)st.lastS - (int64_t)st.lastQ;
+	const uint32_t sd = st.lastS - st.lastQ; // subject position of window position x: x + sd (x + dg >= lastS >= 0: 32 bits do)
 	const uint32_t e0 = st.lastQ + st.lastLen;
 	const uint32_t wbase = e0 & ~31u;
 	constexpr uint32_t W = 2048 * NCH;
@@ -404,9 +405,8 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			const uint4 qv = ld_query(c, x0);
 			m = squeeze32(neq32(qv, ld_subject_guarded(c, (int64_t)x0 + dg)));
 			codes = make_uint2(squeeze_codes(qv.x) | (squeeze_codes(qv.y) << 16), squeeze_codes(qv.z) | (squeeze_codes(qv.w) << 16));
-			uint32_t bad = squeeze32(make_uint4(qv.x << 1, qv.y << 1, qv.z << 1, qv.w << 1)); // bit 2 of a symbol: no nucleotide
-			if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0), bad &= ~(~0u << (c.qlen - x0));
-			dirty |= bad;
+			if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0);
+			dirty |= (qv.x | qv.y | qv.z | qv.w) & 0x44444444u; // bit 2 of a symbol: no nucleotide (the padding behind the query's end too: its last window's walks read the query itself)
 		}
 		if (x0 <= e0 && e0 - x0 < WNT) m &= ~0u << (e0 - x0); // (what lies before the anchor is none of the window's business)
 		if (x0 + WNT <= e0) m = 0;
@@ -516,7 +516,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 				if (mn) {
 					bool seen;
 					const uint32_t r = run_ahead(p, seen);
-					have = coop_probe_multi(c, p, dg, mx, mn, mq, r, seen, pr, long_diag);
+					have = coop_probe_multi(c, p, sd, mx, mn, mq, r, seen, pr, long_diag);
 				}
 				if (!have) pr = lane_probe(c, p, w), long_diag = false;
 				have = true, parked = false;
@@ -525,7 +525,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 #endif
 				if (long_diag && pr.unique) { // the diagonal's occurrence is the longest, longer than the bits at hand show
 					if (wbase + W - p >= 32) {
-						const bool same_side = ((int64_t)p + dg < (int64_t)c.border) == ((int64_t)e + dg <= (int64_t)c.border);
+						const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
 						res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
 						ra = p;
 					} else {
@@ -537,7 +537,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			} else if (p - wbase >= W) {
 				res = Xl ? W_BREAK : W_OPEN; // the walk has left the window
 			} else if (Xl == 0) {
-				if ((int64_t)p + dg < (int64_t)n && p - e <= thr) { // lucky_anchor applies on the diagonal: the bits answer
+				if (p + sd < n && p - e <= thr) { // lucky_anchor applies on the diagonal: the bits answer
 					bool seen;
 					const uint32_t r = run_ahead(p, seen);
 					if (seen) { // a mismatch of the window ends the run (r < 32: thr < 32)
@@ -560,15 +560,15 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			}
 			if (!res && !have) {
 				bool on_diag;
-				have = coop_probe_fast<NCH>(c, L, wbase, clean, p, dg, pr, on_diag, mx, mn, mq);
+				have = coop_probe_fast<NCH>(c, L, wbase, clean, p, sd, pr, on_diag, mx, mn, mq);
 				if (!have) parked = true; // (the lucky attempt above has failed or does not apply: it is not repeated)
 				if (on_diag) { // the K-mer's one occurrence is the diagonal's: the bits know the match
 					bool seen;
 					const uint32_t r = run_ahead(p, seen);
-					pr.unique = true, pr.pos = (uint32_t)((int64_t)p + dg), pr.len = r;
+					pr.unique = true, pr.pos = p + sd, pr.len = r;
 					if (!seen) { // longer than the bits at hand show: an anchor (thr < 32) whose end is settled later -- if 32 bits were at hand
 						if (wbase + W - p >= 32) {
-							const bool same_side = ((int64_t)p + dg < (int64_t)c.border) == ((int64_t)e + dg <= (int64_t)c.border);
+							const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
 							res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
 							ra = p;
 						} else {
@@ -582,9 +582,9 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			}
 			if (!res && have) {
 				if (pr.unique && pr.len >= thr) {
-					if ((int64_t)pr.pos == (int64_t)p + dg) { // on the diagonal
+					if (pr.pos == p + sd) { // on the diagonal
 						// a right anchor of the anchor before the head only on the same strand (src/process.c:162)
-						const bool same_side = ((int64_t)p + dg < (int64_t)c.border) == ((int64_t)e + dg <= (int64_t)c.border);
+						const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
 						if (!same_side || (Xl && Xl >= 2 * thr))
 							res = W_BREAK;
 						else
@@ -602,7 +602,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 				if (!res) p += pr.len + 1;
 			}
 			if (res) {
-				if ((res & W_LUCKY) && ((int64_t)ra + dg < (int64_t)c.border) != ((int64_t)e + dg <= (int64_t)c.border)) res = W_BREAK;
+				if ((res & W_LUCKY) && (ra + sd < c.border) != (e + sd <= c.border)) res = W_BREAK;
 				if ((res & W_STATUS) == W_OK && (res & W_HADX) && atomicAdd(&L.nhadx, 1u) >= COOP_KCAP) res = W_BREAK; // (the list of such stretches is full)
 				L.ha[hk] = ra, L.hlen[hk] = rlen, L.hflag[hk] = res;
 				hk = NOPOS;
@@ -772,64 +772,63 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 
 	TOCK(tph, PH_STRETCH);
 	// ---- the mismatches behind which a lucky anchor follows at once (all that are in no such stretch), and the
-	// anchors: one ends at every position that starts a gap.  Positions e0 ... cur - 1.
+	// anchors: one ends at every position that starts a gap.  Positions e0 ... cur - 1; lane l takes the NCH words of
+	// positions 32 NCH l ... (what lies before its first word comes from one scan over the lanes).
 	uint32_t q_acc = 0, r_acc = 0, n_acc = 0;
-	uint32_t carry = st.lastQ - 1; // the last position so far that is in no anchor (- 1: the anchor before e0 starts at lastQ)
-	uint32_t last_word = (cur - 1 - wbase) >> 5; // (a landing beyond the window: nothing but that anchor out there)
-	if (last_word > 64 * NCH - 1) last_word = 64 * NCH - 1;
-	auto fetch = [&](uint32_t ck, uint4 &qv, uint4 &sv) { // the symbols of the lane's word of chunk ck, if it has mismatches to count
-		const uint32_t wi = 64 * ck + lane, x0 = wbase + 32 * wi;
-		qv = sv = make_uint4(0, 0, 0, 0);
-		if (64 * ck <= last_word && x0 < cur && x0 + WNT > e0 && (L.mbits[wi] & ~L.ebits[wi]))
-			qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
-	};
-	uint4 qnext, snext;
-	fetch(0, qnext, snext);
-	for (uint32_t ck = 0; 64 * ck <= last_word; ++ck) {
-		const uint32_t wi = 64 * ck + lane, x0 = wbase + 32 * wi;
-		const uint4 qv = qnext, sv = snext;
-		fetch(ck + 1, qnext, snext); // (in flight while this chunk is counted: one wait per window, not one per chunk)
-		uint32_t rm = ~0u; // positions e0 ... cur - 1
+	auto in_range = [&](uint32_t x0) { // the positions e0 ... cur - 1 of the word that starts at x0
+		uint32_t rm = ~0u;
 		if (x0 + WNT <= e0 || x0 >= cur) rm = 0;
 		if (rm && e0 > x0) rm &= ~0u << (e0 - x0);
 		if (rm && cur - x0 < WNT) rm &= (1u << (cur - x0)) - 1u;
-		const uint32_t m = L.mbits[wi] & rm, eb = L.ebits[wi] & rm;
-		const uint32_t u = m | eb;
-		// the last position of u before each lane's word
-		const uint32_t mine = u ? x0 + 31u - (uint32_t)__builtin_clz(u) + 2u : 0u; // (+ 2: 0 = none; positions from -1 on)
-		uint32_t scan = mine;
+		return rm;
+	};
+	uint32_t before = 0; // (the last position in no anchor before the lane's words) + 2; 0: none
+	for (uint32_t jw = 0; jw < (uint32_t)NCH; ++jw) {
+		const uint32_t w = NCH * lane + jw, x0 = wbase + 32 * w;
+		const uint32_t u = (L.mbits[w] | L.ebits[w]) & in_range(x0);
+		if (u) before = x0 + 31u - (uint32_t)__builtin_clz(u) + 2u;
+	}
+	{
+		uint32_t scan = before;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
 			const uint32_t o = (uint32_t)__shfl_up((int)scan, d);
 			if (lane >= (uint32_t)d && o > scan) scan = o;
 		}
-		uint32_t before = (uint32_t)__shfl_up((int)scan, 1);
-		if (lane == 0) before = 0;
-		const uint32_t cin = carry + 2u;
-		if (cin > before) before = cin;
-		const uint32_t all = (uint32_t)__shfl((int)scan, 63);
-		if (all > cin) carry = uni(all) - 2u;
-		// gap starts: a bit of u whose predecessor is none
-		const uint32_t prev_top = wi ? ((L.mbits[wi - 1] | L.ebits[wi - 1]) >> 31) : 0u;
-		const uint32_t prev_in = (x0 > e0) ? prev_top : 0u; // (what lies before e0 is the anchor)
-		uint32_t gs = u & ~((u << 1) | prev_in);
+		before = (uint32_t)__shfl_up((int)scan, 1);
+		if (lane == 0 || before < st.lastQ + 1u) before = st.lastQ + 1u; // (the anchor before e0 starts at lastQ: lastQ - 1 is the position before it)
+	}
+	uint32_t prev_top = 0; // the last position of the word before is in no anchor (what lies before e0 is the anchor)
+	{
+		const uint32_t w = NCH * lane;
+		if (w && wbase + 32 * w > e0) prev_top = ((L.mbits[w - 1] | L.ebits[w - 1]) & in_range(wbase + 32 * (w - 1))) >> 31;
+	}
+	auto fetch = [&](uint32_t jw, uint4 &qv, uint4 &sv) { // the symbols of a word that has single mismatches to count
+		const uint32_t w = NCH * lane + jw, x0 = wbase + 32 * w;
+		qv = sv = make_uint4(0, 0, 0, 0);
+		if (jw < (uint32_t)NCH && (L.mbits[w] & ~L.ebits[w] & in_range(x0))) qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
+	};
+	uint4 qnext, snext;
+	fetch(0, qnext, snext);
+	for (uint32_t jw = 0; jw < (uint32_t)NCH; ++jw) {
+		const uint32_t w = NCH * lane + jw, x0 = wbase + 32 * w;
+		const uint4 qv = qnext, sv = snext;
+		fetch(jw + 1, qnext, snext); // (in flight while this word is counted)
+		const uint32_t rm = in_range(x0), m = L.mbits[w] & rm, eb = L.ebits[w] & rm, u = m | eb;
+		uint32_t gs = u & ~((u << 1) | prev_top); // gap starts: a position in no anchor whose predecessor is in one
 		n_acc += (uint32_t)__builtin_popcount(gs);
 		for (; gs; gs &= gs - 1) {
-			const uint32_t b = (uint32_t)__builtin_ctz(gs);
-			const uint32_t below = u & ((1u << b) - 1u);
-			uint32_t pv; // the last position before x0 + b that is in no anchor
-			if (below)
-				pv = x0 + 31u - (uint32_t)__builtin_clz(below);
-			else
-				pv = before - 2u;
+			const uint32_t b = (uint32_t)__builtin_ctz(gs), below = u & ((1u << b) - 1u);
+			const uint32_t pv = below ? x0 + 31u - (uint32_t)__builtin_clz(below) : before - 2u; // the last position before x0 + b in no anchor
 			const uint32_t len = x0 + b - 1u - pv; // (pv may be lastQ - 1 = -1: unsigned wrap is fine)
 			// (the anchor before a stretch that is counted nowhere: the hop above has dealt with it, src/process.c:176-186)
 			bool nowhere = false;
 			for (uint32_t t = 0; t < kn; ++t) nowhere |= L.kpos[t] == x0 + b;
 			if (!nowhere) q_acc += len >> 2, r_acc += len & 3u;
 		}
-		// mismatches in no head's stretch: single-position gaps
-		for (uint32_t singles = m & ~eb; singles; singles &= singles - 1) {
+		if (u) before = x0 + 31u - (uint32_t)__builtin_clz(u) + 2u;
+		prev_top = u >> 31;
+		for (uint32_t singles = m & ~eb; singles; singles &= singles - 1) { // mismatches in no head's stretch: single-position gaps
 			const uint32_t b = (uint32_t)__builtin_ctz(singles), sh = 4 * (b & 7u);
 			const uint32_t qn = (pick(qv, b >> 3) >> sh) & 15u, sn = (pick(sv, b >> 3) >> sh) & 15u;
 			if (!((qn | sn) & 4u)) lds_add((lds_u32 *)&L.hist[((sn & 3u) << 2) | (qn & 3u)], 1u);
@@ -849,7 +848,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 
 // ------------------------------------------------------------------ the kernel
 template <int NCH>
-__global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 5 : 4) void k_coop_cold(ScanArgs a) {
+__global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 6 : 4) void k_coop_cold(ScanArgs a) {
 	__shared__ CoopLds<NCH> s_lds[COOP_WAVES];
 	CoopLds<NCH> &L = s_lds[threadIdx.x >> 6];
 	const uint32_t lane = __lane_id();
