@@ -74,6 +74,9 @@ struct andi_hip_ctx {
 	size_t sa_ws_bytes = 0;
 	int32_t *sa_pinned = nullptr;
 	uint32_t *h_quad_waves = nullptr; // pinned: the length of k_lane_quad's list of a scan call
+	uint32_t *d_coop_abort = nullptr; // pass A by wavefronts on trial: the word its wavefronts set when the call is not their kind
+	uint32_t *h_coop_abort = nullptr; // pinned copy
+	uint32_t coop_backoff = 0;        // scan calls for which the trial is skipped (it failed recently)
 	std::vector<EventPair> pending;
 	andi_hip_timings acc{};
 };
@@ -118,6 +121,12 @@ struct andi_hip_queries {
 	uint32_t *d_qseg_start = nullptr;
 	uint32_t *d_seg2query = nullptr;
 	uint32_t total_segs = 0;
+	// a second one: the long segments of pass A by wavefronts (scan_coop.hip), kept beside the call's own so that a
+	// call that falls back to the lane scan does not cut the queries anew every time
+	uint32_t c_seg = 0;
+	uint32_t *c_qseg_start = nullptr;
+	uint32_t *c_seg2query = nullptr;
+	uint32_t c_total_segs = 0;
 };
 
 namespace {
@@ -290,6 +299,8 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_quad_waves, sizeof(uint32_t), hipHostMallocDefault);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_coop_abort, sizeof(uint32_t), hipHostMallocDefault);
+	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_coop_abort, sizeof(uint32_t));
 	if (e != hipSuccess) {
 		set_err(errbuf, errlen, "context setup: %s", hipGetErrorString(e));
 		andi_hip_ctx_destroy(ctx);
@@ -322,6 +333,8 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->sa_ws) (void)andi_arena::dev_free(ctx->sa_ws);
 	if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
 	if (ctx->h_quad_waves) (void)hipHostFree(ctx->h_quad_waves);
+	if (ctx->h_coop_abort) (void)hipHostFree(ctx->h_coop_abort);
+	if (ctx->d_coop_abort) (void)andi_arena::dev_free(ctx->d_coop_abort);
 	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
 	if (ctx->side_stream) {
 		(void)hipStreamSynchronize(ctx->side_stream);
@@ -537,10 +550,11 @@ int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!ctx || !e) return 1;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	Timed t(ctx, 0);
-	hipError_t err = andi_launch_index_build(build_args(e), ctx->stream);
+	const int ext = andi_index_single_ext(ctx->queries_hint);
+	hipError_t err = andi_launch_index_build(build_args(e), ext, ctx->stream);
 	t.stop();
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index", err);
-	e->index_built = true, e->deep_ext = andi_index_single_ext() != 0;
+	e->index_built = true, e->deep_ext = ext != 0;
 	return 0;
 }
 
@@ -579,10 +593,11 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 	Timed t(ctx, 0);
 	hipError_t err = hipMemcpyAsync(ctx->ib_dev, ctx->ib_host, count * sizeof(AndiIndexBatchItem), hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess) err = hipEventRecord(ctx->ib_done, ctx->stream);
-	if (err == hipSuccess) err = andi_launch_index_build_batch((const AndiIndexBatchItem *)ctx->ib_dev, (uint32_t)count, max_n, ctx->stream);
+	const int ext = andi_index_single_ext(ctx->queries_hint);
+	if (err == hipSuccess) err = andi_launch_index_build_batch((const AndiIndexBatchItem *)ctx->ib_dev, (uint32_t)count, max_n, ext, ctx->stream);
 	t.stop();
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index_batch", err);
-	for (size_t k = 0; k < count; ++k) esas[k]->index_built = true, esas[k]->deep_ext = andi_index_single_ext() != 0;
+	for (size_t k = 0; k < count; ++k) esas[k]->index_built = true, esas[k]->deep_ext = ext != 0;
 	return 0;
 }
 
@@ -701,18 +716,20 @@ void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q) {
 	if (!q) return;
 	if (ctx) (void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize();
-	void *bufs[] = {q->pool, q->nib, q->d_off, q->d_len, q->d_qseg_start, q->d_seg2query};
+	void *bufs[] = {q->pool, q->nib, q->d_off, q->d_len, q->d_qseg_start, q->d_seg2query, q->c_qseg_start, q->c_seg2query};
 	for (void *b : bufs) (void)andi_arena::dev_free(b, false);
 	if (q->h_foreign) (void)hipHostFree(q->h_foreign);
 	delete q;
 }
 
-static int ensure_segmentation(andi_hip_ctx *ctx, andi_hip_queries *q, uint32_t seg) {
-	if (q->seg == seg && q->d_qseg_start) return 0;
+static int ensure_segmentation(andi_hip_ctx *ctx, andi_hip_queries *q, uint32_t seg, bool coop = false) {
+	uint32_t &have = coop ? q->c_seg : q->seg, &total_out = coop ? q->c_total_segs : q->total_segs;
+	uint32_t *&d_start = coop ? q->c_qseg_start : q->d_qseg_start, *&d_s2q = coop ? q->c_seg2query : q->d_seg2query;
+	if (have == seg && d_start) return 0;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	(void)andi_arena::dev_free(q->d_qseg_start);
-	(void)andi_arena::dev_free(q->d_seg2query);
-	q->d_qseg_start = q->d_seg2query = nullptr;
+	(void)andi_arena::dev_free(d_start);
+	(void)andi_arena::dev_free(d_s2q);
+	d_start = d_s2q = nullptr;
 	std::vector<uint32_t> start(q->nq + 1);
 	uint64_t total = 0;
 	for (size_t i = 0; i < q->nq; ++i) {
@@ -727,12 +744,12 @@ static int ensure_segmentation(andi_hip_ctx *ctx, andi_hip_queries *q, uint32_t 
 	std::vector<uint32_t> s2q((size_t)total);
 	for (size_t i = 0; i < q->nq; ++i)
 		for (uint32_t w = start[i]; w < start[i + 1]; ++w) s2q[w] = (uint32_t)i;
-	HIP_TRY(ctx, dmalloc(&q->d_qseg_start, q->nq + 1));
-	HIP_TRY(ctx, dmalloc(&q->d_seg2query, (size_t)total));
-	HIP_TRY(ctx, hipMemcpy(q->d_qseg_start, start.data(), (q->nq + 1) * 4, hipMemcpyHostToDevice));
-	HIP_TRY(ctx, hipMemcpy(q->d_seg2query, s2q.data(), (size_t)total * 4, hipMemcpyHostToDevice));
-	q->seg = seg;
-	q->total_segs = (uint32_t)total;
+	HIP_TRY(ctx, dmalloc(&d_start, q->nq + 1));
+	HIP_TRY(ctx, dmalloc(&d_s2q, (size_t)total));
+	HIP_TRY(ctx, hipMemcpy(d_start, start.data(), (q->nq + 1) * 4, hipMemcpyHostToDevice));
+	HIP_TRY(ctx, hipMemcpy(d_s2q, s2q.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+	have = seg;
+	total_out = (uint32_t)total;
 	return 0;
 }
 
@@ -784,19 +801,27 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// segment == 0: the engine chooses.  With the lane scan and a moderate number of pairs
 	// the segment length is chosen per pair (scan_lane.hip: k_pair_estimate); otherwise one
 	// length for the call.
-	// Pass A with one wavefront per chain (scan_coop.hip): the lane scan's default for the models that split an
-	// anchor's length evenly, thresholds a 32-symbol window can decide.  One segment length for the call, long
-	// segments (a wavefront needs far fewer chains in flight than a lane): 32768 symbols while that leaves 2^14.
-	int coop = andi_scan_group() == 0 && andi_coop_enabled() && model <= ANDI_M_KIMURA;
-	for (size_t s = 0; s < nsub && coop; ++s)
-		if (!subjects[s] || subjects[s]->thr < 2 || subjects[s]->thr > 30) coop = 0;
+	// Pass A with one wavefront per chain (scan_coop.hip) for the models that split an anchor's length evenly and
+	// thresholds a 32-symbol window can decide.  ANDI_COOP=n: the call's pass A, one (long) segment length for the call.
+	// Unset: ON TRIAL for large calls -- it runs first, on its own segmentation; a wavefront that meets what the
+	// kernel is slow at (a pair with long matches, a stretch without homology) ends the trial and the call takes the
+	// lane scan as if nothing had happened (a context whose trial failed skips the next ones).
+	const int coop_mode = andi_coop_enabled();
+	int coop_ok = andi_scan_group() == 0 && coop_mode != 0 && model <= ANDI_M_KIMURA && !getenv("ANDI_FORCE_REFERENCE");
+	for (size_t s = 0; s < nsub && coop_ok; ++s)
+		if (!subjects[s] || subjects[s]->thr < 2 || subjects[s]->thr > 30) coop_ok = 0;
+	const int coop = coop_ok && coop_mode > 0;
+	uint32_t coop_seg = 32768; // a wavefront needs far fewer chains in flight than a lane: long segments
+	if (const char *cs = getenv("ANDI_COOP_SEG")) // experiments
+		if (atoi(cs) >= 64) coop_seg = (uint32_t)atoi(cs);
+	bool coop_trial = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub / coop_seg >= (1u << 14) &&
+					  !getenv("ANDI_UNIFORM_SEGMENTS") && !getenv("ANDI_FORCE_ADAPTIVE");
+	if (coop_trial && ctx->coop_backoff) --ctx->coop_backoff, coop_trial = false;
 	const bool want_adaptive = !coop && segment == 0 && andi_scan_group() == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
 							   !getenv("ANDI_UNIFORM_SEGMENTS");
 	if (segment == 0 && coop) {
 		const uint64_t nt = q->total_nt * (uint64_t)nsub;
-		segment = 32768;
-		if (const char *cs = getenv("ANDI_COOP_SEG")) // experiments
-			if (atoi(cs) >= 64) segment = (uint32_t)atoi(cs);
+		segment = coop_seg;
 		while (segment > 2048 && nt / segment < (1u << 14)) segment /= 2;
 	}
 	if (segment == 0) {
@@ -855,6 +880,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 								ctx->stream));
 	HIP_TRY(ctx, hipEventRecord(ctx->desc_done, ctx->stream));
 
+	if (any_reference) coop_trial = false;
+	if (coop_trial && ensure_segmentation(ctx, q, coop_seg, true)) return 1;
 	// scratch: per (subject, segment) two states and two count vectors
 	bool adaptive = want_adaptive && !any_reference;
 	uint32_t seg0 = segment / 2; // classes: 1/2, 1, 2, 4 times the call's segment length
@@ -879,7 +906,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		if (!fits || (10 * used < 7 * 64 * max_waves && !getenv("ANDI_FORCE_ADAPTIVE"))) adaptive = false, max_waves = 0;
 	}
 	const size_t pairs_all = nsub * q->nq;
-	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
+	size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
+	if (coop_trial && slots < nsub * (size_t)q->c_total_segs) slots = nsub * (size_t)q->c_total_segs; // (both layouts carve the same scratch)
 	const size_t need = slots * ANDI_SLOT_BYTES + 128 +
 						(adaptive ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
 	if (ctx->scratch_bytes < need) {
@@ -951,6 +979,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	a.lanes = a.group == 0;
 	a.coop = coop && a.lanes && !a.adaptive;
+	a.coop_abort = nullptr, a.coop_classes = 0;
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 
 	if (a.adaptive) {
@@ -959,13 +988,45 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		t.stop();
 		if (e != hipSuccess) return fail(ctx, "scan layout", e);
 	}
-	{
+	bool coop_done = false;
+	if (coop_trial && a.lanes) {
+		// pass A by wavefronts on trial: its own (long) segments in the same scratch; the pairs' classes, if the call
+		// has sampled them, tell it which pairs are not its kind
+		ScanArgs b = a;
+		b.adaptive = 0, b.coop = 1;
+		b.qseg_start = q->c_qseg_start, b.seg2query = q->c_seg2query, b.total_segs = q->c_total_segs, b.seg = coop_seg;
+		b.coop_abort = ctx->d_coop_abort, b.coop_classes = a.adaptive;
+		Timed t(ctx, 1);
+		hipError_t e = hipMemsetAsync(ctx->d_coop_abort, 0, sizeof(uint32_t), ctx->stream);
+		if (e == hipSuccess) e = andi_launch_coop_cold(b, ctx->stream);
+		if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_coop_abort, ctx->d_coop_abort, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e != hipSuccess) return fail(ctx, "scan pass A", e);
+		if (*ctx->h_coop_abort == 0) {
+			t.stop();
+			coop_done = true;
+			b.coop_abort = nullptr;
+			Timed t2(ctx, 2);
+			e = andi_launch_scan_stitch(b, ctx->stream);
+			if (e == hipSuccess) e = andi_launch_scan_reduce(b, ctx->stream);
+			t2.stop();
+			if (e != hipSuccess) return fail(ctx, "scan passes B/C", e);
+			ctx->acc.coop_calls++;
+		} else { // not its kind of call: the lane scan, and no more trials for a while
+			ctx->coop_backoff = 16;
+			ctx->acc.coop_fallbacks++;
+			e = andi_launch_scan_cold(a, ctx->stream);
+			t.stop();
+			if (e != hipSuccess) return fail(ctx, "scan pass A", e);
+		}
+	} else {
 		Timed t(ctx, 1);
 		hipError_t e = andi_launch_scan_cold(a, ctx->stream);
 		t.stop();
 		if (e != hipSuccess) return fail(ctx, "scan pass A", e);
+		if (a.coop) ctx->acc.coop_calls++;
 	}
-	{
+	if (!coop_done) {
 		Timed t(ctx, 2);
 		hipError_t e = andi_launch_scan_stitch(a, ctx->stream);
 		if (e == hipSuccess) e = andi_launch_scan_reduce(a, ctx->stream);
@@ -979,7 +1040,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		fprintf(stderr, "stitch: %zu slots; true chains that left on their own %u; stitched again in rounds: %u %u %u; last list %u\n", slots,
 				h[ANDI_RESTITCH_ROUNDS], h[0], h[1], h[2], h[8]);
 	}
-	(adaptive ? ctx->acc.adaptive_calls : ctx->acc.uniform_calls)++;
+	((adaptive && !coop_done) ? ctx->acc.adaptive_calls : ctx->acc.uniform_calls)++;
 	ctx->acc.scan_pairs += pairs;
 	ctx->acc.scan_query_nt += nt;
 	return 0;

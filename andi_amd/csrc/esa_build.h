@@ -41,12 +41,12 @@ struct AndiIndexBatchItem {
 
 size_t andi_min_tree_entries(int32_t n);
 // 1: the index builds launched now write the extended entries of K-mers that occur once (andi_dev.h: DEEP_SINGLE)
-int andi_index_single_ext(void);
+int andi_index_single_ext(size_t queries);
 // the scan indexes of `count` subjects (device array of items) in two launches; max_n = the longest text
-hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, hipStream_t st);
+hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, int single_ext, hipStream_t st);
 // (scan_lane.hip) packed symbols of the items' texts, `bytes` source bytes each at most (shorter texts stop at their own end)
 hipError_t andi_launch_pack_symbols_batch(const AndiIndexBatchItem *d_items, uint32_t count, size_t bytes, hipStream_t st);
 // reference arrays LCP, CLD, FVC, tab (esa_init_LCP/_CLD/_FVC/_cache)
 hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st);
 // scan index: deep, side, flags from S and SA alone
-hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st);
+hipError_t andi_launch_index_build(const EsaBuildArgs &a, int single_ext, hipStream_t st);

@@ -610,28 +610,33 @@ size_t andi_min_tree_entries(int32_t n) {
 // The entries of K-mers that occur once also carry the (up to 13) nucleotides behind the occurrence when a scan is going to
 // read them: pass A in rounds (scan_rounds.hip) and pass A with one wavefront per chain (scan_coop.hip).  Every scan
 // understands both forms (the position is in the same place); the subject's handle remembers which it has.
-int andi_index_single_ext(void) {
-	return andi_rounds_lines() != 0 || andi_coop_enabled() != 0;
+int andi_index_single_ext(size_t queries) { // queries: how many the subject is going to meet (0: unknown)
+	if (andi_rounds_lines() != 0) return 1;
+	if (getenv("ANDI_COOP_PLAIN")) return 0; // (experiments)
+	const int coop = andi_coop_enabled();
+	// pass A by wavefronts reads them -- worth the build's extra gather (+ 20 %) when the scan is forced to it, or, on
+	// trial, when the subject meets hundreds of queries
+	return coop > 0 || (coop < 0 && queries >= 256);
 }
 
-hipError_t andi_launch_index_build(const EsaBuildArgs &a, hipStream_t st) {
+hipError_t andi_launch_index_build(const EsaBuildArgs &a, int single_ext, hipStream_t st) {
 	const int32_t n = a.n;
 	hipError_t e;
 	// symbols for the lane scan: the text, its NUL and 64 bytes of the zero padding behind it
 	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 1, st);
 	if (e != hipSuccess) return e;
 	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_TILE - 1) / PT_TILE), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.rec, a.deep, a.flags, n,
-																				  a.deepK, andi_index_single_ext());
+																				  a.deepK, single_ext);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
 
-hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, hipStream_t st) {
+hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, int single_ext, hipStream_t st) {
 	if (count == 0) return hipSuccess;
 	hipError_t e = andi_launch_pack_symbols_batch(d_items, count, (size_t)max_n + 1 + 64, st);
 	if (e != hipSuccess) return e;
 	const dim3 grid((unsigned)(((int64_t)max_n + 1 + PT_TILE - 1) / PT_TILE), count);
-	k_probe_table_batch<<<grid, PT_BLOCK, 0, st>>>(d_items, andi_index_single_ext());
+	k_probe_table_batch<<<grid, PT_BLOCK, 0, st>>>(d_items, single_ext);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }

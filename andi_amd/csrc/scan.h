@@ -97,6 +97,8 @@ struct ScanArgs {
 	// matches, k_lane_cold for the others) share the device instead of each ending in a tail of its own
 	hipStream_t side_stream;
 	hipEvent_t side_fork, side_join;
+	uint32_t *coop_abort; // pass A by wavefronts on trial (null: it is the call's pass A, come what may): a wavefront that meets what the kernel is slow at -- a pair with long matches, a stretch without homology -- sets the word and all return; the host then takes the lane scan
+	int coop_classes;    // the pairs' classes are valid (k_pair_estimate has run): a call most of whose pairs are of k_lane_quad's class ends the trial at once
 	int coop;            // pass A with one wavefront per chain (scan_coop.hip): one segment length, RAW/JC/Kimura, probe-table subjects
 	uint32_t knock;      // diagnostic builds (-DANDI_LANE_STATS): parts of pass A switched off to time them (results are then wrong)
 };
@@ -113,7 +115,7 @@ int andi_scan_group(void);
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 // pass A with one wavefront per chain (scan_coop.hip); andi_coop_enabled(): 0 = off (ANDI_COOP=0), else the window's length in chunks of 2048 symbols
-int andi_coop_enabled(void);
+int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: on trial for calls it suits (the default); n > 0: windows of 2048 n symbols, unconditionally
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStream_t st); // k_lane_quad, one wavefront per block (scan_lane.hip compiled a second time)

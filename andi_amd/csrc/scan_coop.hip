@@ -34,6 +34,8 @@ namespace {
 #define COOP_HCAP (32u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
 constexpr int COOP_WAVES = 2; // wavefronts per block: each has a window's worth of LDS, small blocks fill a CU more evenly
 constexpr uint32_t COOP_KCAP = 32; // stretches of a window that are counted nowhere (more: the window ends before the next one)
+constexpr uint32_t COOP_TRIAL_G = 192;   // on trial: a segment that needs more generic steps than this is in a stretch without homology (clean sets: <= 45)
+constexpr uint32_t COOP_TRIAL_LCP = 16;  // on trial: a match followed through more rounds of 2048 symbols than this is longer than its segment
 constexpr uint32_t COOP_PARK = 16; // parked lanes (their probe needs lane_probe) that are served together
 constexpr uint32_t COOP_MAX_X = 3;  // anchors off the window's diagonal a walk follows before it gives up
 constexpr uint32_t NOPOS = 0xffffffffu;
@@ -58,6 +60,9 @@ __device__ unsigned long long g_coop_cycles[8];
 #define CSTAT(k, v) ((void)0)
 #define TICK(t) ((void)0)
 #define TOCK(t, ph) ((void)0)
+#endif
+#ifdef ANDI_COOP_STATS
+__device__ unsigned int g_coop_max[4];
 #endif
 enum { PH_G, PH_STREAM, PH_HEADS, PH_WALKS, PH_HOPS, PH_STRETCH, PH_FINAL };
 enum { CS_SEGMENTS, CS_G_STEPS, CS_BLOCKS, CS_LCP, CS_WINDOWS, CS_MOVED, CS_HEADS, CS_TRIPS, CS_LANE_STEPS, CS_PROBES, CS_ONPATH,
@@ -137,7 +142,8 @@ struct Chain { // the chain of the wavefront: everything wave-uniform
 };
 
 // lcp(Q + p, S + s, maxlen) (src/process.c:59-65) with all lanes: 2048 symbols per round trip
-__device__ __forceinline__ uint32_t coop_lcp(const PairCtx &c, uint32_t p, uint32_t s, uint32_t maxlen) {
+// (max_rounds: give up after that many round trips and return NOPOS)
+__device__ __forceinline__ uint32_t coop_lcp(const PairCtx &c, uint32_t p, uint32_t s, uint32_t maxlen, uint32_t max_rounds = ~0u) {
 	const uint32_t lane = __lane_id(), pe = p & ~1u, skip = p & 1u;
 	const int64_t dg = (int64_t)s - (int64_t)p;
 	CSTAT(CS_LCP, 1);
@@ -157,6 +163,7 @@ __device__ __forceinline__ uint32_t coop_lcp(const PairCtx &c, uint32_t p, uint3
 			return len < maxlen ? len : maxlen;
 		}
 		if (base + 64 * WNT - skip >= maxlen) return maxlen;
+		if (base / (64 * WNT) + 1 >= max_rounds) return NOPOS;
 	}
 }
 
@@ -253,7 +260,7 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 #else
 #define WHY(k) ((void)0)
 #endif
-	if (!(clean && E.deep_ext && o + 32 <= 2048 * NCH && p + 32 <= c.qlen)) {
+	if (!(clean && o + 32 <= 2048 * NCH && p + 32 <= c.qlen)) {
 		WHY(CS_WHY_PRE);
 		return false;
 	}
@@ -278,6 +285,10 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 	if (x == p + sd) {
 		on_diag = true;
 		return true;
+	}
+	if (!E.deep_ext) { // (plain entries: the occurrence has to be looked at -- with the parked lanes, its position is known)
+		multi_x = x, multi_n = 0x80000001u, multi_q = behind;
+		return false;
 	}
 	const uint32_t nval = (ty >> 2) & 15u, ext = ty >> 6;
 	const uint32_t diff = (behind ^ ext) & 0x03ffffffu;
@@ -305,7 +316,9 @@ __device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, u
 												 uint32_t diag_run, bool diag_seen, Probe &r, bool &on_diag_long) {
 	const EsaG &E = c.E;
 	const uint32_t K = (uint32_t)E.deepK, qrem = c.qlen - p;
-	const uint4 pos4 = ld_u128_unaligned((g_u8p)(E.SA + x)); // (SA is padded by eight entries)
+	uint4 pos4 = make_uint4(x, 0, 0, 0); // (n & 0x80000000: x is the one occurrence's position itself)
+	if (!(n & 0x80000000u)) pos4 = ld_u128_unaligned((g_u8p)(E.SA + x)); // (SA is padded by eight entries)
+	n &= 0x7fffffffu;
 	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
 	bool deep = false;
 	on_diag_long = false;
@@ -864,6 +877,16 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 6 : 4) void k_coop_cold
 	const size_t slot = (size_t)sub * a.total_segs + wseg;
 	const uint32_t n = (uint32_t)c.E.n, thr = c.thr;
 
+	auto give_up = [&]() { // on trial: this is not the kernel's kind of call
+		if (lane == 0) __hip_atomic_store(a.coop_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	};
+	auto given_up = [&]() { return a.coop_abort && uni(__hip_atomic_load(a.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0; };
+	if (a.coop_abort) {
+		// a call whose pairs mostly have long matches (a quarter of the layout's wavefronts on k_lane_quad's list) is the
+		// lane scan's: its two kernels stream such pairs faster than the windows here
+		if (a.coop_classes && 4 * a.restitch_count[ANDI_QUAD_WAVES] > a.pair_wave0[a.nsub * a.nq]) return give_up();
+		if (given_up()) return;
+	}
 	if (lane < 16) L.hist[lane] = 0;
 	Chain ch;
 	ch.st = seg_in_q == 0 ? initial_state() : cold_state(start, n);
@@ -873,14 +896,21 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 6 : 4) void k_coop_cold
 
 	CSTAT(CS_SEGMENTS, 1);
 	TICK(tall);
+	uint32_t my_g = 0;
 	while (st.p < end) {
 		CSTAT(CS_G_STEPS, 1);
+		++my_g;
+		if (a.coop_abort) {
+			if (my_g > COOP_TRIAL_G) return give_up();
+			if (given_up()) return;
+		}
 		// ---- one step of mode G (src/process.c:153-197)
 		bool found = false, lucky = false;
 		uint32_t curS = 0, curLen = 0;
 		if (lucky_applies(st, n, thr)) {
 			curS = st.lastS + (st.p - st.lastQ);
-			curLen = coop_lcp(c, st.p, curS, c.qlen - st.p);
+			curLen = coop_lcp(c, st.p, curS, c.qlen - st.p, a.coop_abort ? COOP_TRIAL_LCP : ~0u);
+			if (curLen == NOPOS) return give_up();
 			found = lucky = curLen >= thr;
 		}
 		if (!found) {
@@ -915,10 +945,15 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 6 : 4) void k_coop_cold
 		// ---- windows one after the other while the chain stays canonical on the diagonal and moves
 		if (found && lucky)
 			while (st.p < end && st.lastQ + st.lastLen < c.qlen && coop_window<NCH>(a, c, ch, L, end)) {
+				if (given_up()) return;
 			}
 	}
 
 	TOCK(tall, 7);
+#ifdef ANDI_COOP_STATS
+	if (lane == 0) atomicMax(&g_coop_max[0], my_g);
+#endif
+	(void)my_g;
 	// ---- what pass B reads (scan.h)
 	wave_sync();
 	if (lane == 0) {
@@ -939,16 +974,17 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 6 : 4) void k_coop_cold
 
 } // namespace
 
-int andi_coop_enabled(void) { // ANDI_COOP=n: pass A with one wavefront per chain, windows of 2048 n symbols (n = 2, 4, 8); unset or 0: one lane per chain (scan_lane.hip)
+int andi_coop_enabled(void) { // ANDI_COOP=0: never; n = 2, 4, 8, 16: pass A with one wavefront per chain, windows of 2048 n symbols, whatever the call; unset: on trial (< 0)
 	const char *e = getenv("ANDI_COOP");
-	if (!e) return 0; // (measured slower so far: DESIGN.md 3.6)
+	if (!e) return -4;
 	const int v = atoi(e);
 	return v == 2 || v == 4 || v == 8 || v == 16 ? v : (v == 0 ? 0 : 4);
 }
 
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one segment length for the call, RAW/JC/Kimura
 	const dim3 grid((a.total_segs + COOP_WAVES - 1) / COOP_WAVES, a.nsub);
-	switch (andi_coop_enabled()) {
+	const int nch = andi_coop_enabled();
+	switch (nch < 0 ? -nch : nch) {
 		case 2: k_coop_cold<2><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 		case 8: k_coop_cold<8><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 		case 16: k_coop_cold<16><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
@@ -965,6 +1001,11 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 		for (int k = 0; k < 24; ++k) fprintf(stderr, "coop_stats %-36s %llu\n", names[k], h[k]);
 		memset(h, 0, sizeof h);
 		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), h, sizeof h);
+		unsigned int mx[4];
+		(void)hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_coop_max), sizeof mx);
+		fprintf(stderr, "coop_stats most G steps of a segment          %u\n", mx[0]);
+		memset(mx, 0, sizeof mx);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_coop_max), mx, sizeof mx);
 		unsigned long long cy[8];
 		(void)hipMemcpyFromSymbol(cy, HIP_SYMBOL(g_coop_cycles), sizeof cy);
 		static const char *ph[7] = {"(mode G: the rest)", "window: bits", "window: heads", "window: walks", "window: hops", "window: stretches", "window: counting"};

@@ -68,6 +68,8 @@ class Timings(C.Structure):
         ("sa_rounds", C.c_uint64),
         ("adaptive_calls", C.c_uint64),
         ("uniform_calls", C.c_uint64),
+        ("coop_calls", C.c_uint64),
+        ("coop_fallbacks", C.c_uint64),
     ]
 
 

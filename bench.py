@@ -319,8 +319,9 @@ def main():
         copy_gbps = 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
+    # pass A's kernel: one wavefront per chain (scan_coop.hip) where the call suits it, else one lane per chain
     scan_kernel = "k_scan_cold" if os.environ.get("ANDI_SCAN_G", "0") != "0" else (
-        "k_coop_cold" if os.environ.get("ANDI_COOP", "0") not in ("", "0") else "k_lane_cold")
+        "k_coop_cold" if tm["coop_calls"] >= max(int(tm["scan_launches"]), 1) else "k_lane_cold")
     out = None
     if rank == 0:
         full = gathered[0] if use_dist else shard.gather_matrix(block, G, rows=S)
@@ -332,7 +333,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload_name(args.set, G, S, args.length, args.dlo, args.dhi, args.seed, world),
                        "genomes": G, "subjects": S, "length": args.length, "model": "JC", "pairs": pairs_total,
-                       "segment": args.segment or "auto (chosen per pair from its sampled match lengths: 2048 ... 16384 for this set)"},
+                       "segment": args.segment or ("auto (32768: pass A by wavefronts)" if tm["coop_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "measured_copy_GBps": copy_gbps,
@@ -342,6 +343,8 @@ def main():
                                       "scan_cold_pass": tm["scan_ms"] / args.steps,
                                       "scan_stitch_reduce": tm["stitch_ms"] / args.steps,
                                       "fixups": int(tm["fixups"]),
+                                      "scan_calls_pass_a_by_wavefronts": int(tm["coop_calls"]),
+                                      "scan_calls_fallen_back_to_lanes": int(tm["coop_fallbacks"]),
                                       "scan_calls_with_per_pair_segments": int(tm["adaptive_calls"]),
                                       "scan_calls_with_one_segment_length": int(tm["uniform_calls"])},
             "end_to_end": {"note": "rank 0, untimed staging of its rows: RS on %d host threads, H2D of RS, suffix arrays "

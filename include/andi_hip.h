@@ -225,6 +225,8 @@ typedef struct {
 	uint64_t sa_rounds;      /* sorting rounds of those builds */
 	uint64_t adaptive_calls; /* scan calls that chose the segment length per pair */
 	uint64_t uniform_calls;  /* ... one segment length for the call */
+	uint64_t coop_calls;     /* scan calls whose pass A ran with one wavefront per chain (scan_coop.hip) */
+	uint64_t coop_fallbacks; /* ... that tried it and fell back to one lane per chain (long matches, stretches without homology) */
 } andi_hip_timings;
 int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t);
 void andi_hip_timings_reset(andi_hip_ctx *ctx);

@@ -67,3 +67,52 @@ def test_headline_pair_full_length():
     seqs, _ = synth.genome_set(3, 4_900_000, 0.0004, 0.03, seed=1729)
     lane = _matrix(seqs, andi_amd.M_JC, 0)
     assert (_matrix(seqs, andi_amd.M_JC, 4) == lane).all()
+
+
+def _rows(seqs, env):
+    """rows of all subjects through andi_hip_scan_rows on a context of its own; returns (counts, timings)"""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = andi_amd.Context(0)
+        Q = andi_amd.Queries(ctx, seqs)
+        esas = [andi_amd.Esa(ctx, s, sa="device") for s in seqs]
+        ctx.timings_reset()
+        got = andi_amd.scan_rows(ctx, esas, list(range(len(seqs))), Q)
+        t = ctx.timings()
+        for e in esas:
+            e.close()
+        Q.close()
+        ctx.close()
+        return got, t
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_trial_on_a_large_clean_call_and_fallback_on_a_structured_one():
+    """Unset, ANDI_COOP means ON TRIAL for large calls: on a star set the wavefront kernel is the call's pass A; on
+    genomes with unrelated stretches (and on a set with a pair of k_lane_quad's class) the trial ends and the lane scan
+    takes the call.  Same counts every way."""
+    os.environ.pop("ANDI_COOP", None)
+    star, _ = synth.genome_set(12, 4_900_000, 0.004, 0.03, seed=5)
+    lane, t0 = _rows(star, {"ANDI_COOP": "0"})
+    assert t0["coop_calls"] == 0 and t0["coop_fallbacks"] == 0
+    got, t = _rows(star, {})
+    assert (t["coop_calls"], t["coop_fallbacks"]) == (1, 0), t
+    assert (got == lane).all()
+    # genomes a few substitutions apart: matches longer than a segment (and k_lane_quad's class throughout)
+    base = synth.base_codes(4_900_000, 5)
+    close = [synth.to_bytes(synth.mutate_codes(base, 0.00002, 90 + k)) for k in range(12)]
+    lane, _ = _rows(close, {"ANDI_COOP": "0"})
+    got, t = _rows(close, {})
+    assert (t["coop_calls"], t["coop_fallbacks"]) == (0, 1), t
+    assert (got == lane).all()
+    real, _ = synth.realistic_set(12, 4_900_000, 0.004, 0.03, seed=9)
+    lane, _ = _rows(real, {"ANDI_COOP": "0"})
+    got, t = _rows(real, {})
+    assert (t["coop_calls"], t["coop_fallbacks"]) == (0, 1), t
+    assert (got == lane).all()
