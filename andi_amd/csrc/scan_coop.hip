@@ -31,7 +31,7 @@
 
 namespace {
 
-#define COOP_HCAP (32u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
+#define COOP_HCAP (NCH <= 2 ? 64u : 24u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
 constexpr int COOP_WAVES = 2; // wavefronts per block: each has a window's worth of LDS, small blocks fill a CU more evenly
 constexpr uint32_t COOP_KCAP = 32; // stretches of a window that are counted nowhere (more: the window ends before the next one)
 constexpr uint32_t COOP_TRIAL_G = 192;   // on trial: a segment that needs more generic steps than this is in a stretch without homology (clean sets: <= 45)
@@ -69,20 +69,28 @@ enum { CS_SEGMENTS, CS_G_STEPS, CS_BLOCKS, CS_LCP, CS_WINDOWS, CS_MOVED, CS_HEAD
 	   CS_HOPS, CS_G_GAPS, CS_COVERED, CS_DROPPED, CS_X, CS_LCP_ROUNDS, CS_NODES, CS_SERVICE, CS_SERVICE_LANES, CS_WHY_PRE, CS_WHY_MULTI, CS_WHY_LONG, CS_WHY_OTHER };
 
 // how a head's walk ended
-enum : uint32_t { W_OK = 1, W_OPEN = 2, W_EXIT = 3, W_BREAK = 4, W_STATUS = 7u, W_HADX = 8u, W_LUCKY = 16u, W_NX_SHIFT = 8, W_ONPATH = 1u << 16 };
+enum : uint32_t { W_OK = 1, W_OPEN = 2, W_EXIT = 3, W_BREAK = 4, W_STATUS = 7u, W_HADX = 8u, W_LUCKY = 16u, W_NX_SHIFT = 8, W_ONPATH = 1u << 12 };
 
 template <int NCH>
 struct CoopLds {
 	uint32_t mbits[64 * NCH + 4]; // mismatch bits of the window, bit (x - wbase); the words behind it stay 0: nothing known there
-	uint32_t ebits[64 * NCH];     // the stretches behind the heads the chain came by, [head, landing): counted as gaps -- except
+	union {
+		uint32_t q2[128 * NCH + 4]; // the window's query symbols as 2-bit codes, 16 per word, symbol k of a word at bits 2k, 2k + 1: for the walks;
+		uint32_t ebits[64 * NCH];   // once they are done: the stretches behind the heads the chain came by, [head, landing): counted as gaps -- except
+	};
 	uint32_t kpos[COOP_KCAP];     // those that start at one of these positions (the walk met anchors off the diagonal): counted nowhere
 	uint32_t nhadx;               // walks of the window that ended that way (at most COOP_KCAP: the others give up)
-	uint32_t ha[COOP_HCAP];       // landing position of the head's walk
-	uint32_t hlen[COOP_HCAP];     // length of the anchor there (W_LUCKY: not known yet)
-	uint32_t hflag[COOP_HCAP];
-	uint16_t hpos[COOP_HCAP];     // the head's position - wbase
-	uint32_t q2[128 * NCH + 4];   // the window's query symbols as 2-bit codes, 16 per word, symbol k of a word at bits 2k, 2k + 1
-	uint32_t pl[64], pp[64];      // the block of probes of mode G: length | unique << 31, position
+	union {
+		struct {
+			uint32_t hend[COOP_HCAP]; // from the walk: length of the anchor it landed on (W_LUCKY: not known yet); then: where that anchor ends
+			uint16_t ha[COOP_HCAP];   // landing position of the head's walk - wbase
+			uint16_t hflag[COOP_HCAP];
+			uint16_t hpos[COOP_HCAP]; // the head's position - wbase
+		};
+		struct {
+			uint32_t pl[64], pp[64]; // mode G (no window open): the block of probes, length | unique << 31, position
+		};
+	};
 	uint32_t hist[16];
 };
 
@@ -430,13 +438,15 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	if (lane < 4) L.q2[128 * NCH + lane] = 0;
 	if (lane == 0) L.nhadx = 0;
 	if (lane < 4) L.mbits[64 * NCH + lane] = 0;
+	ch.blk_base = NOPOS; // (mode G's block of probes lies where the heads are about to be listed)
 	wave_sync();
 
 	TOCK(tph, PH_STREAM);
 	// ---- heads: a mismatch with fewer than thr equal symbols behind it and at least thr before it.  Lane l looks
 	// at the NCH words of positions 32 NCH l ...; a word together with its neighbours, thr < 32
-	uint32_t nh = 0;
-	for (uint32_t j = 0; j < (uint32_t)NCH; ++j) {
+	uint32_t hmask[NCH], nh = 0;
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) {
 		const uint32_t w = NCH * lane + j;
 		const uint32_t cur = L.mbits[w], nxt = L.mbits[w + 1], prv = w ? L.mbits[w - 1] : 0u;
 		// a mismatch among the next thr positions / among the thr positions before: smear the bits over thr - 1 more
@@ -450,9 +460,8 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		const uint32_t x0 = wbase + 32 * w;
 		if (x0 + 1 >= end) live = 0;
 		else if (end - 1 - x0 < 32) live = (1u << (end - 1 - x0)) - 1u;
-		const uint32_t hm = cur & soon & ~before & live;
-		L.ebits[w] = hm; // (parked there: the stretches are set much later, and the words are cleared below)
-		nh += (uint32_t)__builtin_popcount(hm);
+		hmask[j] = cur & soon & ~before & live;
+		nh += (uint32_t)__builtin_popcount(hmask[j]);
 	}
 	uint32_t hbase = nh; // exclusive prefix sum over the lanes
 #pragma unroll
@@ -463,19 +472,16 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	const uint32_t nheads_all = uni((uint32_t)__shfl((int)hbase, 63));
 	hbase -= nh;
 	uint32_t dropped = NOPOS; // the first head beyond the list's capacity: nothing is decided from there on
-	for (uint32_t j = 0; j < (uint32_t)NCH; ++j) {
-		const uint32_t w = NCH * lane + j;
-		uint32_t hm = L.ebits[w];
-		L.ebits[w] = 0;
-		for (; hm; hm &= hm - 1) {
-			const uint32_t off = 32 * w + (uint32_t)__builtin_ctz(hm);
+#pragma unroll
+	for (int j = 0; j < NCH; ++j)
+		for (uint32_t hm = hmask[j]; hm; hm &= hm - 1) {
+			const uint32_t off = 32 * (NCH * lane + j) + (uint32_t)__builtin_ctz(hm);
 			if (hbase < COOP_HCAP)
 				L.hpos[hbase] = (uint16_t)off;
 			else if (dropped == NOPOS)
 				dropped = wbase + off;
 			++hbase;
 		}
-	}
 	const uint32_t nheads = nheads_all < COOP_HCAP ? nheads_all : COOP_HCAP;
 	CSTAT(CS_WINDOWS, 1);
 	CSTAT(CS_HEADS, nheads);
@@ -617,7 +623,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			if (res) {
 				if ((res & W_LUCKY) && (ra + sd < c.border) != (e + sd <= c.border)) res = W_BREAK;
 				if ((res & W_STATUS) == W_OK && (res & W_HADX) && atomicAdd(&L.nhadx, 1u) >= COOP_KCAP) res = W_BREAK; // (the list of such stretches is full)
-				L.ha[hk] = ra, L.hlen[hk] = rlen, L.hflag[hk] = res;
+				L.ha[hk] = (uint16_t)(ra - wbase), L.hend[hk] = rlen, L.hflag[hk] = (uint16_t)res;
 				hk = NOPOS;
 			}
 		}
@@ -625,6 +631,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	wave_sync();
 
 	TOCK(tph, PH_WALKS);
+	for (uint32_t jw = 0; jw < (uint32_t)NCH; ++jw) L.ebits[NCH * lane + jw] = 0; // (the walks are done with the query codes that lay there)
 	// ---- the chain hops from head to head; between them every mismatch is followed by a lucky anchor.
 	// Nearly every head is on the chain's path and is followed by the next one: the lanes work out, head by head,
 	// where its walk's anchor ends and whether anything is unusual about it (the next head lies inside the walk's
@@ -649,14 +656,14 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		const uint32_t pos = valid ? wbase + L.hpos[k] : NOPOS, fl = valid ? L.hflag[k] : 0u;
 		uint32_t endk = NOPOS; // where the anchor the walk landed on ends: the chain's next stand
 		if ((fl & W_STATUS) == W_OK) {
-			const uint32_t la = L.ha[k];
+			const uint32_t la = wbase + L.ha[k];
 			if (fl & W_LUCKY) {
 				const uint32_t o = la - wbase;
 				uint32_t wi = o >> 5, v = L.mbits[wi] & (~0u << (o & 31u));
 				while (v == 0 && wi + 1 < 64 * NCH) v = L.mbits[++wi];
 				if (v) endk = wbase + 32 * wi + (uint32_t)__builtin_ctz(v);
 			} else {
-				endk = la + L.hlen[k];
+				endk = la + L.hend[k];
 			}
 		}
 		const bool hop_ok = endk != NOPOS;
@@ -702,8 +709,8 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			}
 		}
 		if (valid) {
-			L.hlen[k] = endk;
-			if (onpath) L.hflag[k] = fl | W_ONPATH;
+			L.hend[k] = endk;
+			if (onpath) L.hflag[k] = (uint16_t)(fl | W_ONPATH);
 		}
 #ifdef ANDI_COOP_STATS
 		{
@@ -720,8 +727,8 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	wave_sync();
 	// the anchor that ends at cur: the one the last hop landed on, or the one behind the mismatch before cur
 	uint32_t aQ, lw = 1;
-	if (hop != NOPOS && uni(L.hlen[hop]) == cur) {
-		aQ = uni(L.ha[hop]), lw = (uni(L.hflag[hop]) & W_HADX) ? 0u : 1u;
+	if (hop != NOPOS && uni(L.hend[hop]) == cur) {
+		aQ = wbase + uni(L.ha[hop]), lw = (uni(L.hflag[hop]) & W_HADX) ? 0u : 1u;
 	} else {
 		aQ = coop_prev_mismatch(L, wbase, cur) + 1;
 	}
@@ -740,11 +747,11 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			} else {
 				for (uint32_t b2 = 0; b2 < nheads && a_before == NOPOS; b2 += 64) { // a hop that landed right before this head?
 					const uint32_t k2 = b2 + lane;
-					const bool m = k2 < nheads && (L.hflag[k2] & W_ONPATH) && L.hlen[k2] == pk;
+					const bool m = k2 < nheads && (L.hflag[k2] & W_ONPATH) && L.hend[k2] == pk;
 					const uint64_t bm = __ballot(m);
 					if (bm) {
 						const uint32_t kp = b2 + (uint32_t)__builtin_ctzll(bm);
-						a_before = uni(L.ha[kp]), lw_before = (uni(L.hflag[kp]) & W_HADX) ? 0u : 1u;
+						a_before = wbase + uni(L.ha[kp]), lw_before = (uni(L.hflag[kp]) & W_HADX) ? 0u : 1u;
 					}
 				}
 				if (a_before == NOPOS) a_before = coop_prev_mismatch(L, wbase, pk) + 1;
@@ -770,7 +777,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			const uint32_t i = b + lane;
 			const uint32_t fl = i < nheads ? L.hflag[i] : 0u;
 			if (!(fl & W_ONPATH)) continue;
-			const uint32_t o0 = L.hpos[i], o1 = L.ha[i] - wbase; // [o0, o1)
+			const uint32_t o0 = L.hpos[i], o1 = L.ha[i]; // [o0, o1)
 			uint32_t *dst = L.ebits;
 			for (uint32_t wd = o0 >> 5; 32 * wd < o1; ++wd) {
 				uint32_t m = ~0u;
@@ -978,7 +985,7 @@ int andi_coop_enabled(void) { // ANDI_COOP=0: never; n = 2, 4, 8, 16: pass A wit
 	const char *e = getenv("ANDI_COOP");
 	if (!e) return -4;
 	const int v = atoi(e);
-	return v == 2 || v == 4 || v == 8 || v == 16 ? v : (v == 0 ? 0 : 4);
+	return v == 2 || v == 4 || v == 8 ? v : (v == 0 ? 0 : 4);
 }
 
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one segment length for the call, RAW/JC/Kimura
@@ -987,7 +994,6 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 	switch (nch < 0 ? -nch : nch) {
 		case 2: k_coop_cold<2><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 		case 8: k_coop_cold<8><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
-		case 16: k_coop_cold<16><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 		default: k_coop_cold<4><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 	}
 #ifdef ANDI_COOP_STATS
