@@ -811,10 +811,15 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	for (size_t s = 0; s < nsub && coop_ok; ++s)
 		if (!subjects[s] || subjects[s]->thr < 2 || subjects[s]->thr > 30) coop_ok = 0;
 	const int coop = coop_ok && coop_mode > 0;
-	uint32_t coop_seg = 32768; // a wavefront needs far fewer chains in flight than a lane: long segments
+	// A wavefront needs far fewer chains in flight than a lane, and every segment costs it a cold start of a dozen
+	// dependent round trips: segments as long as leave the device four rounds of wavefronts (24576), 32768 ... 524288
+	// symbols (measured: bench set 5.57 / 5.39 / 5.31 / 5.34 ms at 32768 / 65536 / 131072 / 262144, C4 shape 38.6 / 33.5 /
+	// 32.6 / 32.6 / 35.4 / 44.0 ms at 32768 / 131072 / 262144 / 524288 / 2^20 / 2^21 -- whole queries: pairs differ too much)
+	uint32_t coop_seg = 524288;
+	while (coop_seg > 32768 && q->total_nt * (uint64_t)nsub / coop_seg < 24576) coop_seg /= 2;
 	if (const char *cs = getenv("ANDI_COOP_SEG")) // experiments
 		if (atoi(cs) >= 64) coop_seg = (uint32_t)atoi(cs);
-	bool coop_trial = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub / coop_seg >= (1u << 14) &&
+	bool coop_trial = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub / 32768 >= (1u << 14) &&
 					  !getenv("ANDI_UNIFORM_SEGMENTS") && !getenv("ANDI_FORCE_ADAPTIVE");
 	if (coop_trial && ctx->coop_backoff) --ctx->coop_backoff, coop_trial = false;
 	const bool want_adaptive = !coop && segment == 0 && andi_scan_group() == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&

@@ -908,7 +908,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 6 : 4) void k_coop_cold
 		CSTAT(CS_G_STEPS, 1);
 		++my_g;
 		if (a.coop_abort) {
-			if (my_g > COOP_TRIAL_G) return give_up();
+			if (my_g > COOP_TRIAL_G + (a.seg >> 12)) return give_up(); // (a few more per window the segment holds)
 			if (given_up()) return;
 		}
 		// ---- one step of mode G (src/process.c:153-197)
