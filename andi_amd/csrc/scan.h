@@ -137,6 +137,8 @@ hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStr
 #endif
 static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at the front, defer_count at 8, ANDI_STRAGGLERS at 12, ANDI_QUAD_WAVES at 13");
 #define ANDI_QUAD_WAVES 13 /* restitch_count[this] during pass A: wavefronts on k_lane_quad's list */
+#define ANDI_SPARSE_WAVES 14 /* restitch_count[this] during pass A: wavefronts of pairs whose sampled mean match is below ANDI_SPARSE_MATCH */
+#define ANDI_SPARSE_MATCH 19u
 #define ANDI_STRAGGLERS 12 /* restitch_count[this]: replays of the call so far that went past ANDI_STITCH_FIRST steps */
 #ifndef ANDI_STITCH_BUDGET
 #define ANDI_STITCH_BUDGET 48

@@ -891,7 +891,9 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 6 : 4) void k_coop_cold
 	if (a.coop_abort) {
 		// a call whose pairs mostly have long matches (a quarter of the layout's wavefronts on k_lane_quad's list) is the
 		// lane scan's: its two kernels stream such pairs faster than the windows here
-		if (a.coop_classes && 4 * a.restitch_count[ANDI_QUAD_WAVES] > a.pair_wave0[a.nsub * a.nq]) return give_up();
+		// (so is one of pairs so far apart that matches hardly reach the anchor threshold: their true and cold chains
+		// meet slowly, and with long segments pass B has few lanes to take those replays)
+		if (a.coop_classes && 4 * (a.restitch_count[ANDI_QUAD_WAVES] + a.restitch_count[ANDI_SPARSE_WAVES]) > a.pair_wave0[a.nsub * a.nq]) return give_up();
 		if (given_up()) return;
 	}
 	if (lane < 16) L.hist[lane] = 0;

@@ -76,6 +76,9 @@ __global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
 		// bit 7: the pair's matches are long enough for pass A with the streams fetched by quads (k_lane_quad)
 		a.pair_class[pair] = (uint8_t)(cls | ((sum >> 6) >= a.quad_min_match && !islands ? 0x80u : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
+		// pairs whose matches hardly reach the anchor threshold (divergence beyond some 6 %): their chains probe at nearly
+		// every step and meet their neighbours' slowly -- pass A by wavefronts (scan_coop.hip) leaves calls of such pairs alone
+		if ((sum >> 6) < ANDI_SPARSE_MATCH) atomicAdd(&a.restitch_count[ANDI_SPARSE_WAVES], (nseg + 63) / 64);
 	}
 }
 
@@ -1088,7 +1091,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
 	const uint32_t P = a.nsub * a.nq;
-	(void)hipMemsetAsync(a.restitch_count + ANDI_QUAD_WAVES, 0, sizeof(uint32_t), st); // k_lane_quad's list is empty
+	(void)hipMemsetAsync(a.restitch_count + ANDI_QUAD_WAVES, 0, 2 * sizeof(uint32_t), st); // k_lane_quad's list is empty (and no pair counted as sparse)
 	k_pair_estimate<<<(P + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	const unsigned nb = (P + 1023) / 1024;
