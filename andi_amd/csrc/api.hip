@@ -1075,6 +1075,14 @@ int andi_hip_bootstrap(andi_hip_ctx *ctx, const andi_hip_model *M, size_t n, uin
 	return 0;
 }
 
+int andi_hip_has_experiments(void) {
+#ifdef ANDI_EXPERIMENTS
+	return 1;
+#else
+	return 0;
+#endif
+}
+
 int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t) {
 	if (!ctx || !t) return 1;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

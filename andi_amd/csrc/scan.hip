@@ -620,7 +620,10 @@ hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
 	if (a.lanes) {
 		// RAW, JC, Kimura: in rounds (scan_rounds.hip); LogDet/ANI count every anchor's nucleotides: scan_lane.hip
 		hipError_t e = a.coop ? andi_launch_coop_cold(a, st)
-							  : (!a.exact_equal && andi_rounds_lines()) ? andi_launch_rounds_cold(a, st) : andi_launch_lane_cold(a, st);
+#ifdef ANDI_EXPERIMENTS
+							  : (!a.exact_equal && andi_rounds_lines()) ? andi_launch_rounds_cold(a, st)
+#endif
+							  : andi_launch_lane_cold(a, st);
 		if (e != hipSuccess || !a.any_reference) return e;
 		DISPATCH_G(launch_cold, SCAN_G, false)
 	}

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(1024) void k_pair_offsets(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------ pass A
+#ifdef ANDI_EXPERIMENTS /* measured slower, kept for the record (make experiments) */
 // Pass A with the chain step cut in two, so that the lanes of a wavefront do the same thing at the same
 // time: every trip of the loop a lane that is ON A DIAGONAL (lucky_anchor's precondition holds,
 // src/process.c:86-92) takes the next window of that diagonal and settles every anchor and mismatch inside
@@ -250,6 +251,8 @@ __device__ __forceinline__ void lane_cold_stream(const ScanArgs &a, const LaneIt
 	for (int t = 0; t < 4; ++t) dst[t] = make_uint4(out[4 * t], out[4 * t + 1], out[4 * t + 2], out[4 * t + 3]);
 }
 
+#endif // ANDI_EXPERIMENTS
+
 __device__ __forceinline__ uint32_t dpp_quad_floor(uint32_t v, int ctrl) { // quad_perm: broadcast lane `ctrl`, or lane ^ 1 (4), lane ^ 2 (5)
 	switch (ctrl) {
 		case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true);
@@ -261,6 +264,7 @@ __device__ __forceinline__ uint32_t dpp_quad_floor(uint32_t v, int ctrl) { // qu
 	}
 }
 
+#ifdef ANDI_EXPERIMENTS
 __device__ __forceinline__ void quad_transpose_floor(uint4 (&R)[4], uint32_t qi) { // R[r] of quad lane i <- R[i] of quad lane r
 	auto sel = [](bool c, const uint4 &a, const uint4 &b) { return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); };
 	auto dpp4 = [](const uint4 &v, int ctrl) {
@@ -346,6 +350,8 @@ __global__ __launch_bounds__(BLOCK, 6) void k_stream_floor(ScanArgs a, int varia
 	for (int t = 0; t < 16; ++t) dst[t] = tally.hist[t * BLOCK];
 	a.marks[it.slot * ANDI_COLD_MARKS].st.pad[0] = 0;
 }
+
+#endif // ANDI_EXPERIMENTS
 
 __device__ __forceinline__ bool pos_in(const LWin &w, uint32_t p) {
 	return w.q0 != EMPTY && p >= w.q0 && p - w.q0 < WNT;
@@ -602,6 +608,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_quad(ScanArgs a) { // (4 wave
 	lane_cold_quad<EXACT>(a, it, s_hist, s_stage);
 }
 
+#ifdef ANDI_EXPERIMENTS
 template <bool EXACT, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void k_lane_stream(ScanArgs a) {
 	__shared__ uint32_t s_hist[16 * BLOCK];
@@ -610,6 +617,8 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_stream(ScanArgs a) {
 	if (!__any(it.valid)) return;
 	lane_cold_stream<EXACT>(a, it, s_hist);
 }
+
+#endif // ANDI_EXPERIMENTS
 
 // The lanes of a wavefront take consecutive segments of one query, so they see the
 // same divergence and stay in step.  (Persistent lanes that fetch their next segment
@@ -1024,10 +1033,12 @@ template <bool EXACT>
 static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	const char *pe = getenv("ANDI_LANE_LDS_PAD"); // experiments: unused LDS per block, limits the resident wavefronts
 	const size_t pad = pe ? (size_t)atoi(pe) : 0;
+#ifdef ANDI_EXPERIMENTS
 	if (const char *fl = getenv("ANDI_FLOOR")) { // diagnostic: the cost of the bare streams (wrong results)
 		k_stream_floor<<<grid, BLOCK, 0, st>>>(a, atoi(fl));
 		return hipGetLastError();
 	}
+#endif
 	if (getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) == 2) { // experiments: everything through the quads
 		ScanArgs b = a;
 		b.quad_all = 1;
@@ -1035,6 +1046,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 		k_lane_quad<EXACT><<<grid, BLOCK, 0, st>>>(b);
 		return hipGetLastError();
 	}
+#ifdef ANDI_EXPERIMENTS
 	const bool stream = getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) != 0; // measured slower: an experiment
 	if (stream) { // (k_lane_stream knows no classes: it takes every pair)
 		switch (lane_occupancy(false)) {
@@ -1043,6 +1055,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 		}
 		return hipGetLastError();
 	}
+#endif
 	const bool blocks4 = getenv("ANDI_QUAD_UNLISTED") != nullptr; // (experiments: k_lane_quad's wavefronts in the call's order)
 	const bool quads = a.adaptive && a.quad_min_match != 0xffffffffu;
 	const bool side = quads && a.side_stream && !getenv("ANDI_NO_SIDE_STREAM");

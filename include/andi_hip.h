@@ -228,6 +228,8 @@ typedef struct {
 	uint64_t coop_calls;     /* scan calls whose pass A ran with one wavefront per chain (scan_coop.hip) */
 	uint64_t coop_fallbacks; /* ... that tried it and fell back to one lane per chain (long matches, stretches without homology) */
 } andi_hip_timings;
+/* 1 in a build that carries the pass A variants kept for the record (make -C andi_amd/csrc experiments), else 0 */
+int andi_hip_has_experiments(void);
 int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t);
 void andi_hip_timings_reset(andi_hip_ctx *ctx);
 

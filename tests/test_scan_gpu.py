@@ -343,7 +343,10 @@ def test_pass_a_in_rounds_agrees(ctx, orc, monkeypatch, lines):
     wavefront in one place, the streams through line buffers in LDS, probe-table entries that carry the
     symbols behind a K-mer that occurs once.  Same counts, whatever the buffers' sizes and however often
     the wavefront goes to memory."""
+    import andi_amd
     from andi_amd import synth
+    if not andi_amd.lib.has_experiments():
+        pytest.skip("scan_rounds.hip is in the experiments build only (make -C andi_amd/csrc experiments; ANDI_HIP_LIB)")
     monkeypatch.setenv("ANDI_ROUNDS", lines)
     rng = np.random.default_rng(6)
     base = synth.base_codes(90000, 13)
@@ -436,7 +439,10 @@ def test_pass_a_variants_agree(ctx, orc, monkeypatch, variant):
     streams fetched by quads of lanes, comparisons resumed trip after trip -- which by default takes only the pairs
     with long matches and only with per-pair segment lengths (here also with one segment length for the call, where
     the lanes of a quad belong to different queries).  Same counts."""
+    import andi_amd
     from andi_amd import synth
+    if variant == "1" and not andi_amd.lib.has_experiments():
+        pytest.skip("lane_cold_stream is in the experiments build only (make -C andi_amd/csrc experiments; ANDI_HIP_LIB)")
     monkeypatch.setenv("ANDI_LANE_STREAM", variant)
     seqs, _ = synth.realistic_set(5, 150000, 0.0005, 0.08, seed=5, novel_fraction=0.05)
     seqs.append(seqs[0])  # identical to its subject: one anchor as long as the sequence
