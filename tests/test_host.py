@@ -151,3 +151,69 @@ def test_tree_structured_generator():
         p = float((a[i] != a[j]).mean())
         want = 0.75 - 0.75 * math.exp(-4.0 * D[i, j] / 3.0)
         assert abs(p - want) < 0.15 * want + 1.5e-4, (i, j, p, want)
+
+
+def _patch_text():
+    with open(os.path.join(ROOT, "integration", "andi-hip.patch")) as f:
+        return f.read()
+
+
+def test_integration_snippet_compiles(tmp_path):
+    """integration/andi-hip.patch: the binding a maintainer adds to src/process.c, compiled (syntax and types) against
+    include/andi_hip.h with stand-ins for what the reference's headers give it (struct model, seq_t and the globals,
+    src/model.h:52-57, src/sequence.h:18-29, src/global.h) -- the layout assertion of the snippet holds there too."""
+    import subprocess
+    added = []
+    take = False
+    for line in _patch_text().splitlines():
+        if line.startswith("+++ ") and "process.c" in line:
+            take = True
+        elif line.startswith("+++ "):
+            take = False
+        elif take and line.startswith("+") and not line.startswith("+++"):
+            added.append(line[1:])
+    body = "\n".join(added)
+    assert "distMatrixHIP" in body and "andi_hip_dist_matrix" in body
+    src = r"""
+#define HAVE_ANDI_HIP 1
+#include <stdlib.h>
+#include <stddef.h>
+#include <err.h>
+struct model { unsigned int counts[16]; unsigned int seq_len; };      /* src/model.h:52-57 */
+typedef struct { char *S, *name; size_t len; double gc; } seq_t;      /* the fields the binding reads, src/sequence.h */
+extern double ANCHOR_P_VALUE; extern int MODEL, THREADS, FLAGS;
+enum { F_LOW_MEMORY = 8 };
+#define CHECK_MALLOC(p) do { if (!(p)) err(1, "Out of memory"); } while (0)
+static void distMatrix(struct model *M, const seq_t *s, size_t n) { (void)M; (void)s; (void)n; }
+static void distMatrixLM(struct model *M, const seq_t *s, size_t n) { (void)M; (void)s; (void)n; }
+void calculate_distances_stub(struct model *M, seq_t *sequences, size_t n);
+""" + body.split("#ifdef HAVE_ANDI_HIP\n\tdistMatrixHIP(M, sequences, n);")[0] + r"""
+void calculate_distances_stub(struct model *M, seq_t *sequences, size_t n) {
+#ifdef HAVE_ANDI_HIP
+	distMatrixHIP(M, sequences, n);
+#else
+	if (FLAGS & F_LOW_MEMORY) distMatrixLM(M, sequences, n); else distMatrix(M, sequences, n);
+#endif
+}
+"""
+    f = tmp_path / "snippet.c"
+    f.write_text(src)
+    r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Wno-unused-function", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(f)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "warning" not in r.stderr, r.stderr
+
+
+def test_integration_patch_applies_to_the_reference(tmp_path):
+    """the patch against the upstream tree, where that is mounted (this container; not the GPU box)"""
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "src", "process.c")) or not shutil.which("patch"):
+        pytest.skip("upstream tree not mounted")
+    os.makedirs(tmp_path / "src")
+    shutil.copy(os.path.join(ref, "src", "process.c"), tmp_path / "src" / "process.c")
+    shutil.copy(os.path.join(ref, "configure.ac"), tmp_path / "configure.ac")
+    r = subprocess.run(["patch", "-p1", "-i", os.path.join(ROOT, "integration", "andi-hip.patch")], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = (tmp_path / "src" / "process.c").read_text()
+    assert "distMatrixHIP(M, sequences, n);" in text and "HAVE_ANDI_HIP" in (tmp_path / "configure.ac").read_text()
