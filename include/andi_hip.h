@@ -62,12 +62,12 @@ typedef struct {
 	uint32_t segment;  /* query nucleotides per scan work item; 0 = default */
 	void (*progress)(size_t done, size_t total, void *ud); /* serialised; called from the devices' driver threads */
 	void *ud;
+	int sa_on_host;    /* 0: suffix arrays are built on the device (sa_device.hip); 1: by the host pool
+	                    * (andi_hip_suffix_array), as the reference does with libdivsufsort (src/esa.c:303) */
 	/* The N x N loop is tiled over the GPUs of the node by rows (the parallel loop of
 	 * src/dist_hack.h:46-47): num_gpus devices device, device + 1, ...; 0 or 1 = one device; < 0 = all
 	 * visible devices from `device` on.  Every device owns a contiguous block of subject rows; the row
 	 * blocks are gathered on the first device with RCCL (send/recv over xGMI) and copied to M once. */
-	int sa_on_host;    /* 0: suffix arrays are built on the device (sa_device.hip); 1: by the host pool
-	                    * (andi_hip_suffix_array), as the reference does with libdivsufsort (src/esa.c:303) */
 	int num_gpus;
 	const int *devices; /* optional: exactly these num_gpus ordinals (an ordinal may repeat: several contexts
 	                     * on one device, rows then go to M directly) */
