@@ -32,7 +32,7 @@
 namespace {
 
 #define COOP_HCAP (NCH <= 2 ? 64u : 24u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
-constexpr int COOP_WAVES = 2; // wavefronts per block: each has a window's worth of LDS, small blocks fill a CU more evenly
+constexpr int COOP_WAVES = 1; // wavefronts per block: single wavefronts find a place on a CU the moment one leaves (bench set 5.39 -> 5.24 ms against blocks of two, 5.61 with four); seven per SIMD (72 registers): 4.94
 constexpr uint32_t COOP_KCAP = 32; // stretches of a window that are counted nowhere (more: the window ends before the next one)
 constexpr uint32_t COOP_TRIAL_G = 192;   // on trial: a segment that needs more generic steps than this is in a stretch without homology (clean sets: <= 45)
 constexpr uint32_t COOP_TRIAL_LCP = 16;  // on trial: a match followed through more rounds of 2048 symbols than this is longer than its segment
@@ -868,7 +868,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 
 // ------------------------------------------------------------------ the kernel
 template <int NCH>
-__global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 6 : 4) void k_coop_cold(ScanArgs a) {
+__global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 7 : 4) void k_coop_cold(ScanArgs a) {
 	__shared__ CoopLds<NCH> s_lds[COOP_WAVES];
 	CoopLds<NCH> &L = s_lds[threadIdx.x >> 6];
 	const uint32_t lane = __lane_id();
