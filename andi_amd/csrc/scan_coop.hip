@@ -506,8 +506,11 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			seen = v != 0 && o + r < W;
 			return r;
 		};
-		LWin w;
-		w.q0 = EMPTY, w.dg = NO_DIAG;
+		auto generic_probe = [&](uint32_t pp) { // lane_probe with a window of its own (rare: nothing to keep across the trips)
+			LWin w;
+			w.q0 = EMPTY, w.dg = NO_DIAG;
+			return lane_probe(c, pp, w);
+		};
 		for (;;) {
 			const uint64_t idle = __ballot(hk == NOPOS);
 			if (idle && next_head < nheads) {
@@ -537,7 +540,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 					const uint32_t r = run_ahead(p, seen);
 					have = coop_probe_multi(c, p, sd, mx, mn, mq, r, seen, pr, long_diag);
 				}
-				if (!have) pr = lane_probe(c, p, w), long_diag = false;
+				if (!have) pr = generic_probe(p), long_diag = false;
 				have = true, parked = false;
 #ifdef ANDI_COOP_STATS
 				atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
@@ -548,7 +551,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 						res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
 						ra = p;
 					} else {
-						pr = lane_probe(c, p, w); // (the window's end)
+						pr = generic_probe(p); // (the window's end)
 					}
 				}
 			} else if (p >= end) {

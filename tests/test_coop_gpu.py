@@ -116,3 +116,43 @@ def test_trial_on_a_large_clean_call_and_fallback_on_a_structured_one():
     got, t = _rows(real, {})
     assert (t["coop_calls"], t["coop_fallbacks"]) == (0, 1), t
     assert (got == lane).all()
+
+
+def test_ragged_rows_thresholds_and_windows_full_of_heads():
+    """The wavefront kernel forced on what the trial would not pick: a C4-shaped call of ragged short genomes (hundreds
+    of queries per subject: extended probe-table entries), anchor thresholds from other significance levels, and pairs
+    so far apart that a window lists more heads than it has room for (the window then ends at the first one dropped)."""
+    rng = np.random.default_rng(7)
+    base = synth.base_codes(30000, 3)
+    seqs = []
+    for k in range(300):
+        codes = synth.mutate_codes(base, float(rng.uniform(0.001, 0.02)), 100 + k)
+        seqs.append(synth.to_bytes(codes[: int(30000 * (1.0 - 0.3 * rng.random()))]))
+    subjects = [0, 7, 150, 299]
+    want = np.stack([orc.scan_row(orc.OracleEsa(seqs[i]), seqs, i, orc.M_JC, threads=0) for i in subjects])
+    os.environ["ANDI_COOP"] = "4"
+    try:
+        ctx = andi_amd.Context(0)
+        ctx.expect_queries(len(seqs) - 1)
+        Q = andi_amd.Queries(ctx, seqs)
+        esas = [andi_amd.Esa(ctx, seqs[i]) for i in subjects]
+        got = andi_amd.scan_rows(ctx, esas, subjects, Q)
+        assert ctx.timings()["coop_calls"] == 1
+        for e in esas:
+            e.close()
+        Q.close()
+        ctx.close()
+    finally:
+        del os.environ["ANDI_COOP"]
+    assert (got == want).all(), np.argwhere((got != want).any(axis=2))[:5]
+    a, b = synth.pair(200000, 0.08, seed=21)
+    c = synth.to_bytes(synth.mutate_codes(synth.base_codes(200000, 21), 0.25, 5))
+    for p_value in (0.025, 0.3, 1e-6):
+        want = orc.dist_matrix([a, b, c], p_value=p_value, model=orc.M_RAW, threads=3)
+        for coop in (2, 8):
+            os.environ["ANDI_COOP"] = str(coop)
+            try:
+                got = andi_amd.dist_matrix([a, b, c], p_value=p_value, model=andi_amd.M_RAW)
+            finally:
+                del os.environ["ANDI_COOP"]
+            assert (got == want).all(), (p_value, coop)
