@@ -1342,6 +1342,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		andi_hip_ctx *prep = nullptr; // uploads, suffix arrays, index builds
 		andi_hip_queries *Q = nullptr;
 		andi_hip_model *d_rows = nullptr; // rccl: the whole row block; direct: one batch of rows
+		char *pinned = nullptr;           // staging buffer for RS: uploads from pinned memory go through the DMA engines, beside a scan
 		std::vector<andi_hip_esa *> slots; // sets x batch
 	};
 	std::vector<Dev> dv(ndev);
@@ -1377,18 +1378,23 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
 				const size_t per_slot = 10 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap, D.ctx->queries_hint))) + (1 << 20);
-				while (batch > 1 && 2 * batch * per_slot > free_b / (2 * ndev)) batch /= 2;
+				while (batch > 1 && 3 * batch * per_slot > free_b / (2 * ndev)) batch /= 2;
 			}
 		}
 		if (batch > rows) batch = rows;
 		const size_t nbatches = (rows + batch - 1) / batch;
-		const size_t sets = (nbatches > 1 && !o.low_memory) ? 2 : 1; // (low_memory: one index resident at a time)
+		// Three sets of slots: while batch k is scanned, batch k + 2 is uploaded (no compute units needed) and batch k + 1
+		// is ready; the device's COMPUTE alternates strictly -- suffix sorts and index builds of batch k + 1, then the scan
+		// of batch k -- because side by side the staging kernels starve behind the workgroups of a scan that fills the
+		// device (sorts of 8 subjects: 6 ms alone, 38 ms beside a scan, on a high-priority stream as on a plain one).
+		const size_t sets = o.low_memory ? 1 : (nbatches > 2 ? 3 : (nbatches > 1 ? 2 : 1)); // (low_memory: one index resident at a time)
 		D.slots.assign(sets * batch, nullptr);
 		if (andi_hip_queries_stage(D.ctx, seqs, n, &D.Q)) return bail("staging queries", D.ctx);
 		lap(t_queries);
 		for (size_t b = 0; b < sets * batch; ++b)
 			if (esa_reserve(D.prep, rs_cap, &D.slots[b])) return bail("allocating subject slots", D.prep);
 		if (andi_hip_sync(D.prep)) return bail("allocating subject slots", D.prep);
+		if (hipHostMalloc((void **)&D.pinned, rs_cap + 1, hipHostMallocDefault) != hipSuccess) D.pinned = nullptr; // (then from where RS lies)
 		if (andi_hip_dev_alloc(D.ctx, (use_rccl ? rows : batch) * n * sizeof(andi_hip_model), (void **)&D.d_rows)) return bail("row buffer", D.ctx);
 		lap(t_slots);
 
@@ -1420,7 +1426,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 				tl = now_ms();
 				const size_t i0 = first[d] + k * batch, nb = std::min(batch, last[d] - i0);
 				andi_hip_esa **set = D.slots.data() + (k % sets) * batch;
-				for (size_t b = 0; b < nb; ++b) {
+				for (size_t b = 0; b < nb; ++b) { // uploads: beside whatever the device computes
 					Prepared *p = take(i0 + b);
 					if (!p) return give_up();
 					plap(p_take);
@@ -1431,10 +1437,10 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 						fail_all(msg);
 						ok = false;
 					}
-					if (ok && esa_upload(D.prep, set[b], p->RS, o.sa_on_host ? p->SA.data() : nullptr, p->n, p->thr)) bail("staging subject", D.prep), ok = false;
+					const char *src = p->RS;
+					if (ok && D.pinned) memcpy(D.pinned, p->RS, p->n), src = D.pinned; // (esa_upload waits for the copy: one buffer does)
+					if (ok && esa_upload(D.prep, set[b], src, o.sa_on_host ? p->SA.data() : nullptr, p->n, p->thr)) bail("staging subject", D.prep), ok = false;
 					plap(p_upload);
-					if (ok && !o.sa_on_host && esa_sort_suffixes(D.prep, set[b])) bail("suffix array", D.prep), ok = false;
-					plap(p_sort);
 					andi_hip_free(p->RS);
 					delete p;
 					{
@@ -1443,6 +1449,19 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 					}
 					cv.notify_all();
 					if (!ok) return give_up();
+				}
+				if (sets == 3) { // the device's compute is this batch's once the scan of batch k - 2 is done
+					std::unique_lock<std::mutex> lk(pm);
+					pcv.wait(lk, [&] { return k < scanned + 2 || prep_failed; });
+					if (prep_failed) return;
+					tl = now_ms();
+				}
+				for (size_t b = 0; b < nb && !o.sa_on_host; ++b) {
+					if (esa_sort_suffixes(D.prep, set[b])) {
+						bail("suffix array", D.prep);
+						return give_up();
+					}
+					plap(p_sort);
 				}
 				if (andi_hip_esa_build_index_batch(D.prep, set, nb) || andi_hip_sync(D.prep)) {
 					bail("index build", D.prep);
@@ -1464,7 +1483,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		for (size_t k = 0; k < nbatches && !failed; ++k) {
 			{
 				std::unique_lock<std::mutex> lk(pm);
-				pcv.wait(lk, [&] { return prepared > k || prep_failed; });
+				pcv.wait(lk, [&] { return (prepared > k && (sets < 3 || prepared > k + 1 || prepared == nbatches)) || prep_failed; });
 				if (prepared <= k) break; // (the staging thread has reported why)
 			}
 			lap(acc_wait);
@@ -1595,6 +1614,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			if (e) andi_hip_esa_free(D.ctx, e);
 		if (D.d_rows) andi_hip_dev_free(D.ctx, D.d_rows);
 		if (D.Q) andi_hip_queries_free(D.ctx, D.Q);
+		if (D.pinned) (void)hipHostFree(D.pinned);
 		if (D.prep) andi_hip_ctx_destroy(D.prep);
 		andi_hip_ctx_destroy(D.ctx);
 	}
