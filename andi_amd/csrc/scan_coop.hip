@@ -554,53 +554,44 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 						pr = generic_probe(p); // (the window's end)
 					}
 				}
-			} else if (p >= end) {
-				res = Xl ? W_BREAK : W_EXIT;
-			} else if (p - wbase >= W) {
-				res = Xl ? W_BREAK : W_OPEN; // the walk has left the window
-			} else if (Xl == 0) {
-				if (p + sd < n && p - e <= thr) { // lucky_anchor applies on the diagonal: the bits answer
-					bool seen;
-					const uint32_t r = run_ahead(p, seen);
-					if (seen) { // a mismatch of the window ends the run (r < 32: thr < 32)
-						if (r >= thr) res = W_OK | W_LUCKY, ra = p;
-					} else if (wbase + W - p >= thr) { // thr equal symbols and more: an anchor; where it ends is settled later
-						res = W_OK | W_LUCKY, ra = p;
-					} else {
-						res = W_OPEN;
+			} else {
+				// ---- a lane that is not parked: the step's conditions as values, few branches (a wavefront executes every
+				// branch some lane takes, and keeps the books of the execution mask for each: the nested form of this cost
+				// 230 vector and 260 scalar instructions per trip)
+				const uint32_t o = p - wbase;
+				const bool inwin = p < end && o < W;
+				bool seen;
+				const uint32_t r = run_ahead(inwin ? p : wbase, seen); // equal symbols from p on along the diagonal
+				const uint32_t left = W - (inwin ? o : 0u);             // positions of the window from p on
+				const bool near = Xl == 0 && p + sd < n && p - e <= thr; // lucky_anchor applies on the diagonal: the bits answer
+				const bool run_ok = seen ? r >= thr : left >= thr;      // an anchor (not seen: thr equal symbols and more, its end is settled later)
+				res = !inwin ? (Xl ? W_BREAK : (p >= end ? W_EXIT : W_OPEN)) // (the walk has left the segment / the window)
+					  : (near && run_ok) ? (W_OK | W_LUCKY)
+					  : (near && !seen && left < thr) ? W_OPEN : 0u;
+				ra = p;
+				if (inwin && Xl) { // lucky_anchor on the diagonal of the anchor off the window's: compare (rare)
+					const uint32_t adv = p - Xq;
+					if (Xs + adv < n && adv - Xl <= thr) {
+						const uint32_t qa = p & ~1u;
+						const uint4 d = neq32(ld_query(c, qa), ld_subject_guarded(c, (int64_t)qa + ((int64_t)Xs - (int64_t)Xq)));
+						uint32_t l = first_from(d, p & 1u) - (p & 1u);
+						if (l > c.qlen - p) l = c.qlen - p;
+						if (l >= thr) res = W_BREAK; // the chain really changes its diagonal: not this window's business
 					}
 				}
-			} else { // lucky_anchor on the diagonal of the anchor off the window's: compare
-				const uint32_t adv = p - Xq;
-				if (Xs + adv < n && adv - Xl <= thr) {
-					const uint32_t qa = p & ~1u;
-					const uint4 d = neq32(ld_query(c, qa), ld_subject_guarded(c, (int64_t)qa + ((int64_t)Xs - (int64_t)Xq)));
-					uint32_t l = first_from(d, p & 1u) - (p & 1u);
-					if (l > c.qlen - p) l = c.qlen - p;
-					if (l >= thr) res = W_BREAK; // the chain really changes its diagonal: not this window's business
-				}
-			}
-			if (!res && !have) {
-				bool on_diag;
-				have = coop_probe_fast<NCH>(c, L, wbase, clean, p, sd, pr, on_diag, mx, mn, mq);
-				if (!have) parked = true; // (the lucky attempt above has failed or does not apply: it is not repeated)
-				if (on_diag) { // the K-mer's one occurrence is the diagonal's: the bits know the match
-					bool seen;
-					const uint32_t r = run_ahead(p, seen);
-					pr.unique = true, pr.pos = p + sd, pr.len = r;
-					if (!seen) { // longer than the bits at hand show: an anchor (thr < 32) whose end is settled later -- if 32 bits were at hand
-						if (wbase + W - p >= 32) {
-							const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
-							res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
-							ra = p;
-						} else {
-							have = false, parked = true; // (the window's end: lane_probe follows the occurrence)
-						}
+				if (inwin && !res) { // the probe (the lucky attempt has failed or does not apply: it is not repeated)
+					bool on_diag;
+					have = coop_probe_fast<NCH>(c, L, wbase, clean, p, sd, pr, on_diag, mx, mn, mq);
+					if (on_diag) { // the K-mer's one occurrence is the diagonal's: the bits know the match
+						pr.unique = true, pr.pos = p + sd, pr.len = r;
+						if (!seen && left < 32) have = false; // (the window's end: lane_probe follows the occurrence)
+						else if (!seen) rlen = NOPOS;         // longer than the bits at hand show: an anchor (thr < 32) whose end is settled later
 					}
-				}
+					parked = !have;
 #ifdef ANDI_COOP_STATS
-				if (have) atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
+					if (have) atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
 #endif
+				}
 			}
 			if (!res && have) {
 				if (pr.unique && pr.len >= thr) {
@@ -610,7 +601,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 						if (!same_side || (Xl && Xl >= 2 * thr))
 							res = W_BREAK;
 						else
-							res = W_OK | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT), ra = p, rlen = pr.len;
+							res = W_OK | (rlen == NOPOS ? W_LUCKY : 0u) | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT), ra = p, rlen = rlen == NOPOS ? 0u : pr.len;
 					} else {
 						const uint32_t endS = Xs + Xl, endQ = Xq + Xl;
 						if (Xl && ((pr.pos > endS && p - endQ == pr.pos - endS && (pr.pos < c.border) == (Xs < c.border)) || Xl >= 2 * thr))
