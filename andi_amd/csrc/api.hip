@@ -886,7 +886,6 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	HIP_TRY(ctx, hipEventRecord(ctx->desc_done, ctx->stream));
 
 	if (any_reference) coop_trial = false;
-	if (coop_trial && ensure_segmentation(ctx, q, coop_seg, true)) return 1;
 	// scratch: per (subject, segment) two states and two count vectors
 	bool adaptive = want_adaptive && !any_reference;
 	uint32_t seg0 = segment / 2; // classes: 1/2, 1, 2, 4 times the call's segment length
@@ -911,6 +910,10 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		if (!fits || (10 * used < 7 * 64 * max_waves && !getenv("ANDI_FORCE_ADAPTIVE"))) adaptive = false, max_waves = 0;
 	}
 	const size_t pairs_all = nsub * q->nq;
+	// (the trial wants the pairs' sampled classes -- k_pair_estimate runs for the per-pair layout only: calls that do not
+	// get that layout keep the lane scan)
+	if (!adaptive) coop_trial = false;
+	if (coop_trial && ensure_segmentation(ctx, q, coop_seg, true)) return 1;
 	size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
 	if (coop_trial && slots < nsub * (size_t)q->c_total_segs) slots = nsub * (size_t)q->c_total_segs; // (both layouts carve the same scratch)
 	const size_t need = slots * ANDI_SLOT_BYTES + 128 +
