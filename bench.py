@@ -115,28 +115,33 @@ def workload_name(kind, G, S, length, dlo, dhi, seed, world):
     """what the set really is: the C2 name only for C2's shape (29 genomes of 4.9 Mbp per GPU tile)"""
     import andi_amd.shard as shard
     c2 = length == 4_900_000 and G == shard.weak_scaling_set_size(world) and (kind != "star" or (dlo, dhi) == (0.0004, 0.03))
+    c4 = kind == "star" and G == 3085 and length == 2_100_000  # BASELINE's config 3 as synthetic data (SURVEY.md 8d: C4-synth)
     tag = {"star": "synth", "realistic": "realistic", "tree": "tree"}[kind]
     what = {"star": "d~U[%g,%g] from a common base (star)" % (dlo, dhi),
             "realistic": "d~U[%g,%g] from a common base, with repeats, indels, inversions, 10%% unrelated sequence" % (dlo, dhi),
             "tree": "substitutions along a random tree, pairwise d 4.4e-4 ... 2.6e-2"}[kind]
     return "%s: %d genomes x %d nt, %s, JC, seed %d; %s rows block-partitioned over %d GPU(s)" % (
-        ("C2-" + tag) if c2 else ("synthetic " + tag + " set"), G, length, what, seed,
+        ("C2-" + tag) if c2 else ("C4-synth" if c4 else "synthetic " + tag + " set"), G, length, what, seed,
         "all" if S == G else "the first %d subject" % S, world)
 
 
-def secondary(kind, args, model, p_value):
-    """The same step on another kind of set (one GPU, after the headline's timed region): structured genomes and the
-    tree-structured variant, reported beside -- never instead of -- the star headline."""
+def secondary(kind, args, model, p_value, G=29, L=None, S=None, dlo=None, dhi=None):
+    """The same step on another set (one GPU, after the headline's timed region): structured genomes, the tree-structured
+    variant, and a call of BASELINE's config 3 (S subject rows of the 3085-genome set: the shape the north_star's target
+    is stated on) -- reported beside, never instead of, the star headline."""
     import andi_amd
     from andi_amd import lib
-    G, L = 29, args.length
-    seqs = make_set(kind, G, L, args.dlo, args.dhi, args.seed)
+    L = L or args.length
+    S = S or G
+    dlo = args.dlo if dlo is None else dlo
+    dhi = args.dhi if dhi is None else dhi
+    seqs = make_set(kind, G, L, dlo, dhi, args.seed)
     ctx = andi_amd.Context(0)
     ctx.expect_queries(G - 1)
     Q = andi_amd.Queries(ctx, seqs)
-    esas = [andi_amd.Esa(ctx, s, p_value, build=False, sa="device") for s in seqs]
-    M = ctx.alloc(G * G * 68)
-    selfs = list(range(G))
+    esas = [andi_amd.Esa(ctx, s, p_value, build=False, sa="device") for s in seqs[:S]]
+    M = ctx.alloc(S * G * 68)
+    selfs = list(range(S))
 
     def step():
         lib.build_indexes(ctx, esas)
@@ -153,9 +158,10 @@ def secondary(kind, args, model, p_value):
     tm = ctx.timings()
     scan_ms = tm["scan_ms"] / max(int(tm["scan_launches"]), 1)
     alg = 2.0 * tm["scan_query_nt"] / max(int(tm["scan_launches"]), 1)
-    out = {"workload": workload_name(kind, G, G, L, args.dlo, args.dhi, args.seed, 1),
-           "pairs_per_s": G * (G - 1) / (el / steps), "ms_per_step": 1e3 * el / steps,
+    out = {"workload": workload_name(kind, G, S, L, dlo, dhi, args.seed, 1),
+           "pairs_per_s": S * (G - 1) / (el / steps), "ms_per_step": 1e3 * el / steps,
            "roofline_frac": alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if scan_ms > 0 else None,
+           "pass_a_kernel": "k_coop_cold" if tm["coop_calls"] >= max(int(tm["scan_launches"]), 1) else "k_lane_cold",
            "index_build_ms": tm["build_ms"] / steps, "scan_cold_pass_ms": tm["scan_ms"] / steps,
            "scan_stitch_reduce_ms": tm["stitch_ms"] / steps, "fixups_per_step": int(tm["fixups"]) // steps}
     ctx.free(M)
@@ -333,7 +339,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload_name(args.set, G, S, args.length, args.dlo, args.dhi, args.seed, world),
                        "genomes": G, "subjects": S, "length": args.length, "model": "JC", "pairs": pairs_total,
-                       "segment": args.segment or ("auto (pass A by wavefronts: 32768 ... 524288 symbols by the size of the call, 131072 for this set)" if tm["coop_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
+                       "segment": args.segment or ("auto (pass A by wavefronts: 32768 ... 524288 symbols by the size of the call)" if tm["coop_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "measured_copy_GBps": copy_gbps,
@@ -403,7 +409,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0 and world == 1 and not args.no_extra and args.set == "star" and not args.subjects:
         out["extra"] = {"realistic": secondary("realistic", args, model, p_value),
-                        "tree_structured": secondary("tree", args, model, p_value)}
+                        "tree_structured": secondary("tree", args, model, p_value),
+                        "c4_shape": secondary("star", args, model, p_value, G=3085, L=2_100_000, S=8, dlo=0.001, dhi=0.015)}
     if rank == 0:
         print(json.dumps(out))
 
