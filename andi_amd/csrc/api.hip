@@ -957,6 +957,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.defer_list = (unsigned long long *)p;
 	p += slots * sizeof(unsigned long long);
 	a.first_pub = (unsigned long long *)p; // (k_lane_quad, per-pair segment lengths only)
+	a.stretch_bad = (uint8_t *)p;          // (pass B: a byte per slot, while first_pub is idle)
 	p += slots * sizeof(unsigned long long);
 	a.adaptive = adaptive ? 1 : 0;
 	a.seg0 = seg0, a.max_waves = (uint32_t)max_waves;

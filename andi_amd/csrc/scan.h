@@ -65,6 +65,7 @@ struct ScanArgs {
 	// k_lane_quad: where a cold chain's first anchor starts at its segment's start, (pos_S << 32 | length), published for
 	// the chain of the segment before it -- in another wavefront -- whose match may run on into it (all ones: none yet)
 	unsigned long long *first_pub;
+	uint8_t *stretch_bad; // pass B, stitching again (k_stitch_heads): the segment's entry was not its predecessor's true exit when the round began (lies in first_pub's memory, idle by then)
 	uint32_t *owned;       // [..][16] counts the true chain adds inside the segment
 	andi_hip_model *M;     // [nsub][nq]
 	unsigned long long *fixups;
@@ -143,11 +144,15 @@ static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at
 #ifndef ANDI_STITCH_BUDGET
 #define ANDI_STITCH_BUDGET 48
 #endif
+#ifndef ANDI_LISTED_LANES
 #define ANDI_LISTED_LANES 2
+#endif
 #ifndef ANDI_LISTED_BLOCKS
 #define ANDI_LISTED_BLOCKS 1024 /* one round of the device at 4 wavefronts per SIMD; 4096: passes B/C 15.5 ms on the realistic set, 1024: 13.3, 512: 13.7 */
 #endif
+#ifndef ANDI_STITCH_TOGETHER
 #define ANDI_STITCH_TOGETHER 40 /* steps of pass B's phase 2 in which the cold chain is replayed beside the true one */
+#endif
 // pass A in rounds with line buffers (scan_rounds.hip); andi_rounds_lines() != 0: in use
 int andi_rounds_lines(void);
 hipError_t andi_launch_rounds_cold(const ScanArgs &a, hipStream_t st);

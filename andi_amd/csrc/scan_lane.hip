@@ -686,13 +686,38 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_lane_cold(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------ pass B
+#ifdef ANDI_LANE_STATS
+__device__ unsigned long long g_stitch_hist[4][16], g_stitch_steps[4], g_stitch_exit[4][8][2], g_stitch_phase[4][8];
+__device__ unsigned int g_stitch_max[4];
+#endif
 // as stitch_segment in scan.hip: the true chain (entering in state T) is replayed next
 // to the segment's cold chain until both are in the same state
 // LISTED: the segments an earlier launch put on the list
-template <bool EXACT, bool AGAIN, bool LISTED>
-__device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &it, uint32_t (*s_hist)[16 * BLOCK]) {
+// One segment, entered by the true chain in state T: what it counts there (owned), the state it leaves in (E, and
+// true_exit) and the entry that was used (used_entry: pass C verifies it against the predecessor's true exit).
+// KIND: 0 first stage, 1 first stage's list, 3 a stretch stitched again (statistics; 1 and 3 have no budget).
+// false: the replay is too long for this launch and was put on the list.
+template <bool EXACT, int KIND>
+__device__ __forceinline__ bool stitch_one(const ScanArgs &a, const LaneItem &it, const PairCtx &c, ChainState T,
+										   uint32_t (*s_hist)[16 * BLOCK], ChainState &E) {
+	constexpr bool LISTED = KIND != 0;
 	const size_t slot = it.slot;
 	uint32_t steps = 0; // chain steps replayed so far
+#ifdef ANDI_LANE_STATS
+	int exit_kind = 0; // 0 left for the list, 1 shortcut, 2 first anchor, 3 mark, 4 met, 5 position, 6 on its own
+	struct StepRec { // (diagnostic builds: how long the replays of each kind of launch are)
+		const uint32_t &s;
+		const int &xk;
+		__device__ ~StepRec() {
+			const int b = s ? 32 - __builtin_clz(s) : 0;
+			atomicAdd(&g_stitch_exit[KIND][xk][0], 1ull);
+			atomicAdd(&g_stitch_exit[KIND][xk][1], (unsigned long long)s);
+			atomicAdd(&g_stitch_hist[KIND][b < 15 ? b : 15], 1ull);
+			atomicAdd(&g_stitch_steps[KIND], (unsigned long long)s);
+			atomicMax(&g_stitch_max[KIND], s);
+		}
+	} step_rec{steps, exit_kind};
+#endif
 	bool early = false;
 	auto over_budget = [&]() { // (not LISTED) too long for this launch: leave it to the listed one
 		if (++steps <= ANDI_STITCH_FIRST || LISTED) return false;
@@ -707,26 +732,6 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 	};
 	const uint32_t *coldCounts = a.cold_counts + slot * 16;
 	uint32_t *owned = a.owned + slot * 16;
-
-	if (it.seg_in_q == 0) { // the first segment's "cold" chain is the true chain
-		if (AGAIN) return;
-		a.true_exit[slot] = a.cold_exit[slot];
-		for (int t = 0; t < 16; ++t) owned[t] = coldCounts[t];
-		return;
-	}
-	PairCtx c = make_ctx(a, it.sub, it.qidx);
-	ChainState T;
-	if constexpr (AGAIN) { // where the true chain of the segment before really left, as far as that is known by now
-		const size_t row = slot - it.seg_in_q;
-		T = a.true_exit[row + entry_source(a, row, it.seg_in_q, it.seg, c.qlen)];
-		T.pad[0] = T.pad[1] = T.pad[2] = 0;
-		if (!LISTED) {
-			if (same_state(T, a.used_entry[slot])) return;
-			atomicAdd(&a.restitch_count[a.restitch_round], 1u);
-		}
-	} else { // assumed entry
-		T = assumed_entry(a, slot - it.seg_in_q, it.seg_in_q, it.seg, c.qlen);
-	}
 	a.used_entry[slot] = T; // verified in pass C
 	ChainState C = cold_state(it.start, (uint32_t)c.E.n);
 	Tally tT, tC;
@@ -736,8 +741,7 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 	w.q0 = EMPTY, w.dg = NO_DIAG;
 	bool found;
 
-	// Phase 1: only the true chain runs, until it is in a state the cold chain was in
-	// right after one of its first anchors (pass A's marks).
+	// pass A's marks: the states the cold chain was in right after its first anchors
 	const ColdMark *marks = a.marks + slot * ANDI_COLD_MARKS;
 	ChainState M[ANDI_COLD_MARKS];
 	uint32_t lastMarkP = 0;
@@ -768,76 +772,143 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 					if (t == 15) v += dq + dr;
 					owned[t] = v;
 				}
-				a.true_exit[slot] = a.cold_exit[slot];
+				a.true_exit[slot] = E = a.cold_exit[slot];
 				STAT(ST_X0);
-				return;
+#ifdef ANDI_LANE_STATS
+				exit_kind = 1;
+#endif
+				return true;
 			}
 		}
 	}
+	// The replay is ONE loop with one place where a chain steps (lane_step is most of this kernel's code, and the lanes
+	// of a wavefront are in different phases of their replays: with a loop per phase a trip of the wavefront went through
+	// up to five copies of it, one after the other).  Its phases:
+	//
 	// Phase 0: the cold chain's first anchor lies far ahead -- the segment starts in a stretch without homology
 	// (an island, an unrelated contig).  Until a chain finds an anchor, and once lucky_anchor's precondition is
 	// gone, its positions depend on its position alone: both chains step (the one behind) until they stand at the
 	// same position; from there the true chain's steps are the cold chain's, so it arrives at the cold chain's
 	// first anchor just as that did and is put there, with its own memory, instead of being replayed through
 	// the stretch.
+	//
+	// Phase 1: only the true chain runs, until it is in a state the cold chain was in right after one of its first
+	// anchors (pass A's marks).  The state right behind the cold chain's FIRST anchor is a mark too, and one that costs
+	// nothing to keep: the cold chain has counted nothing by then (its first anchor is no right anchor and has no anchor
+	// before it to count), and it leaves with last_was_right_anchor clear.  A true chain that finds that anchor from the
+	// same position -- in a stretch without homology the two chains fall in with each other's positions after a few
+	// steps, and chance anchors come every few hundred nucleotides -- and is no right anchor of what it remembers is in
+	// that state: it need not walk on to the cold chain's second anchor.
+	//
+	// Phase 2 (no mark was hit): both chains, the one that is behind steps, until they meet.
+	// Without an anchor ahead of it a chain's positions depend on its position alone (once lucky_anchor's
+	// precondition is gone): when the two chains stand at the same position and the cold chain has found all
+	// the anchors it finds in this segment, the true chain's remaining steps are the cold chain's -- whatever
+	// the two remember.  That settles the segments of a stretch without homology after a few steps.
+	// Chains that have not met after ANDI_STITCH_TOGETHER steps are in a stretch in which they will not soon
+	// (without homology the step lengths hardly vary and the two keep leapfrogging; chance anchors of one are
+	// not the other's): the true chain then runs alone to the segment's end -- half the steps of replaying both.
 	uint32_t foundC = 0; // anchors the replayed cold chain has behind it
 	const ChainState coldExit = a.cold_exit[slot];
 	const uint32_t totalC = coldExit.pad[1], nS = (uint32_t)c.E.n;
-	if (totalC >= 1 && totalC != ANDI_ANCHORS_UNKNOWN) {
-		const uint4 f1 = *(const uint4 *)marks[0].first; // the cold chain's 1st anchor: pos_Q, pos_S, length
-		if (f1.x > T.p + 4 * WNT && !lucky_applies(T, nS, c.thr)) { // (a true chain that comes from an anchor nearby falls in with the marks at once)
-			while (T.p < f1.x && C.p < f1.x) {
-				if (T.p == C.p && !lucky_applies(T, nS, c.thr)) {
-					T.p = f1.x;
-					lane_account<EXACT>(c, T, tT, w, f1.y);
-					T.lastS = f1.y, T.lastQ = f1.x, T.lastLen = f1.z;
-					T.p += f1.z + 1;
-					break;
-				}
-				if (over_budget()) return;
-				const bool stepT = T.p <= C.p;
-				Tally tx = stepT ? tT : tC;
-				ChainState nx = lane_step<EXACT>(c, stepT ? T : C, tx, w, found);
-				if (stepT) {
-					T = nx, tT = tx;
-				} else {
-					C = nx, tC = tx;
-					if (found) ++foundC;
-				}
-				if (found) break; // the true chain found an anchor of its own, or the cold chain its first: go on as usual
-			}
-		}
-	}
-	// The state right behind the cold chain's FIRST anchor is a mark too, and one that costs nothing to keep: the cold
-	// chain has counted nothing by then (its first anchor is no right anchor and has no anchor before it to count), and
-	// it leaves with last_was_right_anchor clear.  A true chain that finds that anchor from the same position -- in a
-	// stretch without homology the two chains fall in with each other's positions after a few steps, and chance
-	// anchors come every few hundred nucleotides -- and is no right anchor of what it remembers is in that state:
-	// it need not walk on to the cold chain's second anchor.
+	const bool knownC = totalC >= 1 && totalC != ANDI_ANCHORS_UNKNOWN;
+	uint4 f1 = make_uint4(0, 0, 0, 0); // the cold chain's 1st anchor: pos_Q, pos_S, length
+	if (knownC) f1 = *(const uint4 *)marks[0].first;
 	ChainState MF = initial_state();
 	bool hasF = false;
-	if (totalC >= 1 && totalC != ANDI_ANCHORS_UNKNOWN) {
-		const uint4 f1 = *(const uint4 *)marks[0].first;
+	if (knownC) {
 		MF.p = f1.x + f1.z + 1, MF.lastS = f1.y, MF.lastQ = f1.x, MF.lastLen = f1.z;
 		hasF = f1.x + f1.z + 1 < it.end; // (an anchor that leaves the segment is the cold exit: nothing to gain)
 		if (hasF && MF.p > lastMarkP) lastMarkP = MF.p;
 	}
+	enum { PH0, PH1, PH2_ENTER, PH2, PH2_ALONE };
+	// (a true chain that comes from an anchor nearby falls in with the marks at once: no phase 0)
+	uint32_t phase = (knownC && f1.x > T.p + 4 * WNT && !lucky_applies(T, nS, c.thr)) ? PH0 : PH1;
 	int hit = -1;
-	if (anyMark || hasF) {
-		for (;;) {
-#pragma unroll
-			for (int k = 0; k < ANDI_COLD_MARKS; ++k)
-				if (hit < 0 && M[k].pad[0] && same_state(T, M[k])) hit = k;
-			if (hit < 0 && hasF && same_state(T, MF)) hit = ANDI_COLD_MARKS;
-			if (hit >= 0 || T.p >= it.end || T.p > lastMarkP) break;
-			if (over_budget()) return;
-			T = lane_step<EXACT>(c, T, tT, w, found);
+	bool synced = false, psynced = false;
+	uint32_t together = 0;
+	for (;;) {
+		// (phase 0 begins whenever its condition comes to hold: a true chain that enters right behind an anchor -- the usual
+		// case -- is past lucky_anchor's precondition after a step or two; left in phase 1 it walked all the way to the
+		// cold chain's first anchor on its own, 55 steps on average for 106 K of the realistic set's listed replays)
+		if (phase == PH1 && knownC && foundC == 0 && f1.x > T.p + 4 * WNT && C.p < f1.x && !lucky_applies(T, nS, c.thr)) phase = PH0;
+		if (phase == PH0) {
+			if (!(T.p < f1.x && C.p < f1.x)) {
+				phase = PH1;
+			} else if (T.p == C.p && !lucky_applies(T, nS, c.thr)) {
+				T.p = f1.x;
+#ifdef ANDI_LANE_STATS
+				atomicAdd(&g_stitch_phase[KIND][6], 1ull);
+#endif
+				lane_account<EXACT>(c, T, tT, w, f1.y);
+				T.lastS = f1.y, T.lastQ = f1.x, T.lastLen = f1.z;
+				T.p += f1.z + 1;
+				phase = PH1;
+			}
 		}
+		if (phase == PH1) {
+			if (anyMark || hasF) {
+#pragma unroll
+				for (int k = 0; k < ANDI_COLD_MARKS; ++k)
+					if (hit < 0 && M[k].pad[0] && same_state(T, M[k])) hit = k;
+				if (hit < 0 && hasF && same_state(T, MF)) hit = ANDI_COLD_MARKS;
+				if (hit >= 0) break;
+				if (T.p >= it.end || T.p > lastMarkP) phase = PH2_ENTER;
+			} else {
+				phase = PH2_ENTER;
+			}
+		}
+		if (phase == PH2_ENTER) {
+			STAT(ST_SEARCH); // (diagnostic builds: segments that reach phase 2)
+			if (M[0].pad[0] && T.p >= M[0].p) { // the cold chain need not be replayed up to its mark
+				C = M[0];
+				foundC = 2;
+				for (int t = 0; t < 16; ++t) tC.hist[t * BLOCK] = marks[0].counts[t];
+			}
+			phase = PH2;
+		}
+		if (phase == PH2) {
+			if (same_state(T, C)) {
+				synced = true;
+				break;
+			}
+			if (together >= ANDI_STITCH_TOGETHER) {
+				phase = PH2_ALONE;
+			} else {
+				if (T.p == C.p && totalC < 255 && foundC == totalC && !lucky_applies(T, nS, c.thr) && !lucky_applies(C, nS, c.thr)) {
+					psynced = true;
+					break;
+				}
+				if (T.p >= it.end) break;
+			}
+		}
+		if (phase == PH2_ALONE && T.p >= it.end) break;
+		if (over_budget()) return false;
+		// who steps: the one that is behind (phases 0 and 2) -- but in phase 2 a cold chain with no anchor left to find is
+		// only needed to learn where the true chain falls in with it, and that cannot happen while the true chain runs on
+		// lucky anchors (through a repeat, where the cold chain would crawl from probe to probe)
+		const bool stepT = phase == PH0 ? T.p <= C.p
+						 : phase == PH2 ? (C.p >= it.end || T.p <= C.p || (totalC < 255 && foundC == totalC && lucky_applies(T, nS, c.thr)))
+						 : true;
+		Tally tx = stepT ? tT : tC;
+#ifdef ANDI_LANE_STATS
+		atomicAdd(&g_stitch_phase[KIND][phase == PH0 ? (stepT ? 0 : 1) : phase == PH1 ? 2 : phase == PH2 ? (stepT ? 3 : 4) : 5], 1ull);
+#endif
+		ChainState nx = lane_step<EXACT>(c, stepT ? T : C, tx, w, found);
+		if (stepT) {
+			T = nx, tT = tx;
+		} else {
+			C = nx, tC = tx;
+			if (found) ++foundC;
+		}
+		if (phase == PH0 && found) phase = PH1; // the true chain found an anchor of its own, or the cold chain its first: go on as usual
+		if (phase == PH2) ++together;
 	}
 	if (hit >= 0) {
 		tally_finish<1>(tT);
 #ifdef ANDI_LANE_STATS
 		if (hit == ANDI_COLD_MARKS) STAT(ST_X1); else STAT(ST_X2);
+		exit_kind = hit == ANDI_COLD_MARKS ? 2 : 3;
 		atomicAdd(&g_lane_stats[ST_X7], (unsigned long long)steps);
 #endif
 		if (hit == ANDI_COLD_MARKS) {
@@ -846,58 +917,12 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 			const uint32_t *markCounts = marks[hit].counts;
 			for (int t = 0; t < 16; ++t) owned[t] = tT.hist[t * BLOCK] + coldCounts[t] - markCounts[t];
 		}
-		a.true_exit[slot] = a.cold_exit[slot];
-		return;
-	}
-
-	// Phase 2 (no mark was hit): both chains, the one that is behind steps, until they meet
-	STAT(ST_SEARCH); // (diagnostic builds: segments that reach phase 2)
-	if (M[0].pad[0] && T.p >= M[0].p) { // the cold chain need not be replayed up to its mark
-		C = M[0];
-		foundC = 2;
-		for (int t = 0; t < 16; ++t) tC.hist[t * BLOCK] = marks[0].counts[t];
-	}
-	// Without an anchor ahead of it a chain's positions depend on its position alone (once lucky_anchor's
-	// precondition is gone): when the two chains stand at the same position and the cold chain has found all
-	// the anchors it finds in this segment, the true chain's remaining steps are the cold chain's -- whatever
-	// the two remember.  That settles the segments of a stretch without homology after a few steps.
-	// Chains that have not met after ANDI_STITCH_TOGETHER steps are in a stretch in which they will not soon
-	// (without homology the step lengths hardly vary and the two keep leapfrogging; chance anchors of one are
-	// not the other's): the true chain then runs alone to the segment's end -- half the steps of replaying both.
-	bool synced = false, psynced = false;
-	for (uint32_t together = 0;; ++together) {
-		if (same_state(T, C)) {
-			synced = true;
-			break;
-		}
-		if (together >= ANDI_STITCH_TOGETHER) {
-			while (T.p < it.end) {
-				if (over_budget()) return;
-				T = lane_step<EXACT>(c, T, tT, w, found);
-			}
-			break;
-		}
-		if (T.p == C.p && totalC < 255 && foundC == totalC && !lucky_applies(T, nS, c.thr) && !lucky_applies(C, nS, c.thr)) {
-			psynced = true;
-			break;
-		}
-		if (T.p >= it.end) break;
-		if (over_budget()) return;
-		// the one that is behind steps -- but a cold chain with no anchor left to find is only needed to learn
-		// where the true chain falls in with it, and that cannot happen while the true chain runs on lucky
-		// anchors (through a repeat, where the cold chain would crawl from probe to probe)
-		const bool stepT = C.p >= it.end || T.p <= C.p || (totalC < 255 && foundC == totalC && lucky_applies(T, nS, c.thr));
-		Tally tx = stepT ? tT : tC;
-		ChainState nx = lane_step<EXACT>(c, stepT ? T : C, tx, w, found);
-		if (stepT) {
-			T = nx, tT = tx;
-		} else {
-			C = nx, tC = tx;
-			if (found) ++foundC;
-		}
+		a.true_exit[slot] = E = a.cold_exit[slot];
+		return true;
 	}
 #ifdef ANDI_LANE_STATS
 	if (synced) STAT(ST_X3); else if (psynced) STAT(ST_X4); else STAT(ST_X5);
+	exit_kind = synced ? 4 : psynced ? 5 : 6;
 	atomicAdd(&g_lane_stats[(synced || psynced) ? ST_X7 : ST_X6], (unsigned long long)steps);
 #endif
 	tally_finish<1>(tT);
@@ -909,17 +934,84 @@ __device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &i
 		owned[t] = v;
 	}
 	if (psynced) T.p = coldExit.p; // same steps from here on, the true chain's own memory
-	a.true_exit[slot] = synced ? coldExit : T;
+	a.true_exit[slot] = E = synced ? coldExit : T;
 	if (!synced && !psynced) atomicAdd(&a.restitch_count[ANDI_RESTITCH_ROUNDS], 1u); // its successor's assumed entry is at stake
+	return true;
 }
 
-template <bool EXACT, bool AGAIN, bool LISTED>
+// first stage: every segment, entered in the state pass B assumes for it (scan_dev.h: assumed_entry)
+template <bool EXACT, bool LISTED>
+__device__ __forceinline__ void stitch_item(const ScanArgs &a, const LaneItem &it, uint32_t (*s_hist)[16 * BLOCK]) {
+	const size_t slot = it.slot;
+	if (it.seg_in_q == 0) { // the first segment's "cold" chain is the true chain
+		const uint32_t *coldCounts = a.cold_counts + slot * 16;
+		uint32_t *owned = a.owned + slot * 16;
+		a.true_exit[slot] = a.cold_exit[slot];
+		for (int t = 0; t < 16; ++t) owned[t] = coldCounts[t];
+		return;
+	}
+	const PairCtx c = make_ctx(a, it.sub, it.qidx);
+	ChainState E;
+	(void)stitch_one<EXACT, LISTED ? 1 : 0>(a, it, c, assumed_entry(a, slot - it.seg_in_q, it.seg_in_q, it.seg, c.qlen), s_hist, E);
+}
+
+// Stitching again.  A segment is BAD if the state it was entered in (used_entry) is not the one the true chain left
+// its predecessor in (true_exit) -- pass C's check.  Bad segments come in stretches: the successor of a segment whose
+// true chain left on its own, stitched again, usually leaves in yet another state, and so on until the chain falls in
+// with a cold chain again (a repeat the true chain crosses on lucky anchors, src/process.c:95-97; the edge of an
+// island).  k_stitch_heads lists the first segment of every stretch; one lane per stretch then stitches it again,
+// segment after segment, each entered in the state the one before was just left in, until a segment is entered in
+// the state that was used for it before.  It stops short of the next stretch's first segment (another lane's), whose
+// entry it may have changed: the next round finds that, or pass C does.  (Rounds that stitched every bad segment with
+// its predecessor's exit as it stood -- one more segment of every stretch per round -- took 3 x 0.9 ms on the realistic
+// set and left 970 segments to pass C.)
+__global__ __launch_bounds__(BLOCK) void k_stitch_heads(ScanArgs a) {
+	if (a.restitch_count[a.restitch_round > 0 ? a.restitch_round - 1 : ANDI_RESTITCH_ROUNDS] == 0) return; // (nothing left on its own / nothing was stitched again: nothing to do)
+	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
+	const LaneItem it = lane_item(a);
+	if (!it.valid) return;
+	bool bad = false, pred_bad = false;
+	if (it.seg_in_q >= 1) bad = !same_state(a.true_exit[it.slot - 1], a.used_entry[it.slot]);
+	if (it.seg_in_q >= 2) pred_bad = !same_state(a.true_exit[it.slot - 2], a.used_entry[it.slot - 1]);
+	a.stretch_bad[it.slot] = bad ? 1 : 0;
+	if (bad && !pred_bad) {
+		a.defer_list[atomicAdd(a.defer_count, 1u)] = (unsigned long long)it.slot;
+		atomicAdd(&a.restitch_count[a.restitch_round], 1u);
+	}
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void stitch_stretch(const ScanArgs &a, LaneItem it, uint32_t (*s_hist)[16 * BLOCK]) {
+	const PairCtx c = make_ctx(a, it.sub, it.qidx);
+	// the segment before `it` is settled: the true chain leaves it in state E; was_bad: it was bad when the round began
+	ChainState E = a.true_exit[it.slot - 1];
+	bool was_bad = true; // (so that the stretch's own first segment is not taken for another's)
+	for (;;) {
+		const bool bad = a.stretch_bad[it.slot] != 0;
+		if (bad && !was_bad) return; // the next stretch's first segment: another lane's
+		if (same_state(E, a.used_entry[it.slot])) {
+			// the chain enters this segment as was assumed (now): what pass B recorded for it holds.  If it was not bad
+			// before either, the stretch ends here (a bad segment further on is another stretch's first); if it was, the
+			// segments behind it are still this lane's: no other looks at them in this round
+			if (!bad) return;
+			E = a.true_exit[it.slot];
+		} else {
+			E.pad[0] = E.pad[1] = E.pad[2] = 0;
+			const ChainState T = E;
+			(void)stitch_one<EXACT, 3>(a, it, c, T, s_hist, E);
+		}
+		if (it.end >= c.qlen) return; // the query's last segment
+		was_bad = bad;
+		it.slot += 1, it.seg_in_q += 1, it.start += it.seg;
+		it.end = it.start + it.seg < c.qlen ? it.start + it.seg : c.qlen;
+	}
+}
+
+// STAGE 0: every segment; 1: the segments stage 0 put on the list; 2: the stretches k_stitch_heads listed
+template <bool EXACT, int STAGE>
 __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) { // (4 wavefronts per SIMD with 30 spilled registers: 1.33 -> 1.25 ms for passes B/C; 5 with 175: 1.78 ms)
 	__shared__ uint32_t s_hist[2][16 * BLOCK];
-	// stitching again is for the successors of segments whose true chain never fell in with the cold one, and then
-	// for the successors of those that were stitched again
-	if (AGAIN && a.restitch_count[a.restitch_round > 0 ? a.restitch_round - 1 : ANDI_RESTITCH_ROUNDS] == 0) return;
-	if constexpr (LISTED) {
+	if constexpr (STAGE != 0) {
 		// As few segments per wavefront as the list's length allows (at least ANDI_LISTED_LANES): their replays
 		// are long and all different, a full wavefront of them would take its 64 lanes' paths one after the
 		// other at every step, and the device is nearly empty while this launch runs
@@ -928,12 +1020,14 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) { // (4 wa
 		lanes = lanes < ANDI_LISTED_LANES ? ANDI_LISTED_LANES : lanes > 64 ? 64 : lanes;
 		if ((threadIdx.x & 63u) >= lanes) return;
 		const uint32_t stride = waves * lanes;
-		for (uint32_t idx = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * lanes + (threadIdx.x & 63u); idx < count; idx += stride)
-			stitch_item<EXACT, AGAIN, true>(a, lane_item_of_slot(a, a.defer_list[idx]), s_hist);
+		for (uint32_t idx = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * lanes + (threadIdx.x & 63u); idx < count; idx += stride) {
+			const LaneItem it = lane_item_of_slot(a, a.defer_list[idx]);
+			if constexpr (STAGE == 1) stitch_item<EXACT, true>(a, it, s_hist); else stitch_stretch<EXACT>(a, it, s_hist);
+		}
 	} else {
 		if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
 		const LaneItem it = lane_item(a);
-		if (it.valid) stitch_item<EXACT, AGAIN, false>(a, it, s_hist);
+		if (it.valid) stitch_item<EXACT, false>(a, it, s_hist);
 	}
 }
 
@@ -1142,6 +1236,8 @@ hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st) {
 }
 
 hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
+	hipStream_t st_ = st;
+	(void)st_;
 	dim3 grid = lane_grid(a0);
 	ScanArgs a = a0;
 	hipError_t e = hipMemsetAsync(a.restitch_count, 0, 16 * sizeof(uint32_t), st);
@@ -1158,9 +1254,9 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 		listed_kernel<<<lblocks, BLOCK, 0, st>>>(a);
 	};
 	if (a.exact_equal)
-		stage(k_lane_stitch<true, false, false>, k_lane_stitch<true, false, true>);
+		stage(k_lane_stitch<true, 0>, k_lane_stitch<true, 1>);
 	else
-		stage(k_lane_stitch<false, false, false>, k_lane_stitch<false, false, true>);
+		stage(k_lane_stitch<false, 0>, k_lane_stitch<false, 1>);
 #ifdef ANDI_LANE_STATS
 	if (getenv("ANDI_LANE_STATS")) { // pass B's first stage: how its segments were settled, and the chain steps that took
 		static const char *names[8] = {"entered behind the cold chain's first anchor", "met behind its first anchor", "met at a mark",
@@ -1178,10 +1274,52 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 	for (uint32_t r = 0; again && r < ANDI_RESTITCH_ROUNDS; ++r) {
 		a.restitch_round = r;
 		if (a.exact_equal)
-			stage(k_lane_stitch<true, true, false>, k_lane_stitch<true, true, true>);
+			stage(k_stitch_heads, k_lane_stitch<true, 2>);
 		else
-			stage(k_lane_stitch<false, true, false>, k_lane_stitch<false, true, true>);
+			stage(k_stitch_heads, k_lane_stitch<false, 2>);
 	}
+#ifdef ANDI_LANE_STATS
+	if (getenv("ANDI_LANE_STATS")) { // replays by length (steps: 0, 1, 2-3, 4-7, ...) per kind of launch
+		static const char *kinds[4] = {"first stage", "first stage, listed", "-", "stretches stitched again (segments)"};
+		unsigned long long h[4][16], st[4];
+		unsigned int mx[4];
+		(void)hipStreamSynchronize(st_);
+		(void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stitch_hist), sizeof h);
+		(void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stitch_steps), sizeof st);
+		(void)hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_stitch_max), sizeof mx);
+		{
+			uint32_t rc[16];
+			(void)hipMemcpy(rc, a.restitch_count, sizeof rc, hipMemcpyDeviceToHost);
+			fprintf(stderr, "stitch_rounds stretches listed per round: %u %u %u; left on their own: %u\n", rc[0], rc[1], rc[2], rc[ANDI_RESTITCH_ROUNDS]);
+		}
+		{
+			static const char *xn[8] = {"left for the list", "shortcut", "first anchor", "mark", "met", "position", "on its own", "-"};
+			unsigned long long x[4][8][2];
+			(void)hipMemcpyFromSymbol(x, HIP_SYMBOL(g_stitch_exit), sizeof x);
+			for (int k = 0; k < 4; ++k)
+				for (int e = 0; e < 7; ++e)
+					if (x[k][e][0]) fprintf(stderr, "stitch_exit kind %d %-18s %9llu replays %10llu steps\n", k, xn[e], x[k][e][0], x[k][e][1]);
+			memset(x, 0, sizeof x);
+			(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stitch_exit), x, sizeof x);
+			unsigned long long ph[4][8];
+			(void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_stitch_phase), sizeof ph);
+			for (int k = 0; k < 4; ++k)
+				fprintf(stderr, "stitch_phase kind %d steps: phase 0 true %llu cold %llu, phase 1 %llu, phase 2 true %llu cold %llu, alone %llu; put at the first anchor %llu\n", k,
+						ph[k][0], ph[k][1], ph[k][2], ph[k][3], ph[k][4], ph[k][5], ph[k][6]);
+			memset(ph, 0, sizeof ph);
+			(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stitch_phase), ph, sizeof ph);
+		}
+		for (int k = 0; k < 4; ++k) {
+			fprintf(stderr, "stitch_len %-22s steps %llu max %u  by log2:", kinds[k], st[k], mx[k]);
+			for (int b = 0; b < 16; ++b) fprintf(stderr, " %llu", h[k][b]);
+			fprintf(stderr, "\n");
+		}
+		memset(h, 0, sizeof h), memset(st, 0, sizeof st), memset(mx, 0, sizeof mx);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stitch_hist), h, sizeof h);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stitch_steps), st, sizeof st);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_stitch_max), mx, sizeof mx);
+	}
+#endif
 	return hipGetLastError();
 }
 #endif // ANDI_QUAD_TU
