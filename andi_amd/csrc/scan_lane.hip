@@ -969,10 +969,13 @@ __global__ __launch_bounds__(BLOCK) void k_stitch_heads(ScanArgs a) {
 	if (a.restitch_count[a.restitch_round > 0 ? a.restitch_round - 1 : ANDI_RESTITCH_ROUNDS] == 0) return; // (nothing left on its own / nothing was stitched again: nothing to do)
 	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
 	const LaneItem it = lane_item(a);
+	// (consecutive lanes have consecutive segments in both layouts: the predecessor's answer comes from the lane before,
+	// except for a wavefront's first lane)
+	const bool bad = it.valid && it.seg_in_q >= 1 && !same_state(a.true_exit[it.slot - 1], a.used_entry[it.slot]);
+	bool pred_bad = __shfl_up((int)bad, 1) != 0;
 	if (!it.valid) return;
-	bool bad = false, pred_bad = false;
-	if (it.seg_in_q >= 1) bad = !same_state(a.true_exit[it.slot - 1], a.used_entry[it.slot]);
-	if (it.seg_in_q >= 2) pred_bad = !same_state(a.true_exit[it.slot - 2], a.used_entry[it.slot - 1]);
+	if (__lane_id() == 0) pred_bad = it.seg_in_q >= 2 && !same_state(a.true_exit[it.slot - 2], a.used_entry[it.slot - 1]);
+	if (it.seg_in_q < 2) pred_bad = false;
 	a.stretch_bad[it.slot] = bad ? 1 : 0;
 	if (bad && !pred_bad) {
 		a.defer_list[atomicAdd(a.defer_count, 1u)] = (unsigned long long)it.slot;
