@@ -24,8 +24,40 @@
 #include "bootstrap.h"
 #include "dev_arena.h"
 #include "esa_build.h"
+#include "knobs.h"
 #include "sa_device.h"
 #include "scan.h"
+
+// ------------------------------------------------------------------ knobs (knobs.h)
+namespace {
+struct KnobStore {
+	std::string value[KNOB_COUNT];
+	bool set[KNOB_COUNT];
+	KnobStore() { read(); }
+	void read() {
+		static const char *names[KNOB_COUNT] = {
+#define X(n) "ANDI_" #n,
+			ANDI_KNOB_LIST(X)
+#undef X
+		};
+		for (int k = 0; k < KNOB_COUNT; ++k) {
+			const char *v = getenv(names[k]);
+			set[k] = v != nullptr;
+			value[k] = v ? v : "";
+		}
+	}
+};
+KnobStore &knob_store() {
+	static KnobStore s; // (read when the library first looks)
+	return s;
+}
+} // namespace
+
+const char *andi_knob(AndiKnob k) {
+	const KnobStore &s = knob_store();
+	return s.set[k] ? s.value[k].c_str() : nullptr;
+}
+
 
 // segment length when the caller passes 0: short enough that one scan launch has
 // several hundred thousand chains, long enough that stitching stays a few per cent
@@ -69,6 +101,9 @@ struct andi_hip_ctx {
 	void *ib_host = nullptr, *ib_dev = nullptr;
 	size_t ib_cap = 0;
 	hipEvent_t ib_done = nullptr;
+	// index builds queued since the last scan looked at their flags (pinned host words the build kernels write)
+	hipEvent_t built = nullptr;
+	bool builds_pending = false;
 	// device suffix sorter: workspace, two pinned ints
 	void *sa_ws = nullptr;
 	size_t sa_ws_bytes = 0;
@@ -217,7 +252,7 @@ int pick_deep_k(size_t n, size_t queries) {
 	int K = 4;
 	while (K < ANDI_MAX_DEEP_K && ((size_t)1 << (2 * K)) < n) ++K;
 	if (queries >= 1024 && K < ANDI_MAX_DEEP_K) ++K;
-	if (const char *ev = getenv("ANDI_DEEP_K")) {
+	if (const char *ev = andi_knob(KNOB_DEEP_K)) {
 		int v = atoi(ev);
 		if (v >= 4 && v <= ANDI_MAX_DEEP_K) K = v;
 	}
@@ -296,6 +331,7 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->built, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_quad_waves, sizeof(uint32_t), hipHostMallocDefault);
@@ -330,6 +366,7 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->ib_dev) (void)andi_arena::dev_free(ctx->ib_dev);
 	if (ctx->ib_host) (void)hipHostFree(ctx->ib_host);
 	if (ctx->ib_done) (void)hipEventDestroy(ctx->ib_done);
+	if (ctx->built) (void)hipEventDestroy(ctx->built);
 	if (ctx->sa_ws) (void)andi_arena::dev_free(ctx->sa_ws);
 	if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
 	if (ctx->h_quad_waves) (void)hipHostFree(ctx->h_quad_waves);
@@ -449,7 +486,7 @@ static int esa_sort_suffixes(andi_hip_ctx *ctx, andi_hip_esa *e) {
 		ctx->sa_ws_bytes = need;
 	}
 	if (!ctx->sa_pinned) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->sa_pinned, 2 * sizeof(int32_t), hipHostMallocDefault));
-	if (!e->rec && !getenv("ANDI_NO_SORTED_RECORDS")) { // (experiments: the index build then gathers from the text, as with a host-made suffix array)
+	if (!e->rec && !andi_knob(KNOB_NO_SORTED_RECORDS)) { // (experiments: the index build then gathers from the text, as with a host-made suffix array)
 		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec, (e->cap + 8) * sizeof(uint32_t)));
 		e->bytes += (e->cap + 8) * sizeof(uint32_t);
 	}
@@ -541,8 +578,9 @@ int andi_hip_esa_build(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	Timed t(ctx, 0);
 	hipError_t err = andi_launch_esa_build(build_args(e), ctx->stream);
 	t.stop();
+	if (err == hipSuccess) err = hipEventRecord(ctx->built, ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build", err);
-	e->ref_built = true;
+	e->ref_built = true, ctx->builds_pending = true;
 	return 0;
 }
 
@@ -553,8 +591,9 @@ int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	const int ext = andi_index_single_ext(ctx->queries_hint);
 	hipError_t err = andi_launch_index_build(build_args(e), ext, ctx->stream);
 	t.stop();
+	if (err == hipSuccess) err = hipEventRecord(ctx->built, ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index", err);
-	e->index_built = true, e->deep_ext = ext != 0;
+	e->index_built = true, e->deep_ext = ext != 0, ctx->builds_pending = true;
 	return 0;
 }
 
@@ -596,8 +635,10 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 	const int ext = andi_index_single_ext(ctx->queries_hint);
 	if (err == hipSuccess) err = andi_launch_index_build_batch((const AndiIndexBatchItem *)ctx->ib_dev, (uint32_t)count, max_n, ext, ctx->stream);
 	t.stop();
+	if (err == hipSuccess) err = hipEventRecord(ctx->built, ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index_batch", err);
 	for (size_t k = 0; k < count; ++k) esas[k]->index_built = true, esas[k]->deep_ext = ext != 0;
+	ctx->builds_pending = true;
 	return 0;
 }
 
@@ -807,7 +848,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// kernel is slow at (a pair with long matches, a stretch without homology) ends the trial and the call takes the
 	// lane scan as if nothing had happened (a context whose trial failed skips the next ones).
 	const int coop_mode = andi_coop_enabled();
-	int coop_ok = andi_scan_group() == 0 && coop_mode != 0 && model <= ANDI_M_KIMURA && !getenv("ANDI_FORCE_REFERENCE");
+	int coop_ok = andi_scan_group() == 0 && coop_mode != 0 && model <= ANDI_M_KIMURA && !andi_knob(KNOB_FORCE_REFERENCE);
 	for (size_t s = 0; s < nsub && coop_ok; ++s)
 		if (!subjects[s] || subjects[s]->thr < 2 || subjects[s]->thr > 30) coop_ok = 0;
 	const int coop = coop_ok && coop_mode > 0;
@@ -817,13 +858,13 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// 32.6 / 32.6 / 35.4 / 44.0 ms at 32768 / 131072 / 262144 / 524288 / 2^20 / 2^21 -- whole queries: pairs differ too much)
 	uint32_t coop_seg = 524288;
 	while (coop_seg > 32768 && q->total_nt * (uint64_t)nsub / coop_seg < 24576) coop_seg /= 2;
-	if (const char *cs = getenv("ANDI_COOP_SEG")) // experiments
+	if (const char *cs = andi_knob(KNOB_COOP_SEG)) // experiments
 		if (atoi(cs) >= 64) coop_seg = (uint32_t)atoi(cs);
 	bool coop_trial = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub / 32768 >= (1u << 14) &&
-					  !getenv("ANDI_UNIFORM_SEGMENTS") && !getenv("ANDI_FORCE_ADAPTIVE");
+					  !andi_knob(KNOB_UNIFORM_SEGMENTS) && !andi_knob(KNOB_FORCE_ADAPTIVE);
 	if (coop_trial && ctx->coop_backoff) --ctx->coop_backoff, coop_trial = false;
 	const bool want_adaptive = !coop && segment == 0 && andi_scan_group() == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
-							   !getenv("ANDI_UNIFORM_SEGMENTS");
+							   !andi_knob(KNOB_UNIFORM_SEGMENTS);
 	if (segment == 0 && coop) {
 		const uint64_t nt = q->total_nt * (uint64_t)nsub;
 		segment = coop_seg;
@@ -854,8 +895,13 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	auto *h_self = (int64_t *)(h_esa + nsub);
 	uint64_t pairs = 0, nt = 0;
 	int any_reference = 0;
-	// the index builds must have finished: their flags decide which walk is exact
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	// the index builds must have finished: their flags decide which walk is exact.  (Only the builds this context
+	// has queued since its last scan are waited for -- not whatever else is on the stream; subjects built by another
+	// context are the caller's to have synchronised, as before.)
+	if (ctx->builds_pending) {
+		HIP_TRY(ctx, hipEventSynchronize(ctx->built));
+		ctx->builds_pending = false;
+	}
 	for (size_t s = 0; s < nsub; ++s) {
 		andi_hip_esa *e = subjects[s];
 		if (!e || (!e->index_built && !e->ref_built)) {
@@ -863,7 +909,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			return 1;
 		}
 		int mode = ANDI_MODE_PROBE;
-		if (!e->index_built || e->h_flags[0] != 0 || getenv("ANDI_FORCE_REFERENCE")) {
+		if (!e->index_built || e->h_flags[0] != 0 || andi_knob(KNOB_FORCE_REFERENCE)) {
 			// a 10-mer table entry may span a separator: only the reference's
 			// own walk reproduces get_match_cached there
 			mode = ANDI_MODE_REFERENCE;
@@ -889,7 +935,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// scratch: per (subject, segment) two states and two count vectors
 	bool adaptive = want_adaptive && !any_reference;
 	uint32_t seg0 = segment / 2; // classes: 1/2, 1, 2, 4 times the call's segment length
-	if (const char *e0 = getenv("ANDI_SEG0")) { // experiments: shortest segment of the adaptive classes
+	if (const char *e0 = andi_knob(KNOB_SEG0)) { // experiments: shortest segment of the adaptive classes
 		if (atoi(e0) >= 64) seg0 = (uint32_t)atoi(e0);
 	}
 	uint64_t max_waves = 0; // adaptive: wavefronts (64 segments of one pair) if every pair had the shortest segments
@@ -905,9 +951,10 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		for (size_t i = 0; i < q->nq; ++i) used += (q->len[i] + (uint64_t)seg0 - 1) / seg0;
 		used *= nsub;
 		size_t free_b = 0, total_b = 0;
-		const bool fits = max_waves < (1u << 26) &&
-						  (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)64 * max_waves * ANDI_SLOT_BYTES < free_b / 2 + ctx->scratch_bytes);
-		if (!fits || (10 * used < 7 * 64 * max_waves && !getenv("ANDI_FORCE_ADAPTIVE"))) adaptive = false, max_waves = 0;
+		const size_t want_b = (size_t)64 * max_waves * ANDI_SLOT_BYTES;
+		const bool fits = max_waves < (1u << 26) && // (the device is asked only when the scratch would have to grow)
+						  (want_b <= ctx->scratch_bytes || hipMemGetInfo(&free_b, &total_b) != hipSuccess || want_b < free_b / 2 + ctx->scratch_bytes);
+		if (!fits || (10 * used < 7 * 64 * max_waves && !andi_knob(KNOB_FORCE_ADAPTIVE))) adaptive = false, max_waves = 0;
 	}
 	const size_t pairs_all = nsub * q->nq;
 	// (the trial wants the pairs' sampled classes -- k_pair_estimate runs for the per-pair layout only: calls that do not
@@ -968,7 +1015,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.pair_bsum = a.pair_wave0 + pairs_all + 1;
 	a.pair_class = (uint8_t *)(a.pair_bsum + pairs_all / 1024 + 2);
 	{
-		const char *f = getenv("ANDI_SEG_FACTOR");
+		const char *f = andi_knob(KNOB_SEG_FACTOR);
 		a.seg_factor = f && atoi(f) > 0 ? (uint32_t)atoi(f) : 16u; // measured best of 8/16/32 with seg0 = 2048
 	}
 	a.M = M_dev;
@@ -976,14 +1023,14 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.any_reference = any_reference;
 	a.group = andi_scan_group();
 	{
-		const char *mp = getenv("ANDI_ROUNDS_PASSES");
+		const char *mp = andi_knob(KNOB_ROUNDS_PASSES);
 		a.max_passes = mp && atoi(mp) > 0 ? (uint32_t)atoi(mp) : 3u;
-		const char *qm = getenv("ANDI_QUAD_MATCH"); // experiments: mean match length from which a pair goes to k_lane_quad (0: all, -1: none)
+		const char *qm = andi_knob(KNOB_QUAD_MATCH); // experiments: mean match length from which a pair goes to k_lane_quad (0: all, -1: none)
 		a.quad_min_match = qm ? (uint32_t)atoi(qm) : 128u;
 		a.quad_all = 0, a.quad_listed = 0;
 		a.side_stream = ctx->side_stream, a.side_fork = ctx->side_fork, a.side_join = ctx->side_join;
 		a.h_quad_waves = ctx->h_quad_waves;
-		const char *kn = getenv("ANDI_KNOCK");
+		const char *kn = andi_knob(KNOB_KNOCK);
 		a.knock = kn ? (uint32_t)atoi(kn) : 0u;
 	}
 	a.lanes = a.group == 0;
@@ -1042,7 +1089,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		t.stop();
 		if (e != hipSuccess) return fail(ctx, "scan passes B/C", e);
 	}
-	if (getenv("ANDI_DEBUG_STITCH")) { // diagnostics: segments stitched again per round, length of the last stage's list
+	if (andi_knob(KNOB_DEBUG_STITCH)) { // diagnostics: segments stitched again per round, length of the last stage's list
 		uint32_t h[16];
 		(void)hipStreamSynchronize(ctx->stream);
 		(void)hipMemcpy(h, a.restitch_count, sizeof h, hipMemcpyDeviceToHost);
@@ -1078,6 +1125,8 @@ int andi_hip_bootstrap(andi_hip_ctx *ctx, const andi_hip_model *M, size_t n, uin
 	if (e != hipSuccess) return fail(ctx, "andi_hip_bootstrap", e);
 	return 0;
 }
+
+void andi_hip_reload_knobs(void) { knob_store().read(); }
 
 int andi_hip_has_experiments(void) {
 #ifdef ANDI_EXPERIMENTS
@@ -1235,7 +1284,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	bool distinct = true;
 	for (size_t a = 0; a < ndev; ++a)
 		for (size_t b = a + 1; b < ndev; ++b) distinct = distinct && devs[a] != devs[b];
-	const char *gather_env = getenv("ANDI_GATHER");
+	const char *gather_env = andi_knob(KNOB_GATHER);
 	// RCCL gather: several distinct devices (or forced, to exercise the path on one device), and the matrix fits next to the rest
 	bool use_rccl = (ndev > 1 && distinct && !(gather_env && !strcmp(gather_env, "direct"))) ||
 					(distinct && gather_env && !strcmp(gather_env, "rccl"));
@@ -1351,7 +1400,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	};
 	std::vector<Dev> dv(ndev);
 
-	const bool trace = getenv("ANDI_E2E_TRACE") != nullptr; // diagnostics: where the call's wall time goes (device 0's driver)
+	const bool trace = andi_knob(KNOB_E2E_TRACE) != nullptr; // diagnostics: where the call's wall time goes (device 0's driver)
 	auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t_call = now_ms();
 	auto drive = [&](size_t d) {

@@ -11,6 +11,7 @@
 // waits for the device like hipFree does, so a block is never handed out again while a kernel may still use it.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "knobs.h"
 
 #include <cstdlib>
 #include <iterator>
@@ -41,7 +42,7 @@ inline Arena &of_device(int dev) {
 
 inline size_t chunk_bytes() {
 	static const size_t v = [] {
-		const char *e = getenv("ANDI_ARENA_MB");
+		const char *e = andi_knob(KNOB_ARENA_MB);
 		const long mb = e ? atol(e) : 2048;
 		return mb > 0 ? (size_t)mb << 20 : (size_t)0;
 	}();

@@ -21,6 +21,7 @@
 #include "andi_dev.h"
 #include "esa_build.h"
 #include "scan.h"
+#include "knobs.h"
 
 #include <cstring>
 
@@ -614,7 +615,7 @@ int andi_index_single_ext(size_t queries) { // queries: how many the subject is 
 #ifdef ANDI_EXPERIMENTS
 	if (andi_rounds_lines() != 0) return 1;
 #endif
-	if (getenv("ANDI_COOP_PLAIN")) return 0; // (experiments)
+	if (andi_knob(KNOB_COOP_PLAIN)) return 0; // (experiments)
 	const int coop = andi_coop_enabled();
 	// pass A by wavefronts reads them -- worth the build's extra gather (+ 20 %) when the scan is forced to it, or, on
 	// trial, when the subject meets hundreds of queries

@@ -31,6 +31,7 @@
 // memory accesses, so throughput is set by the number of chains in flight; the
 // result is bit-identical to the sequential loop.
 #include "scan_dev.h"
+#include "knobs.h"
 
 #include <cstdlib>
 
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(256) void k_match_positions(EsaDev Ed, const uint8_
 // (scan_lane.hip, the default), 2/4/8 = this file's lane groups on bytes.  Subjects
 // that need the reference's own walk (ANDI_MODE_REFERENCE) always take the latter.
 int andi_scan_group(void) {
-	const char *e = getenv("ANDI_SCAN_G");
+	const char *e = andi_knob(KNOB_SCAN_G);
 	if (!e) return 0;
 	int v = atoi(e);
 	return (v == 0 || v == 2 || v == 4 || v == 8) ? v : 0;

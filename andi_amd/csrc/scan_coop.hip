@@ -24,6 +24,7 @@
 // Layout: one segment length for the call (slot = subject * total_segs + segment), wavefront w of subject
 // blockIdx.y takes segment w.  RAW/JC/Kimura only (LogDet and ANI count every anchor's nucleotides: scan_lane.hip).
 #include "lane_chain.h"
+#include "knobs.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -978,7 +979,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 7 : 4) void k_coop_cold
 } // namespace
 
 int andi_coop_enabled(void) { // ANDI_COOP=0: never; n = 2, 4, 8, 16: pass A with one wavefront per chain, windows of 2048 n symbols, whatever the call; unset: on trial (< 0)
-	const char *e = getenv("ANDI_COOP");
+	const char *e = andi_knob(KNOB_COOP);
 	if (!e) return -4;
 	const int v = atoi(e);
 	return v == 2 || v == 4 || v == 8 ? v : (v == 0 ? 0 : 4);
@@ -993,7 +994,7 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 		default: k_coop_cold<4><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 	}
 #ifdef ANDI_COOP_STATS
-	if (getenv("ANDI_COOP_STATS")) {
+	if (andi_knob(KNOB_COOP_STATS)) {
 		static const char *names[24] = {"segments", "G steps", "probe blocks", "coop_lcp calls", "windows", "windows that moved", "heads", "walk trips",
 										"walk lane-steps", "walk probes", "heads on the path", "hops", "gaps counted in G", "positions covered by windows",
 										"heads dropped", "walks with anchors off the diagonal", "coop_lcp rounds", "nodes", "service trips (lane_probe)", "lanes served", "parked: window edge / separators / plain table", "parked: K-mer occurs several times", "parked: long match off the diagonal", "parked: other"};

@@ -16,6 +16,7 @@
 // The chain logic, the probe table and the three-pass scheme (cold chains,
 // stitch, reduce) are those of scan.hip; the results are bit-identical.
 #include "lane_chain.h"
+#include "knobs.h"
 
 #include <algorithm>
 
@@ -1117,7 +1118,7 @@ hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N
 }
 
 static int lane_occupancy(bool per_pair) { // waves per SIMD pass A is compiled for (experiments: ANDI_LANE_OCC)
-	const char *e = getenv("ANDI_LANE_OCC");
+	const char *e = andi_knob(KNOB_LANE_OCC);
 	int v = e ? atoi(e) : 0;
 	if (v == 6 || v == 7 || v == 8) return v;
 	// per-pair segments: 8 (64 registers, two spilled outside the loop): 6.29 ms against 6.41 at 7 and 6.6 at 6 on the
@@ -1128,15 +1129,15 @@ static int lane_occupancy(bool per_pair) { // waves per SIMD pass A is compiled 
 
 template <bool EXACT>
 static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
-	const char *pe = getenv("ANDI_LANE_LDS_PAD"); // experiments: unused LDS per block, limits the resident wavefronts
+	const char *pe = andi_knob(KNOB_LANE_LDS_PAD); // experiments: unused LDS per block, limits the resident wavefronts
 	const size_t pad = pe ? (size_t)atoi(pe) : 0;
 #ifdef ANDI_EXPERIMENTS
-	if (const char *fl = getenv("ANDI_FLOOR")) { // diagnostic: the cost of the bare streams (wrong results)
+	if (const char *fl = andi_knob(KNOB_FLOOR)) { // diagnostic: the cost of the bare streams (wrong results)
 		k_stream_floor<<<grid, BLOCK, 0, st>>>(a, atoi(fl));
 		return hipGetLastError();
 	}
 #endif
-	if (getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) == 2) { // experiments: everything through the quads
+	if (andi_knob(KNOB_LANE_STREAM) && atoi(andi_knob(KNOB_LANE_STREAM)) == 2) { // experiments: everything through the quads
 		ScanArgs b = a;
 		b.quad_all = 1;
 		(void)hipMemsetAsync(a.first_pub, 0xff, (a.adaptive ? (size_t)64 * a.max_waves : (size_t)a.nsub * a.total_segs) * sizeof(unsigned long long), st);
@@ -1144,7 +1145,7 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 		return hipGetLastError();
 	}
 #ifdef ANDI_EXPERIMENTS
-	const bool stream = getenv("ANDI_LANE_STREAM") && atoi(getenv("ANDI_LANE_STREAM")) != 0; // measured slower: an experiment
+	const bool stream = andi_knob(KNOB_LANE_STREAM) && atoi(andi_knob(KNOB_LANE_STREAM)) != 0; // measured slower: an experiment
 	if (stream) { // (k_lane_stream knows no classes: it takes every pair)
 		switch (lane_occupancy(false)) {
 			case 8: k_lane_stream<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
@@ -1153,14 +1154,14 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 		return hipGetLastError();
 	}
 #endif
-	const bool blocks4 = getenv("ANDI_QUAD_UNLISTED") != nullptr; // (experiments: k_lane_quad's wavefronts in the call's order)
+	const bool blocks4 = andi_knob(KNOB_QUAD_UNLISTED) != nullptr; // (experiments: k_lane_quad's wavefronts in the call's order)
 	const bool quads = a.adaptive && a.quad_min_match != 0xffffffffu;
-	const bool side = quads && a.side_stream && !getenv("ANDI_NO_SIDE_STREAM");
+	const bool side = quads && a.side_stream && !andi_knob(KNOB_NO_SIDE_STREAM);
 	// With the side stream: k_lane_cold goes first, the host then reads how many wavefronts k_lane_quad's list has
 	// (four bytes over the side stream, while k_lane_cold runs: the device is never idle -- a wait for the layout
 	// BEFORE pass A cost it 0.1 ms) and launches k_lane_quad with exactly that many single-wavefront blocks, or
 	// not at all: blocks that only find out that they have nothing to do are not free either (bench set + 0.1 ms).
-	const bool counted = side && a.h_quad_waves && !blocks4 && !getenv("ANDI_QUAD_BLOCKS4");
+	const bool counted = side && a.h_quad_waves && !blocks4 && !andi_knob(KNOB_QUAD_BLOCKS4);
 	if (quads) { // the pairs with long matches, beside the others
 		(void)hipMemsetAsync(a.first_pub, 0xff, (size_t)64 * a.max_waves * sizeof(unsigned long long), st);
 		if (side) {
@@ -1223,7 +1224,7 @@ hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st) {
 	dim3 grid = lane_grid(a);
 	hipError_t e = a.exact_equal ? lane_cold<true>(a, grid, st) : lane_cold<false>(a, grid, st);
 #ifdef ANDI_LANE_STATS
-	if (e == hipSuccess && getenv("ANDI_LANE_STATS")) {
+	if (e == hipSuccess && andi_knob(KNOB_LANE_STATS)) {
 		static const char *names[24] = {"steps", "lcp_reload", "lcp_slide", "probes", "probe_reload", "table", "final_sa",
 										"single", "ext_loop", "multi", "multi_cand", "search", "gap_reload", "gap_words",
 										"substitutions", "lucky_tries", "x0", "x1", "x2", "x3", "x4", "x5", "x6", "x7"};
@@ -1261,7 +1262,7 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 	else
 		stage(k_lane_stitch<false, 0>, k_lane_stitch<false, 1>);
 #ifdef ANDI_LANE_STATS
-	if (getenv("ANDI_LANE_STATS")) { // pass B's first stage: how its segments were settled, and the chain steps that took
+	if (andi_knob(KNOB_LANE_STATS)) { // pass B's first stage: how its segments were settled, and the chain steps that took
 		static const char *names[8] = {"entered behind the cold chain's first anchor", "met behind its first anchor", "met at a mark",
 									   "met in phase 2", "position-synced", "left on their own", "steps of those that left on their own", "steps of the others"};
 		unsigned long long h[24];
@@ -1273,7 +1274,7 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stats), h, sizeof h);
 	}
 #endif
-	const bool again = !getenv("ANDI_NO_RESTITCH");
+	const bool again = !andi_knob(KNOB_NO_RESTITCH);
 	for (uint32_t r = 0; again && r < ANDI_RESTITCH_ROUNDS; ++r) {
 		a.restitch_round = r;
 		if (a.exact_equal)
@@ -1282,7 +1283,7 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 			stage(k_stitch_heads, k_lane_stitch<false, 2>);
 	}
 #ifdef ANDI_LANE_STATS
-	if (getenv("ANDI_LANE_STATS")) { // replays by length (steps: 0, 1, 2-3, 4-7, ...) per kind of launch
+	if (andi_knob(KNOB_LANE_STATS)) { // replays by length (steps: 0, 1, 2-3, 4-7, ...) per kind of launch
 		static const char *kinds[4] = {"first stage", "first stage, listed", "-", "stretches stitched again (segments)"};
 		unsigned long long h[4][16], st[4];
 		unsigned int mx[4];

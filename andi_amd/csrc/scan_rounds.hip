@@ -34,6 +34,7 @@
 // results are bit-identical (tests/test_scan_gpu.py runs both).  Models that count the
 // nucleotides of every anchor (LogDet, ANI) keep scan_lane.hip's kernel.
 #include "lane_dev.h"
+#include "knobs.h"
 
 namespace {
 
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(64) void k_rounds_cold(ScanArgs a) {
 // (scan_lane.hip's kernel, the default).  ANDI_ROUNDS=QP,SP switches the rounds on.
 int andi_rounds_lines(void) {
 	// measured slower than scan_lane.hip's pass A: an experiment, not the default
-	const char *e = getenv("ANDI_ROUNDS");
+	const char *e = andi_knob(KNOB_ROUNDS);
 	int qp = 0, sp = 0;
 	if (e && sscanf(e, "%d,%d", &qp, &sp) == 2 && (qp == 2 || qp == 4 || qp == 8) && (sp == 2 || sp == 4 || sp == 8))
 		return qp * 16 + sp;
@@ -489,7 +490,7 @@ hipError_t andi_launch_rounds_cold(const ScanArgs &a, hipStream_t st) {
 	}
 	hipError_t e = hipGetLastError();
 #ifdef ANDI_LANE_STATS
-	if (e == hipSuccess && getenv("ANDI_LANE_STATS")) {
+	if (e == hipSuccess && andi_knob(KNOB_LANE_STATS)) {
 		static const char *names[16] = {"steps", "q_line_fills", "rounds(waves)", "probes", "passes(waves)", "table", "-",
 										"single", "single_undecided", "multi", "multi_cand", "search", "s_line_fills", "gap_words",
 										"substitutions", "lucky_tries"};

@@ -95,6 +95,7 @@ SYMBOLS = {
                                                C.POINTER(C.c_int)]),
     "andi_hip_device_count": (C.c_int, []),
     "andi_hip_has_experiments": (C.c_int, []),
+    "andi_hip_reload_knobs": (None, []),
     "andi_hip_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_size_t]),
     "andi_hip_ctx_destroy": (None, [_P]),
     "andi_hip_ctx_expect_queries": (None, [_P, C.c_size_t]),
@@ -435,6 +436,11 @@ def device_count():
 def has_experiments():
     """the loaded library carries the pass A variants kept for the record (make -C andi_amd/csrc experiments)"""
     return bool(load().andi_hip_has_experiments())
+
+
+def reload_knobs():
+    """The library reads its ANDI_* environment switches once; read them again (after changing os.environ)."""
+    load().andi_hip_reload_knobs()
 
 
 def last_gather():

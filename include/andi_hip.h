@@ -230,6 +230,11 @@ typedef struct {
 } andi_hip_timings;
 /* 1 in a build that carries the pass A variants kept for the record (make -C andi_amd/csrc experiments), else 0 */
 int andi_hip_has_experiments(void);
+
+/* The library's ANDI_* environment switches (experiments, diagnostics: INTEGRATION.md lists them) are read once, when
+ * the library first looks at one; this reads them again (the tests change them under a live context).  Not to be
+ * called while another thread is inside the library. */
+void andi_hip_reload_knobs(void);
 int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t);
 void andi_hip_timings_reset(andi_hip_ctx *ctx);
 

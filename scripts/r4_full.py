@@ -73,6 +73,7 @@ def main():
 
     # the library's trace goes to the C stderr: capture it through a file
     os.environ["ANDI_E2E_TRACE"] = "1"
+    andi_amd.lib.reload_knobs()
     tf = tempfile.TemporaryFile(mode="w+b")
     saved = os.dup(2)
     sys.stderr.flush()

@@ -90,3 +90,54 @@ def verify_suffix_array(text: bytes, sa) -> None:
 
 def rand_dna(rng, n, alphabet=b"ACGT"):
     return rng.choice(np.frombuffer(alphabet, np.uint8), n).tobytes()
+
+
+# ---------------------------------------------------------------- the library's environment switches
+# libandihip.so reads its ANDI_* switches once (andi_amd/csrc/knobs.h); a test that changes one tells it to look again.
+def reload_knobs():
+    from andi_amd import lib
+    if lib._lib is not None:
+        lib.reload_knobs()
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def knobs(**kv):
+    """ANDI_<NAME>=value for the block (None: unset), e.g. knobs(COOP=4); the library looks again on entry and exit."""
+    old = {k: os.environ.get("ANDI_" + k) for k in kv}
+    try:
+        for k, v in kv.items():
+            if v is None:
+                os.environ.pop("ANDI_" + k, None)
+            else:
+                os.environ["ANDI_" + k] = str(v)
+        reload_knobs()
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop("ANDI_" + k, None)
+            else:
+                os.environ["ANDI_" + k] = v
+        reload_knobs()
+
+
+@pytest.fixture
+def knob(monkeypatch):
+    """knob("ANDI_X", "1") / knob("ANDI_X", None): monkeypatch.setenv / delenv and the library looks again (and once more
+    when the test is over, after monkeypatch has put the environment back: _knobs_restored below)."""
+    def set_(name, value):
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(value))
+        reload_knobs()
+    return set_
+
+
+@pytest.fixture(autouse=True)
+def _knobs_restored():
+    yield
+    reload_knobs()  # (set up before any fixture the test asks for, so torn down after monkeypatch's undo)

@@ -37,7 +37,7 @@ def _star_set(n, length, d_lo, d_hi, seed, ragged=0.0):
 
 
 # ------------------------------------------------------------------ C4: 3085 genomes, ~2 Mbp
-def test_c4_shape_3085_queries_per_row(ctx, orc, monkeypatch):
+def test_c4_shape_3085_queries_per_row(ctx, orc, knob):
     """A scan call of the C4 shape: 8 subject rows x 3085 queries = 24 680 pairs (more than one block of the
     pair layout handles), short genomes so that the oracle finishes: uniform and per-pair segment lengths."""
     import andi_amd
@@ -48,7 +48,7 @@ def test_c4_shape_3085_queries_per_row(ctx, orc, monkeypatch):
     esas = [andi_amd.Esa(ctx, seqs[i]) for i in subjects]
     for force in (False, True):
         if force:
-            monkeypatch.setenv("ANDI_FORCE_ADAPTIVE", "1")  # whole wavefronts per pair although the queries are short
+            knob("ANDI_FORCE_ADAPTIVE", "1")  # whole wavefronts per pair although the queries are short
         ctx.timings_reset()
         got = andi_amd.scan_rows(ctx, esas, subjects, Q)
         t = ctx.timings()

@@ -7,21 +7,15 @@ import pytest
 
 import andi_amd
 from andi_amd import synth
+from conftest import knobs
 from oracle import orc
 
 pytestmark = pytest.mark.gpu
 
 
 def _matrix(seqs, model, coop, segment=0):
-    old = os.environ.get("ANDI_COOP")
-    os.environ["ANDI_COOP"] = str(coop)
-    try:
+    with knobs(COOP=coop):
         return andi_amd.dist_matrix(seqs, model=model, segment=segment)
-    finally:
-        if old is None:
-            del os.environ["ANDI_COOP"]
-        else:
-            os.environ["ANDI_COOP"] = old
 
 
 def _revcomp(b: bytes) -> bytes:
@@ -71,9 +65,7 @@ def test_headline_pair_full_length():
 
 def _rows(seqs, env):
     """rows of all subjects through andi_hip_scan_rows on a context of its own; returns (counts, timings)"""
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with knobs(**{k[len("ANDI_"):]: v for k, v in env.items()}):
         ctx = andi_amd.Context(0)
         Q = andi_amd.Queries(ctx, seqs)
         esas = [andi_amd.Esa(ctx, s, sa="device") for s in seqs]
@@ -85,12 +77,6 @@ def _rows(seqs, env):
         Q.close()
         ctx.close()
         return got, t
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
 
 
 def test_trial_on_a_large_clean_call_and_fallback_on_a_structured_one():
@@ -130,8 +116,7 @@ def test_ragged_rows_thresholds_and_windows_full_of_heads():
         seqs.append(synth.to_bytes(codes[: int(30000 * (1.0 - 0.3 * rng.random()))]))
     subjects = [0, 7, 150, 299]
     want = np.stack([orc.scan_row(orc.OracleEsa(seqs[i]), seqs, i, orc.M_JC, threads=0) for i in subjects])
-    os.environ["ANDI_COOP"] = "4"
-    try:
+    with knobs(COOP=4):
         ctx = andi_amd.Context(0)
         ctx.expect_queries(len(seqs) - 1)
         Q = andi_amd.Queries(ctx, seqs)
@@ -142,17 +127,12 @@ def test_ragged_rows_thresholds_and_windows_full_of_heads():
             e.close()
         Q.close()
         ctx.close()
-    finally:
-        del os.environ["ANDI_COOP"]
     assert (got == want).all(), np.argwhere((got != want).any(axis=2))[:5]
     a, b = synth.pair(200000, 0.08, seed=21)
     c = synth.to_bytes(synth.mutate_codes(synth.base_codes(200000, 21), 0.25, 5))
     for p_value in (0.025, 0.3, 1e-6):
         want = orc.dist_matrix([a, b, c], p_value=p_value, model=orc.M_RAW, threads=3)
         for coop in (2, 8):
-            os.environ["ANDI_COOP"] = str(coop)
-            try:
+            with knobs(COOP=coop):
                 got = andi_amd.dist_matrix([a, b, c], p_value=p_value, model=andi_amd.M_RAW)
-            finally:
-                del os.environ["ANDI_COOP"]
             assert (got == want).all(), (p_value, coop)

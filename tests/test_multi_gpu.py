@@ -42,10 +42,12 @@ from test_multi_gpu import _set
 seqs = _set()
 want = orc.dist_matrix(seqs, threads=0)
 os.environ["ANDI_GATHER"] = "rccl"
+andi_amd.lib.reload_knobs()
 got = andi_amd.dist_matrix(seqs, host_threads=4, num_gpus=-1)
 assert (got == want).all()
 assert andi_amd.lib.last_gather() == "rccl", andi_amd.lib.last_gather()
 del os.environ["ANDI_GATHER"]
+andi_amd.lib.reload_knobs()
 if andi_amd.lib.device_count() > 1:  # several GPUs visible: the same call spans all of them
     got = andi_amd.dist_matrix(seqs, host_threads=4, num_gpus=-1)
     assert (got == want).all() and andi_amd.lib.last_gather() == "rccl", andi_amd.lib.last_gather()

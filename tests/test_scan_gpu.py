@@ -136,7 +136,7 @@ def test_mixed_modes_in_one_scan_call(ctx, orc):
     assert (got == want).all()
 
 
-def test_probe_table_depths_and_reference_walk_agree(ctx, orc, monkeypatch):
+def test_probe_table_depths_and_reference_walk_agree(ctx, orc, knob):
     """Every probe-table depth K and the reference walk give the same counts."""
     import andi_amd
     from andi_amd import synth
@@ -147,11 +147,11 @@ def test_probe_table_depths_and_reference_walk_agree(ctx, orc, monkeypatch):
             rand_dna(rng, 9000, b"AC"), rand_dna(rng, 500) * 30]
     want = orc.dist_matrix(seqs, threads=4)
     for K in ("4", "5", "7", "9", "11", "13"):
-        monkeypatch.setenv("ANDI_DEEP_K", K)
+        knob("ANDI_DEEP_K", K)
         got, t = _gpu_rows(ctx, seqs, segment=700)
         assert (got == want).all(), K
-    monkeypatch.delenv("ANDI_DEEP_K")
-    monkeypatch.setenv("ANDI_FORCE_REFERENCE", "1")
+    knob("ANDI_DEEP_K", None)
+    knob("ANDI_FORCE_REFERENCE", "1")
     ctx.timings_reset()
     got, t = _gpu_rows(ctx, seqs, segment=700)
     assert (got == want).all() and t["reference_subjects"] == len(seqs)
@@ -282,11 +282,11 @@ def test_full_size_properties(ctx, orc):
 
 
 @pytest.mark.parametrize("group", ["0", "2", "4", "8"])
-def test_every_scan_implementation_agrees(ctx, orc, monkeypatch, group):
+def test_every_scan_implementation_agrees(ctx, orc, knob, group):
     """ANDI_SCAN_G selects passes A/B: 0 = one lane per chain on packed symbols
     (scan_lane.hip, the default), 2/4/8 = lane groups on bytes (scan.hip)."""
     from andi_amd import synth
-    monkeypatch.setenv("ANDI_SCAN_G", group)
+    knob("ANDI_SCAN_G", group)
     rng = np.random.default_rng(5)
     a, b = synth.pair(80000, 0.04, seed=3)
     c = synth.to_bytes(synth.mutate_codes(synth.base_codes(80000, 3), 0.003, 11))
@@ -318,7 +318,7 @@ def test_bytes_outside_the_alphabet_are_refused(ctx):
         x.close()
 
 
-def test_segment_length_per_pair_changes_nothing(ctx, orc, monkeypatch):
+def test_segment_length_per_pair_changes_nothing(ctx, orc, knob):
     """segment = 0 lets the engine choose a segment length per pair from sampled match
     lengths (scan_lane.hip: k_pair_estimate); pairs of very different divergence in one
     call, every factor, and the uniform layout must all give the oracle's counts."""
@@ -330,15 +330,15 @@ def test_segment_length_per_pair_changes_nothing(ctx, orc, monkeypatch):
     for env in ({}, {"ANDI_SEG_FACTOR": "1"}, {"ANDI_SEG_FACTOR": "200"}, {"ANDI_SEG0": "128"},
                 {"ANDI_UNIFORM_SEGMENTS": "1"}):
         for k in ("ANDI_SEG_FACTOR", "ANDI_SEG0", "ANDI_UNIFORM_SEGMENTS"):
-            monkeypatch.delenv(k, raising=False)
+            knob(k, None)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            knob(k, v)
         got, t = _gpu_rows(ctx, seqs)
         assert (got == want).all(), env
 
 
 @pytest.mark.parametrize("lines", ["2,2", "4,4", "8,4", "8,8"])
-def test_pass_a_in_rounds_agrees(ctx, orc, monkeypatch, lines):
+def test_pass_a_in_rounds_agrees(ctx, orc, knob, lines):
     """ANDI_ROUNDS=QP,SP runs pass A as scan_rounds.hip does it: chains as state machines, all loads of a
     wavefront in one place, the streams through line buffers in LDS, probe-table entries that carry the
     symbols behind a K-mer that occurs once.  Same counts, whatever the buffers' sizes and however often
@@ -347,7 +347,7 @@ def test_pass_a_in_rounds_agrees(ctx, orc, monkeypatch, lines):
     from andi_amd import synth
     if not andi_amd.lib.has_experiments():
         pytest.skip("scan_rounds.hip is in the experiments build only (make -C andi_amd/csrc experiments; ANDI_HIP_LIB)")
-    monkeypatch.setenv("ANDI_ROUNDS", lines)
+    knob("ANDI_ROUNDS", lines)
     rng = np.random.default_rng(6)
     base = synth.base_codes(90000, 13)
     a = synth.to_bytes(base)
@@ -358,7 +358,7 @@ def test_pass_a_in_rounds_agrees(ctx, orc, monkeypatch, lines):
     joined = a[:30000] + b"!" + rand_dna(rng, 700) + b"!" + seqs[2][30000:70000]
     seqs += [rep, rep[:25000] + a[5000:30000], joined, rand_dna(rng, 3000, b"AC"), rand_dna(rng, 50)]
     for passes in ("1", "3", "50"):
-        monkeypatch.setenv("ANDI_ROUNDS_PASSES", passes)
+        knob("ANDI_ROUNDS_PASSES", passes)
         _check_set(ctx, orc, seqs, segments=(0, 1500, 64))
 
 
@@ -411,14 +411,14 @@ def test_device_buffers_survive_churn(ctx, orc):
         e.close()
 
 
-def test_fixups_in_pass_c(ctx, orc, monkeypatch):
+def test_fixups_in_pass_c(ctx, orc, knob):
     """Pass C stitches again, one after the other, the segments whose assumed entry state turned out wrong
     (k_scan_reduce): it looks for the failing checks 64 at a time and follows each stretch until the true chain
     enters a segment in the state that was assumed for it.  Without pass B's re-stitch rounds, on genomes with
     repeats and unrelated stretches and with short segments, there are hundreds of such stretches -- isolated ones,
     runs over several segments, the last segment of a query: the counts stay bit-exact and the fix-ups are counted."""
     from andi_amd import synth
-    monkeypatch.setenv("ANDI_NO_RESTITCH", "1")
+    knob("ANDI_NO_RESTITCH", "1")
     seqs, _ = synth.realistic_set(5, 200000, 0.001, 0.06, seed=41, novel_fraction=0.1)
     seqs.append(seqs[1][:150017])  # ends inside a segment
     want = orc.dist_matrix(seqs, threads=4)
@@ -432,7 +432,7 @@ def test_fixups_in_pass_c(ctx, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["1", "2"])
-def test_pass_a_variants_agree(ctx, orc, monkeypatch, variant):
+def test_pass_a_variants_agree(ctx, orc, knob, variant):
     """ANDI_LANE_STREAM=1: pass A with the chain step cut in two (scan_lane.hip: lane_cold_stream) -- every trip
     the lanes on a diagonal settle one window of it, then the lanes that need one probe together; an experiment
     (measured slower than the straight-line step).  ANDI_LANE_STREAM=2: EVERY pair through k_lane_quad -- the
@@ -443,7 +443,7 @@ def test_pass_a_variants_agree(ctx, orc, monkeypatch, variant):
     from andi_amd import synth
     if variant == "1" and not andi_amd.lib.has_experiments():
         pytest.skip("lane_cold_stream is in the experiments build only (make -C andi_amd/csrc experiments; ANDI_HIP_LIB)")
-    monkeypatch.setenv("ANDI_LANE_STREAM", variant)
+    knob("ANDI_LANE_STREAM", variant)
     seqs, _ = synth.realistic_set(5, 150000, 0.0005, 0.08, seed=5, novel_fraction=0.05)
     seqs.append(seqs[0])  # identical to its subject: one anchor as long as the sequence
     seqs.append(synth.to_bytes(synth.mutate_codes(synth.realistic_base(150000, 5), 0.0004, 9)))  # long matches
@@ -451,7 +451,7 @@ def test_pass_a_variants_agree(ctx, orc, monkeypatch, variant):
     _check_set(ctx, orc, seqs[:3], model=4)
 
 
-def test_pairs_with_long_matches_take_the_quad_kernel(ctx, orc, monkeypatch):
+def test_pairs_with_long_matches_take_the_quad_kernel(ctx, orc, knob):
     """With per-pair segment lengths the pairs whose sampled matches are long (>= 128 symbols on average) go through
     k_lane_quad, the others through k_lane_cold, side by side on two streams: a set with both kinds, every threshold."""
     from andi_amd import synth
@@ -462,13 +462,13 @@ def test_pairs_with_long_matches_take_the_quad_kernel(ctx, orc, monkeypatch):
     for env in ({}, {"ANDI_QUAD_MATCH": "0"}, {"ANDI_QUAD_MATCH": "1000"}, {"ANDI_QUAD_MATCH": "-1"}, {"ANDI_NO_SIDE_STREAM": "1"},
                 {"ANDI_QUAD_UNLISTED": "1"}, {"ANDI_QUAD_BLOCKS4": "1"}, {"ANDI_QUAD_MATCH": "0", "ANDI_QUAD_BLOCKS4": "1"}):
         for k in ("ANDI_QUAD_MATCH", "ANDI_NO_SIDE_STREAM", "ANDI_QUAD_UNLISTED", "ANDI_QUAD_BLOCKS4"):
-            monkeypatch.delenv(k, raising=False)
+            knob(k, None)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            knob(k, v)
         got, t = _gpu_rows(ctx, seqs)
         assert t["adaptive_calls"] >= 1 and (got == want).all(), env
     for k in ("ANDI_QUAD_MATCH", "ANDI_NO_SIDE_STREAM", "ANDI_QUAD_UNLISTED", "ANDI_QUAD_BLOCKS4"):
-        monkeypatch.delenv(k, raising=False)
+        knob(k, None)
     for model in (3, 4):  # LogDet, ANI: equal runs counted per nucleotide, in k_lane_quad's single-wavefront blocks too
         want_m = orc.dist_matrix(seqs, model=model, threads=0)
         got, _ = _gpu_rows(ctx, seqs, model=model)
