@@ -353,15 +353,21 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 	return v;
 }
 
+// the first code the gap behind the suffix with record L can own (has: there is such a suffix): behind a full K-mer
+// the next code; "w <sep>" sorts before every K-mer that starts with w
+__device__ __forceinline__ uint32_t first_code(bool has, uint32_t L, int K) {
+	if (!has) return 0u;
+	const uint32_t v = REC_V(L), sh = 2 * ((uint32_t)K - v);
+	return ((REC_CODE(L) >> sh) << sh) + (v == (uint32_t)K ? 1u : 0u);
+}
+
 __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
 												  const uint32_t *__restrict__ REC, uint2 *__restrict__ deep,
 												  int32_t *__restrict__ flags, int32_t n, int K, int single_ext, uint32_t block) {
-	__shared__ uint32_t s_off[PT_TILE + 1]; // exclusive prefix sums of the gaps' entry counts
-	__shared__ uint32_t s_first[PT_TILE];   // first code a gap owns
+	__shared__ uint32_t s_first[PT_TILE];   // first code a gap owns (one that owns nothing: its successor's)
 	__shared__ uint32_t s_absent[PT_TILE];  // number of absent codes it owns (they come first)
 	__shared__ uint32_t s_h[PT_TILE + 2];   // s_h[k + 1]: characters the suffixes r0 + k - 1 and r0 + k share
 	__shared__ uint2 s_present[PT_TILE];    // entry of the K-mer of suffix r, if the gap owns it
-	__shared__ uint32_t s_wave[PT_BLOCK / 64];
 	__shared__ uint32_t s_rec[PT_TILE + 3]; // rec of the suffixes r0 - 2 .. r0 + PT_TILE
 	__shared__ uint64_t s_some[PT_WORDS];   // gap i owns entries
 	__shared__ uint32_t s_bits[PT_RANKED / 32]; // bit t: an owning gap's entries start at t
@@ -394,7 +400,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 	if (threadIdx.x == 0) s_h[0] = r0 >= 2 ? rec_lcp(s_rec[0], s_rec[1], K) : 0u;
 	if (threadIdx.x == 1) s_h[PT_TILE + 1] = r0 + PT_TILE < n ? rec_lcp(s_rec[PT_TILE + 1], s_rec[PT_TILE + 2], K) : 0u;
 
-	uint32_t counts[PT_GAPS];
+	uint32_t counts[PT_GAPS], firsts[PT_GAPS];
 #pragma unroll
 	for (int u = 0; u < PT_GAPS; ++u) {
 		const uint32_t i = threadIdx.x + u * PT_BLOCK; // gap r0 + i
@@ -463,7 +469,6 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 					present = make_uint2(0, DEEP_SEARCH);
 				}
 				owns_present = 1;
-				first = REC_CODE(R);
 			}
 
 			// (c) closed run of suffixes "w <sep>" with 1 <= |w| <= 8
@@ -480,15 +485,8 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 			}
 
 			// (b) absent K-mers inside this gap
-			int32_t lo, hi; // codes are below 4^13: 32 bits do
-			if (!hasL) {
-				lo = 0;
-			} else if (REC_V(L) == full) {
-				lo = (int32_t)REC_CODE(L) + 1;
-			} else { // w <sep> sorts before every K-mer that starts with w
-				uint32_t sh = 2 * (full - REC_V(L));
-				lo = (int32_t)((REC_CODE(L) >> sh) << sh);
-			}
+			const int32_t lo = (int32_t)first_code(hasL, L, K); // codes are below 4^13: 32 bits do
+			int32_t hi;
 			if (!hasR) {
 				hi = (int32_t)((1u << (2 * K)) - 1u);
 			} else if (REC_V(R) == full) {
@@ -497,43 +495,35 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 				uint32_t sh = 2 * (full - REC_V(R));
 				hi = (int32_t)((REC_CODE(R) >> sh) << sh) - 1;
 			}
-			if (lo <= hi) {
-				absent = (uint32_t)(hi - lo + 1);
-				first = (uint32_t)lo;
-			}
+			if (lo <= hi) absent = (uint32_t)(hi - lo + 1);
+			first = (uint32_t)lo; // (a gap that owns only its suffix's K-mer: lo is that K-mer; one that owns nothing: where the next one starts)
 		}
 		s_first[i] = first, s_absent[i] = absent, s_present[i] = present;
-		counts[u] = absent + owns_present;
+		counts[u] = absent + owns_present, firsts[u] = first;
 		const uint64_t b = __ballot(counts[u] != 0);
 		if (lane == 0) s_some[u * (PT_BLOCK / 64) + wave] = b;
 	}
 
-	// block-wide exclusive scan of the entry counts, gap order = u * PT_BLOCK + thread
-	uint32_t total = 0;
-#pragma unroll
-	for (int u = 0; u < PT_GAPS; ++u) {
-		const uint32_t incl = wave_scan_incl(counts[u]);
-		__syncthreads(); // s_wave free again
-		if (lane == 63) s_wave[wave] = incl;
-		__syncthreads();
-		uint32_t before = total, all = 0;
-		for (uint32_t w = 0; w < PT_BLOCK / 64; ++w) {
-			if (w < wave) before += s_wave[w];
-			all += s_wave[w];
-		}
-		s_off[threadIdx.x + u * PT_BLOCK] = before + incl - counts[u];
-		total += all;
-	}
-	if (threadIdx.x == 0) s_off[PT_TILE] = total;
+	// The codes the gaps own are consecutive ranges (see above), so a gap's entries start at its first code: the block's
+	// piece of the table is [first code of its first gap, first code of the next block's first gap), entry t of the
+	// piece is code base + t, and no prefix sums over the gaps' counts are needed.
+	__syncthreads();
+	const uint32_t base = first_code(r0 > 0, s_rec[1], K);
+	const uint32_t total = (r0 + PT_TILE <= n ? first_code(true, s_rec[PT_TILE + 1], K) : (1u << (2 * K))) - base;
 	// the owners of the first PT_RANKED entries by rank: a bit where an owning gap's entries start (starts are
 	// distinct), the owning gaps listed in order; the owner of entry t is then number (set bits up to t) of the list
+	uint32_t owners_before; // owning gaps in the ballot words before word `lane` (lane < PT_WORDS)
+	{
+		const uint32_t mine = lane < PT_WORDS ? (uint32_t)__builtin_popcountll(s_some[lane]) : 0u;
+		owners_before = wave_scan_incl(mine) - mine;
+	}
 #pragma unroll
 	for (int u = 0; u < PT_GAPS; ++u) {
+		const uint32_t word = u * (PT_BLOCK / 64) + wave;
+		const uint32_t before = (uint32_t)__shfl((int)owners_before, (int)word);
 		if (counts[u] == 0) continue;
-		const uint32_t i = threadIdx.x + u * PT_BLOCK, word = u * (PT_BLOCK / 64) + wave, off = s_off[i];
-		uint32_t rank = (uint32_t)__builtin_popcountll(s_some[word] & ((1ull << lane) - 1ull));
-		for (uint32_t w = 0; w < word; ++w) rank += (uint32_t)__builtin_popcountll(s_some[w]);
-		s_owner[rank] = (uint16_t)i;
+		const uint32_t i = threadIdx.x + u * PT_BLOCK, off = firsts[u] - base;
+		s_owner[before + (uint32_t)__builtin_popcountll(s_some[word] & ((1ull << lane) - 1ull))] = (uint16_t)i;
 		if (off < PT_RANKED) atomicOr(&s_bits[off >> 5], 1u << (off & 31u));
 	}
 	__syncthreads();
@@ -544,21 +534,22 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 	__syncthreads();
 
 	for (uint32_t t = threadIdx.x; t < total; t += PT_BLOCK) {
+		const uint32_t c = base + t;
 		uint32_t a;
 		if (t < PT_RANKED) {
 			const uint32_t word = t >> 5;
 			a = s_owner[s_before[word] + (uint32_t)__builtin_popcount(s_bits[word] & (0xffffffffu >> (31u - (t & 31u)))) - 1u];
 		} else {
-			// the gap that owns entry t: the last one whose offset is <= t
-			uint32_t b = PT_TILE; // invariant: s_off[a] <= t < s_off[b]
+			// the gap that owns code c: the last one whose first code is <= c (gaps that own nothing share their
+			// successor's first code)
+			uint32_t b = PT_TILE; // invariant: s_first[a] <= c < s_first[b]
 			a = 0;
 			while (b - a > 1) {
 				uint32_t mid = (a + b) >> 1;
-				if (s_off[mid] <= t) a = mid; else b = mid;
+				if (s_first[mid] <= c) a = mid; else b = mid;
 			}
 		}
-		const uint32_t k = t - s_off[a], c = s_first[a] + k;
-		if (k >= s_absent[a]) { // the K-mer of suffix r itself
+		if (c - s_first[a] >= s_absent[a]) { // the K-mer of suffix r itself
 			deep[c] = s_present[a];
 			continue;
 		}
