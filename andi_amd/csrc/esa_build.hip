@@ -411,7 +411,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		const uint32_t L = hasL ? s_rec[i + 1] : 0u, R = hasR ? s_rec[i + 2] : 0u;
 		const uint32_t h = (hasL && hasR) ? rec_lcp(L, R, K) : 0u;
 		s_h[i + 1] = h;
-		uint32_t absent = 0, first = 0, owns_present = 0;
+		uint32_t absent = 0, first = 1u << (2 * K), owns_present = 0; // (gaps beyond the text: behind every code)
 		uint2 present = make_uint2(0, 0);
 
 		if (live) {

@@ -16,8 +16,10 @@ def rows(seg):
     return out, t
 for seg in (100, 2048):
     os.environ["ANDI_KNOCK"] = "64"
+    andi_amd.lib.reload_knobs()
     ref, _ = rows(seg)
     os.environ.pop("ANDI_KNOCK")
+    andi_amd.lib.reload_knobs()
     got, t = rows(seg)
     bad = np.argwhere((got != ref).any(axis=2))
     print("segment", seg, "differing pairs", len(bad), bad[:10].tolist(), "fixups", t["fixups"])

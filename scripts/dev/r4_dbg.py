@@ -10,6 +10,7 @@ want = orc.dist_matrix(seqs, model=orc.M_JC, threads=4)
 for coop in (4, 2):
     for seg in (0, 4096, 1000, 300000):
         os.environ["ANDI_COOP"] = str(coop)
+        andi_amd.lib.reload_knobs()
         got = andi_amd.dist_matrix(seqs, model=andi_amd.M_JC, segment=seg)
         bad = np.argwhere((got != want).any(axis=2))
         print("coop", coop, "seg", seg, "bad pairs", bad.tolist())

@@ -28,12 +28,13 @@ def subjects():
 ctx = andi_amd.Context()
 if True:
     for name, seq in subjects():
-        for K in ([None] if len(seq) > 1000000 else [None, "5", "8", "13"]):
+        for K in ([None] if len(seq) > 1000000 else [None, "5", "8", "11", "13"]):
             import os
             if K is None:
                 os.environ.pop("ANDI_DEEP_K", None)
             else:
                 os.environ["ANDI_DEEP_K"] = K
+            andi_amd.lib.reload_knobs()  # (the library reads its switches once)
             e = andi_amd.Esa(ctx, seq, sa="device")
             k, t = e.download_index()
             print(name, "K", k, "flags", e.flags().tolist(), hashlib.sha256(t.tobytes()).hexdigest()[:20])
