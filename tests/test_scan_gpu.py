@@ -431,6 +431,26 @@ def test_fixups_in_pass_c(ctx, orc, knob):
     assert total > 100, total
 
 
+def test_bad_stretches_are_stitched_in_pass_b(ctx, orc):
+    """Pass B stitches again, one lane per stretch, the runs of segments that were entered in a state their predecessor's
+    true chain did not leave in (scan_lane.hip: k_stitch_heads, stitch_stretch) -- repeats the true chain crosses on
+    lucky anchors (src/process.c:95-97), the edges of unrelated stretches.  With segments of 64 ... 2048 nucleotides a
+    repeat of 5000 spans up to 80 of them: counts bit-exact, and next to nothing is left for pass C's fix-ups (the same
+    sets leave it hundreds without these rounds: test_fixups_in_pass_c)."""
+    from andi_amd import synth
+    seqs, _ = synth.realistic_set(5, 200000, 0.001, 0.06, seed=41, novel_fraction=0.1)
+    seqs.append(seqs[1][:150017])  # ends inside a segment
+    want = orc.dist_matrix(seqs, threads=4)
+    left = {}
+    for seg in (0, 64, 300, 2048):
+        ctx.timings_reset()
+        got, t = _gpu_rows(ctx, seqs, segment=seg)
+        assert (got == want).all(), seg
+        left[seg] = t["fixups"]
+    print("fix-ups left to pass C by segment length:", left)
+    assert left[0] + left[300] + left[2048] <= 20, left  # (segments of 64: stretches run into each other, pass C takes what three rounds leave)
+
+
 @pytest.mark.parametrize("variant", ["1", "2"])
 def test_pass_a_variants_agree(ctx, orc, knob, variant):
     """ANDI_LANE_STREAM=1: pass A with the chain step cut in two (scan_lane.hip: lane_cold_stream) -- every trip
