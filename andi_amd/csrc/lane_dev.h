@@ -30,7 +30,10 @@ constexpr uint32_t EMPTY = ~0u;
 constexpr int32_t NO_DIAG = INT32_MIN;
 constexpr uint32_t ONES = 0x11111111u;
 constexpr uint32_t TOPS = 0x88888888u;
-constexpr uint32_t MULTI_MAX = 32; // occurrences a lane extends along one by one; more: binary search
+#ifndef ANDI_MULTI_MAX
+#define ANDI_MULTI_MAX 32
+#endif
+constexpr uint32_t MULTI_MAX = ANDI_MULTI_MAX; // occurrences a lane extends along one by one; more: binary search
 constexpr uint32_t ROUNDS_MULTI_MAX = 8; // (scan_rounds.hip keeps the positions in registers)
 
 // 32 symbols of the query from q0 (even) and, if dg != NO_DIAG, of the subject from q0 + dg
