@@ -52,7 +52,7 @@ struct ScanArgs {
 	ColdMark *marks;       // [..][ANDI_COLD_MARKS] (lane scan only)
 	ChainState *true_exit; // state of the true chain when it leaves the segment
 	ChainState *used_entry; // the state pass B let the true chain enter the segment in (pass C verifies it)
-	uint32_t *restitch_count; // [r]: segments stitched again in round r (lane scan); [ANDI_RESTITCH_ROUNDS]: true chains that left their segment on their own
+	uint32_t *restitch_count; // [r]: stretches stitched again in round r (lane scan); [ANDI_RESTITCH_ROUNDS]: true chains that left their segment on their own
 	uint32_t restitch_round;
 	// Segments whose stitching takes more than ANDI_STITCH_BUDGET chain steps -- or more than ANDI_STITCH_FIRST
 	// when no more than ANDI_STITCH_FEW lanes of their wavefront are still at it and the call has had more than
@@ -120,12 +120,13 @@ int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: on trial for calls it
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStream_t st); // k_lane_quad, one wavefront per block (scan_lane.hip compiled a second time)
-// Pass B again for the segments whose predecessor's true exit turned out not to be the assumed entry (a true
-// chain that runs on lucky anchors through a repeat in which cold chains find nothing unique): each round
-// settles one more segment of every such stretch, all stretches at once.  Rounds after one without any
-// re-stitched segment return at once.
+// Pass B again for the segments that were entered in a state their predecessor's true chain did not leave in (a true
+// chain that runs on lucky anchors through a repeat in which cold chains find nothing unique): per round, k_stitch_heads
+// lists the first segment of every stretch of such segments and one lane per stretch stitches it to its end
+// (scan_lane.hip).  One round settles all but the stretches that ran into each other; rounds after one that listed
+// nothing return at once.
 #ifndef ANDI_RESTITCH_ROUNDS
-#define ANDI_RESTITCH_ROUNDS 3 /* 5 rounds: 582 -> 21 fix-ups on the realistic set, passes B/C 9.37 -> 9.25 ms: the rounds cost what pass C saves */
+#define ANDI_RESTITCH_ROUNDS 3 /* (realistic set: 18 163 stretches in round 1, 86 in round 2, none in round 3) */
 #endif
 #ifndef ANDI_STITCH_FIRST
 #define ANDI_STITCH_FIRST 12
