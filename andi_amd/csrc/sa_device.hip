@@ -9,13 +9,13 @@
 //
 // Prefix doubling on radix sorts (Manber-Myers / Larsson-Sadakane ranks, with the suffixes
 // that are already in their final place dropped from every later round):
-//   round 0   sort all suffixes by their first 21 symbols (3 bits each: the text's alphabet
-//             NUL ! # ; A C G T in byte order, 63-bit keys);
+//   round 0   sort all suffixes by their first SA_SYMS = 16 symbols (3 bits each: the text's alphabet
+//             NUL ! # ; A C G T in byte order, 48-bit keys; 21 symbols in 63 bits until round 3);
 //   round r   a suffix i that still shares its place with others is keyed by
-//             (group of i, group of i + h), h = 21 * 2^(r-1): sorting those keys orders it by
+//             (group of i, group of i + h), h = 16 * 2^(r-1): sorting those keys orders it by
 //             2h symbols.  Groups are contiguous in the array and keep their span, so the
 //             sorted suffixes go back to the slots the unsorted ones came from.
-// Random-like DNA is done after round 1 (4^21 >> n); repeats take log2(length / 21) more
+// Random-like DNA is done after round 1 (a few suffixes in a thousand share 16 symbols); repeats take log2(length / 16) more
 // rounds over the suffixes inside them only.  Sorting, scans and compaction are rocPRIM's
 // (hipcub front end); the kernels here make keys, group heads and ranks.
 #include <hip/hip_runtime.h>
@@ -29,6 +29,14 @@
 namespace {
 
 #define SA_BLOCK 256
+// symbols of a round-0 key, 3 bits each.  16 (48-bit keys: six 8-bit passes of the radix sort instead of eight) still
+// holds the K <= 13 symbols the scan index's records want; in random-like DNA of 10^7 characters 0.2 % of the
+// suffixes then share their key with another and go through round 1 (21 symbols: a dozen suffixes -- and two more passes
+// over all of them: 1.82 -> 1.67 ms per 9.8 M characters as the bench set's staging has them; 13 symbols, five passes: 1.84)
+#ifndef SA_SYMS
+#define SA_SYMS 16
+#endif
+#define SA_KEY_BITS (3 * SA_SYMS)
 #define SA_TRY(call)                      \
 	do {                                  \
 		hipError_t e__ = (call);          \
@@ -45,18 +53,18 @@ __device__ __forceinline__ uint32_t order_code(uint32_t ch) {
 	return ch == 0 ? 0u : ch == '!' ? 1u : ch == '#' ? 2u : ch == ';' ? 3u : 8u;
 }
 
-// round 0: key of suffix i = its first 21 symbols (positions >= n read the NUL padding: code 0,
+// round 0: key of suffix i = its first SA_SYMS symbols (positions >= n read the NUL padding: code 0,
 // below every symbol, so a suffix that is a prefix of another sorts first)
 __global__ __launch_bounds__(SA_BLOCK) void k_sa_keys0(const uint8_t *__restrict__ S, int32_t n, uint64_t *__restrict__ key,
 														uint32_t *__restrict__ val, int32_t *__restrict__ foreign) {
 	const int64_t i = (int64_t)blockIdx.x * SA_BLOCK + threadIdx.x;
 	if (i >= n) return;
 	g_u8p p = (g_u8p)S + i;
-	const uint64_t w0 = ld_u64_unaligned(p), w1 = ld_u64_unaligned(p + 8), w2 = ld_u64_unaligned(p + 16);
+	const uint64_t w0 = ld_u64_unaligned(p), w1 = ld_u64_unaligned(p + 8), w2 = SA_SYMS > 16 ? ld_u64_unaligned(p + 16) : 0ull;
 	uint64_t k = 0;
 	uint32_t bad = 0;
 #pragma unroll
-	for (int j = 0; j < 21; ++j) {
+	for (int j = 0; j < SA_SYMS; ++j) {
 		const uint64_t w = j < 8 ? w0 : j < 16 ? w1 : w2;
 		const uint32_t c = order_code((uint32_t)(w >> (8 * (j & 7))) & 0xffu);
 		bad |= c;
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(SA_BLOCK) void k_sa_apply(const uint64_t *__restric
 	slots_out[t] = ((uint64_t)pos << 32) | idx;
 }
 
-// The sorted round-0 keys hold the first 21 symbols of every suffix IN SUFFIX-ARRAY ORDER.  The scan index's
+// The sorted round-0 keys hold the first SA_SYMS symbols of every suffix IN SUFFIX-ARRAY ORDER.  The scan index's
 // builder (esa_build.hip: k_probe_table) wants, per suffix, the 2-bit code of its first K characters, the number of
 // leading nucleotides and the separator class behind them -- its record, suffix_rec there -- which it would
 // otherwise gather from the text, one random access per suffix.  Made here from the keys, the records are a
@@ -103,9 +111,9 @@ __global__ __launch_bounds__(SA_BLOCK) void k_sa_apply(const uint64_t *__restric
 __global__ __launch_bounds__(SA_BLOCK) void k_sa_records(const uint64_t *__restrict__ key, int32_t n, int K, uint32_t *__restrict__ rec) {
 	const int64_t i = (int64_t)blockIdx.x * SA_BLOCK + threadIdx.x;
 	if (i >= n) return;
-	const uint64_t k = key[i];
-	const uint64_t other = ~k & 0x4924924924924924ull; // top bit of a symbol clear: not a nucleotide
-	uint32_t v = other ? ((uint32_t)__builtin_clzll(other) - 1u) / 3u : 21u;
+	const uint64_t k = key[i] << (63 - SA_KEY_BITS); // symbol j in bits 62-3j..60-3j, as with 21 symbols
+	const uint64_t other = ~k & (0x4924924924924924ull & ~((1ull << (63 - SA_KEY_BITS)) - 1ull)); // top bit of a symbol clear: not a nucleotide
+	uint32_t v = other ? ((uint32_t)__builtin_clzll(other) - 1u) / 3u : (uint32_t)SA_SYMS;
 	uint32_t sep = 0;
 	if (v < (uint32_t)K) {
 		const uint32_t sym = (uint32_t)(k >> (60 - 3 * v)) & 7u;
@@ -176,12 +184,12 @@ hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *worksp
 	SA_TRY(hipMemsetAsync(d_count, 0, 64, st));
 	k_sa_keys0<<<blocks((uint32_t)n), SA_BLOCK, 0, st>>>(S, n, keyA, valA, d_foreign);
 	SA_TRY(hipGetLastError());
-	uint32_t m = (uint32_t)n, h = 21;
+	uint32_t m = (uint32_t)n, h = SA_SYMS;
 	const uint64_t *slots = nullptr; // round 0: slot t is position t
 	int rounds = 0;
 	for (;;) {
 		size_t tb = tmp_bytes;
-		SA_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keyA, keyB, valA, valB, (int)m, 0, rounds == 0 ? 63 : 2 * bits, st));
+		SA_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keyA, keyB, valA, valB, (int)m, 0, rounds == 0 ? SA_KEY_BITS : 2 * bits, st));
 		if (rounds == 0 && rec) k_sa_records<<<blocks(m), SA_BLOCK, 0, st>>>(keyB, n, recK, rec);
 		k_sa_heads<<<blocks(m), SA_BLOCK, 0, st>>>(keyB, slots, m, hv);
 		SA_TRY(hipGetLastError());
