@@ -90,7 +90,8 @@ def main():
             if not ok:
                 bad = np.argwhere((got != want).any(axis=2))
                 print("pairs that differ:", bad[:10].tolist())
-                np.save("gpurun_out/fuzz_fail_seqs.npy", np.array(seqs, dtype=object), allow_pickle=True)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                np.save(os.path.join(ROOT, "gpurun_out", "fuzz_fail_seqs.npy"), np.array(seqs, dtype=object), allow_pickle=True)
                 sys.exit(1)
     print("fuzz: %d cases, all equal to the oracle" % cases)
 
