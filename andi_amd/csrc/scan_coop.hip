@@ -64,6 +64,7 @@ __device__ unsigned long long g_coop_cycles[8];
 #endif
 #ifdef ANDI_COOP_STATS
 __device__ unsigned int g_coop_max[4];
+__device__ unsigned long long g_coop_trip_lanes[2][8]; // trips by lanes at work: 0, 1, 2-3, 4-7, 8-15, 16-31, 32-63, 64 (plain trips, service trips)
 #endif
 enum { PH_G, PH_STREAM, PH_HEADS, PH_WALKS, PH_HOPS, PH_STRETCH, PH_FINAL };
 enum { CS_SEGMENTS, CS_G_STEPS, CS_BLOCKS, CS_LCP, CS_WINDOWS, CS_MOVED, CS_HEADS, CS_TRIPS, CS_LANE_STEPS, CS_PROBES, CS_ONPATH,
@@ -525,6 +526,8 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			const bool service = waiting && ((uint32_t)__builtin_popcountll(waiting) >= COOP_PARK || waiting == busy);
 #ifdef ANDI_COOP_STATS
 			if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
+				const uint32_t nb = (uint32_t)__builtin_popcountll(service ? waiting : busy & ~waiting); // lanes at work in this trip
+				atomicAdd(&g_coop_trip_lanes[service ? 1 : 0][nb ? 32 - __builtin_clz(nb) : 0], 1ull);
 				atomicAdd(&g_coop_stats[service ? CS_SERVICE : CS_TRIPS], 1ull);
 				atomicAdd(&g_coop_stats[service ? CS_SERVICE_LANES : CS_LANE_STEPS], (unsigned long long)__builtin_popcountll(service ? waiting : busy & ~waiting));
 			}
@@ -1004,6 +1007,12 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 		for (int k = 0; k < 24; ++k) fprintf(stderr, "coop_stats %-36s %llu\n", names[k], h[k]);
 		memset(h, 0, sizeof h);
 		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), h, sizeof h);
+		unsigned long long tl[2][8];
+		(void)hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_coop_trip_lanes), sizeof tl);
+		for (int k = 0; k < 2; ++k)
+			fprintf(stderr, "coop_stats %s trips by lanes at work (0, 1, 2-3, 4-7, 8-15, 16-31, 32-63, 64): %llu %llu %llu %llu %llu %llu %llu %llu\n", k ? "service" : "walk", tl[k][0], tl[k][1], tl[k][2], tl[k][3], tl[k][4], tl[k][5], tl[k][6], tl[k][7]);
+		memset(tl, 0, sizeof tl);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_coop_trip_lanes), tl, sizeof tl);
 		unsigned int mx[4];
 		(void)hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_coop_max), sizeof mx);
 		fprintf(stderr, "coop_stats most G steps of a segment          %u\n", mx[0]);
