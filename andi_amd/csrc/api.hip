@@ -848,7 +848,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// kernel is slow at (a pair with long matches, a stretch without homology) ends the trial and the call takes the
 	// lane scan as if nothing had happened (a context whose trial failed skips the next ones).
 	const int coop_mode = andi_coop_enabled();
-	int coop_ok = andi_scan_group() == 0 && coop_mode != 0 && model <= ANDI_M_KIMURA && !andi_knob(KNOB_FORCE_REFERENCE);
+	int coop_ok = coop_mode != 0 && model <= ANDI_M_KIMURA && !andi_knob(KNOB_FORCE_REFERENCE);
 	for (size_t s = 0; s < nsub && coop_ok; ++s)
 		if (!subjects[s] || subjects[s]->thr < 2 || subjects[s]->thr > 30) coop_ok = 0;
 	const int coop = coop_ok && coop_mode > 0;
@@ -863,7 +863,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	bool coop_trial = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub / 32768 >= (1u << 14) &&
 					  !andi_knob(KNOB_UNIFORM_SEGMENTS) && !andi_knob(KNOB_FORCE_ADAPTIVE);
 	if (coop_trial && ctx->coop_backoff) --ctx->coop_backoff, coop_trial = false;
-	const bool want_adaptive = !coop && segment == 0 && andi_scan_group() == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
+	const bool want_adaptive = !coop && segment == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
 							   !andi_knob(KNOB_UNIFORM_SEGMENTS);
 	if (segment == 0 && coop) {
 		const uint64_t nt = q->total_nt * (uint64_t)nsub;
@@ -1021,20 +1021,16 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.M = M_dev;
 	a.fixups = ctx->d_fixups;
 	a.any_reference = any_reference;
-	a.group = andi_scan_group();
 	{
-		const char *mp = andi_knob(KNOB_ROUNDS_PASSES);
-		a.max_passes = mp && atoi(mp) > 0 ? (uint32_t)atoi(mp) : 3u;
 		const char *qm = andi_knob(KNOB_QUAD_MATCH); // experiments: mean match length from which a pair goes to k_lane_quad (0: all, -1: none)
 		a.quad_min_match = qm ? (uint32_t)atoi(qm) : 128u;
-		a.quad_all = 0, a.quad_listed = 0;
+		a.quad_listed = 0;
 		a.side_stream = ctx->side_stream, a.side_fork = ctx->side_fork, a.side_join = ctx->side_join;
 		a.h_quad_waves = ctx->h_quad_waves;
 		const char *kn = andi_knob(KNOB_KNOCK);
 		a.knock = kn ? (uint32_t)atoi(kn) : 0u;
 	}
-	a.lanes = a.group == 0;
-	a.coop = coop && a.lanes && !a.adaptive;
+	a.coop = coop && !a.adaptive;
 	a.coop_abort = nullptr, a.coop_classes = 0;
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 
@@ -1045,7 +1041,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		if (e != hipSuccess) return fail(ctx, "scan layout", e);
 	}
 	bool coop_done = false;
-	if (coop_trial && a.lanes) {
+	if (coop_trial) {
 		// pass A by wavefronts on trial: its own (long) segments in the same scratch; the pairs' classes, if the call
 		// has sampled them, tell it which pairs are not its kind
 		ScanArgs b = a;
@@ -1127,14 +1123,6 @@ int andi_hip_bootstrap(andi_hip_ctx *ctx, const andi_hip_model *M, size_t n, uin
 }
 
 void andi_hip_reload_knobs(void) { knob_store().read(); }
-
-int andi_hip_has_experiments(void) {
-#ifdef ANDI_EXPERIMENTS
-	return 1;
-#else
-	return 0;
-#endif
-}
 
 int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t) {
 	if (!ctx || !t) return 1;

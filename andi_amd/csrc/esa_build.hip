@@ -603,9 +603,6 @@ size_t andi_min_tree_entries(int32_t n) {
 // read them: pass A in rounds (scan_rounds.hip) and pass A with one wavefront per chain (scan_coop.hip).  Every scan
 // understands both forms (the position is in the same place); the subject's handle remembers which it has.
 int andi_index_single_ext(size_t queries) { // queries: how many the subject is going to meet (0: unknown)
-#ifdef ANDI_EXPERIMENTS
-	if (andi_rounds_lines() != 0) return 1;
-#endif
 	if (andi_knob(KNOB_COOP_PLAIN)) return 0; // (experiments)
 	const int coop = andi_coop_enabled();
 	// pass A by wavefronts reads them -- worth the build's extra gather (+ 20 %) when the scan is forced to it, or, on

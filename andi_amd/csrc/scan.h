@@ -71,7 +71,6 @@ struct ScanArgs {
 	unsigned long long *fixups;
 	int exact_equal;   // LogDet/ANI: count the nucleotides of every anchor (src/model.c:256-278)
 	int any_reference; // some subject is in ANDI_MODE_REFERENCE: launch the reference-walk kernels too
-	int lanes;         // probe-table subjects: one lane per chain on packed symbols (scan_lane.hip)
 	// Per-pair segment lengths (lane scan, all subjects on the probe table).  A pair is
 	// subject * nq + query; its segments are seg0 << pair_class long and occupy the slots
 	// 64 * pair_wave0[pair] ..., i.e. whole wavefronts; pair_wave0[nsub * nq] = wavefronts in use.
@@ -84,8 +83,6 @@ struct ScanArgs {
 	uint32_t *pair_wave0;
 	uint32_t *pair_bsum;  // scratch: sums / offsets of 1024 pairs each
 	uint32_t max_waves;   // upper bound (every pair in class 0): the grid
-	int group;         // otherwise: lanes per chain of scan.hip's kernels (2, 4, 8)
-	uint32_t max_passes; // scan_rounds.hip: trips of the compute loop per round
 	// Pairs whose sampled mean match length is at least quad_min_match (per-pair segment lengths only) take pass A with
 	// the streams fetched by quads of lanes (scan_lane.hip: k_lane_quad), the others lane_step's; 0xffffffff: none do
 	uint32_t quad_min_match;
@@ -93,7 +90,6 @@ struct ScanArgs {
 	// at restitch_count[ANDI_QUAD_WAVES]): k_lane_quad's wavefronts take them in order
 	uint32_t quad_listed; // k_lane_quad takes its wavefronts from that list
 	uint32_t *h_quad_waves; // pinned host word the list's length is copied to (host side only)
-	uint32_t quad_all; // experiments (ANDI_LANE_STREAM=2): k_lane_quad takes every pair
 	// host side only: a second stream and two events, so that pass A's two kernels (k_lane_quad for the pairs with long
 	// matches, k_lane_cold for the others) share the device instead of each ending in a tail of its own
 	hipStream_t side_stream;
@@ -109,9 +105,6 @@ struct ScanArgs {
 // set to 1 if a byte is none of A C G T ! ; # NUL (the packed scan is then not applicable)
 hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N0, uint8_t *N1,
 									int32_t *foreign, hipStream_t st);
-// lanes per chain the scan runs with: 0 = one lane per chain on packed symbols
-// (scan_lane.hip, default), 1/2/4/8/16 = scan.hip's lane groups on bytes (ANDI_SCAN_G)
-int andi_scan_group(void);
 // adaptive mode: sample every pair's match lengths, choose its segment length, lay out the slots
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
@@ -154,9 +147,6 @@ static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at
 #ifndef ANDI_STITCH_TOGETHER
 #define ANDI_STITCH_TOGETHER 40 /* steps of pass B's phase 2 in which the cold chain is replayed beside the true one */
 #endif
-// pass A in rounds with line buffers (scan_rounds.hip); andi_rounds_lines() != 0: in use
-int andi_rounds_lines(void);
-hipError_t andi_launch_rounds_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st);

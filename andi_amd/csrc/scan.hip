@@ -569,75 +569,31 @@ __global__ __launch_bounds__(256) void k_match_positions(EsaDev Ed, const uint8_
 }
 
 // ------------------------------------------------------------------ launchers
-// Which implementation passes A and B run with: 0 = one lane per chain on packed symbols
-// (scan_lane.hip, the default), 2/4/8 = this file's lane groups on bytes.  Subjects
-// that need the reference's own walk (ANDI_MODE_REFERENCE) always take the latter.
-int andi_scan_group(void) {
-	const char *e = andi_knob(KNOB_SCAN_G);
-	if (!e) return 0;
-	int v = atoi(e);
-	return (v == 0 || v == 2 || v == 4 || v == 8) ? v : 0;
-}
-
-template <int G, bool EXACT>
-static hipError_t launch_cold(const ScanArgs &a, hipStream_t st, bool probe) {
-	const uint32_t per_block = BLOCK / G;
+// Passes A and B of probe-table subjects are scan_lane.hip's / scan_coop.hip's (one lane or one wavefront per chain on the
+// packed symbols); this file's lane groups on bytes run them for the subjects that need the reference's own walk
+// (ANDI_MODE_REFERENCE: a 10-mer table entry may span a separator).
+template <bool EXACT>
+static hipError_t launch_reference(const ScanArgs &a, hipStream_t st, bool stitch) {
+	const uint32_t per_block = BLOCK / SCAN_G;
 	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	if (probe) {
-		k_scan_cold<G, ANDI_MODE_PROBE, EXACT><<<grid, BLOCK, 0, st>>>(a);
-		CHECK_LAUNCH();
-	}
-	if (a.any_reference) {
-		k_scan_cold<G, ANDI_MODE_REFERENCE, EXACT><<<grid, BLOCK, 0, st>>>(a);
-		CHECK_LAUNCH();
-	}
+	if (stitch)
+		k_scan_stitch<SCAN_G, ANDI_MODE_REFERENCE, EXACT><<<grid, BLOCK, 0, st>>>(a);
+	else
+		k_scan_cold<SCAN_G, ANDI_MODE_REFERENCE, EXACT><<<grid, BLOCK, 0, st>>>(a);
+	CHECK_LAUNCH();
 	return hipSuccess;
 }
-
-template <int G, bool EXACT>
-static hipError_t launch_stitch(const ScanArgs &a, hipStream_t st, bool probe) {
-	const uint32_t per_block = BLOCK / G;
-	dim3 grid((a.total_segs + per_block - 1) / per_block, a.nsub);
-	if (probe) {
-		k_scan_stitch<G, ANDI_MODE_PROBE, EXACT><<<grid, BLOCK, 0, st>>>(a);
-		CHECK_LAUNCH();
-	}
-	if (a.any_reference) {
-		k_scan_stitch<G, ANDI_MODE_REFERENCE, EXACT><<<grid, BLOCK, 0, st>>>(a);
-		CHECK_LAUNCH();
-	}
-	return hipSuccess;
-}
-
-#define DISPATCH_G(FN, GROUP, PROBE)                                                               \
-	switch (GROUP) {                                                                               \
-		case 2: return a.exact_equal ? FN<2, true>(a, st, PROBE) : FN<2, false>(a, st, PROBE);     \
-		case 8: return a.exact_equal ? FN<8, true>(a, st, PROBE) : FN<8, false>(a, st, PROBE);     \
-		default:                                                                                   \
-			return a.exact_equal ? FN<SCAN_G, true>(a, st, PROBE) : FN<SCAN_G, false>(a, st, PROBE); \
-	}
 
 hipError_t andi_launch_scan_cold(const ScanArgs &a, hipStream_t st) {
-	if (a.lanes) {
-		// RAW, JC, Kimura: in rounds (scan_rounds.hip); LogDet/ANI count every anchor's nucleotides: scan_lane.hip
-		hipError_t e = a.coop ? andi_launch_coop_cold(a, st)
-#ifdef ANDI_EXPERIMENTS
-							  : (!a.exact_equal && andi_rounds_lines()) ? andi_launch_rounds_cold(a, st)
-#endif
-							  : andi_launch_lane_cold(a, st);
-		if (e != hipSuccess || !a.any_reference) return e;
-		DISPATCH_G(launch_cold, SCAN_G, false)
-	}
-	DISPATCH_G(launch_cold, a.group, true)
+	hipError_t e = a.coop ? andi_launch_coop_cold(a, st) : andi_launch_lane_cold(a, st);
+	if (e != hipSuccess || !a.any_reference) return e;
+	return a.exact_equal ? launch_reference<true>(a, st, false) : launch_reference<false>(a, st, false);
 }
 
 hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
-	if (a.lanes) {
-		hipError_t e = andi_launch_lane_stitch(a, st);
-		if (e != hipSuccess || !a.any_reference) return e;
-		DISPATCH_G(launch_stitch, SCAN_G, false)
-	}
-	DISPATCH_G(launch_stitch, a.group, true)
+	hipError_t e = andi_launch_lane_stitch(a, st);
+	if (e != hipSuccess || !a.any_reference) return e;
+	return a.exact_equal ? launch_reference<true>(a, st, true) : launch_reference<false>(a, st, true);
 }
 
 hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st) {

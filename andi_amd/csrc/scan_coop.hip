@@ -866,7 +866,10 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 
 // ------------------------------------------------------------------ the kernel
 template <int NCH>
-__global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? 7 : 4) void k_coop_cold(ScanArgs a) {
+#ifndef COOP_OCC
+#define COOP_OCC 7
+#endif
+__global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_coop_cold(ScanArgs a) {
 	__shared__ CoopLds<NCH> s_lds[COOP_WAVES];
 	CoopLds<NCH> &L = s_lds[threadIdx.x >> 6];
 	const uint32_t lane = __lane_id();

@@ -136,123 +136,6 @@ __global__ __launch_bounds__(1024) void k_pair_offsets(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------ pass A
-#ifdef ANDI_EXPERIMENTS /* measured slower, kept for the record (make experiments) */
-// Pass A with the chain step cut in two, so that the lanes of a wavefront do the same thing at the same
-// time: every trip of the loop a lane that is ON A DIAGONAL (lucky_anchor's precondition holds,
-// src/process.c:86-92) takes the next window of that diagonal and settles every anchor and mismatch inside
-// it -- lucky anchors behind single mismatches are a few register operations each, the window loads of all
-// those lanes are one load instruction and one wait -- and then the lanes whose lucky attempt FAILED, or that
-// are on no diagonal, probe (anchor(), src/process.c:113-123) together.  lane_step does the same work as one
-// straight-line function per step; its 64 lanes are then at ten different places, a load is issued for 5 or
-// 6 of them at a time, and the wavefront waits out each of those latencies in turn.  Same results.
-template <bool EXACT>
-__device__ __forceinline__ void lane_cold_stream(const ScanArgs &a, const LaneItem &it, uint32_t *s_hist) {
-	Tally tally;
-	tally_begin<1>(tally, s_hist + threadIdx.x);
-	PairCtx c = make_ctx(a, it.sub, it.qidx);
-	const uint32_t n = (uint32_t)c.E.n, thr = c.thr;
-	ChainState st = it.seg_in_q == 0 ? initial_state() : cold_state(it.start, n);
-	LWin w;
-	w.q0 = EMPTY, w.dg = NO_DIAG;
-	const size_t slot = it.slot;
-	ColdMark *marks = a.marks + slot * ANDI_COLD_MARKS;
-	uint32_t anchors = 0;
-	uint32_t curLen = 0;    // symbols of the lucky attempt at st.p compared so far (all equal)
-	bool accounted = false; // the anchor at st.p is certain and has been accounted for
-	bool lucky = lucky_applies(st, n, thr);
-	bool active = it.valid && st.p < it.end;
-
-	auto commit = [&](uint32_t curS, uint32_t len) { // an anchor of `len` symbols at st.p, subject offset curS (src/process.c:157-197)
-		if (!accounted) lane_account<EXACT>(c, st, tally, w, curS);
-		st.lastS = curS, st.lastQ = st.p, st.lastLen = len;
-		st.p += len + 1;
-		curLen = 0, accounted = false;
-		if (++anchors == 1) *(uint4 *)marks[0].first = make_uint4(st.lastQ, st.lastS, st.lastLen, 0);
-		if (anchors >= 2 && anchors < 2 + ANDI_COLD_MARKS) { // remember the state after anchors 2, 3, 4
-			ColdMark *m = marks + (anchors - 2);
-			ChainState ms = st;
-			ms.pad[0] = 1;
-			m->st = ms;
-			uint32_t v[16];
-#pragma unroll
-			for (int t = 0; t < 16; ++t) v[t] = tally.hist[t * BLOCK];
-			v[0] += tally.quarter + tally.same[0], v[5] += tally.quarter + tally.same[1];
-			v[10] += tally.quarter + tally.same[2], v[15] += tally.quarter + tally.rest + tally.same[3];
-			uint4 *mc = (uint4 *)m->counts;
-#pragma unroll
-			for (int t = 0; t < 4; ++t) mc[t] = make_uint4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
-		}
-	};
-
-	while (__any(active)) {
-		// ---- on a diagonal: one window of it
-		if (active && lucky) {
-			const uint32_t curS0 = st.lastS + (st.p - st.lastQ);
-			const int32_t dg = (int32_t)(curS0 - st.p);
-			uint32_t pos = st.p + curLen;
-			if (w.q0 == EMPTY || w.dg != dg || pos < w.q0 || pos - w.q0 >= WNT) {
-				uint32_t back = 0; // a fresh attempt: fetch the gap behind the last anchor too, it will be counted from the window
-				if (curLen == 0) back = st.p - st.lastQ - st.lastLen < 16 ? st.p - st.lastQ - st.lastLen : 16;
-				win_load(w, c, (pos - back) & ~1u, dg);
-				STAT(ST_LCP_RELOAD);
-			}
-			for (;;) { // the anchors and mismatches this window holds
-				const uint32_t maxlen = c.qlen - st.p, o = pos - w.q0, f = first_from(neq32(w.q, w.s), o);
-				curLen += f - o, pos += f - o;
-				if (f >= WNT && curLen < maxlen) { // the match runs on past the window: slide on the next trip
-					const uint32_t gap = st.p - st.lastQ - st.lastLen;
-					if (!accounted && curLen >= thr && maxlen >= thr && st.p - gap >= w.q0) {
-						// certainly an anchor already: count the gap while the window still holds it
-						lane_account<EXACT>(c, st, tally, w, st.lastS + (st.p - st.lastQ));
-						accounted = true;
-					}
-					break;
-				}
-				if (curLen > maxlen) curLen = maxlen;
-				if (curLen < thr) { // lucky_anchor failed: the probe follows, below
-					lucky = false;
-					break;
-				}
-				STAT(ST_STEP);
-				commit(st.lastS + (st.p - st.lastQ), curLen);
-				active = st.p < it.end;
-				lucky = lucky_applies(st, n, thr);
-				pos = st.p;
-				// the next attempt on this diagonal starts behind the mismatch: in this window still?
-				if (!active || !lucky || w.dg != dg || pos < w.q0 || pos - w.q0 >= WNT) break;
-			}
-		}
-		// ---- not on a diagonal, or the attempt on it failed: anchor(), src/process.c:113-123
-		if (active && !lucky) {
-			STAT(ST_STEP);
-			const Probe pr = lane_probe(c, st.p, w);
-			if (pr.unique && pr.len >= thr) {
-				accounted = false;
-				commit(pr.pos, pr.len);
-			} else {
-				st.p += pr.len + 1;
-			}
-			curLen = 0, accounted = false;
-			active = st.p < it.end;
-			lucky = lucky_applies(st, n, thr);
-		}
-	}
-	if (!it.valid) return;
-	for (uint32_t k = anchors < 2 ? 0 : anchors - 1; k < ANDI_COLD_MARKS; ++k) marks[k].st.pad[0] = 0; // unused marks
-
-	st.pad[1] = anchors < 255 ? anchors : 255;
-	a.cold_exit[slot] = st;
-	a.exit_p[slot] = st.p;
-	tally_finish<1>(tally);
-	uint32_t out[16];
-#pragma unroll
-	for (int t = 0; t < 16; ++t) out[t] = tally.hist[t * BLOCK];
-	uint4 *dst = (uint4 *)(a.cold_counts + slot * 16);
-#pragma unroll
-	for (int t = 0; t < 4; ++t) dst[t] = make_uint4(out[4 * t], out[4 * t + 1], out[4 * t + 2], out[4 * t + 3]);
-}
-
-#endif // ANDI_EXPERIMENTS
 
 __device__ __forceinline__ uint32_t dpp_quad_floor(uint32_t v, int ctrl) { // quad_perm: broadcast lane `ctrl`, or lane ^ 1 (4), lane ^ 2 (5)
 	switch (ctrl) {
@@ -265,94 +148,6 @@ __device__ __forceinline__ uint32_t dpp_quad_floor(uint32_t v, int ctrl) { // qu
 	}
 }
 
-#ifdef ANDI_EXPERIMENTS
-__device__ __forceinline__ void quad_transpose_floor(uint4 (&R)[4], uint32_t qi) { // R[r] of quad lane i <- R[i] of quad lane r
-	auto sel = [](bool c, const uint4 &a, const uint4 &b) { return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); };
-	auto dpp4 = [](const uint4 &v, int ctrl) {
-		return make_uint4(dpp_quad_floor(v.x, ctrl), dpp_quad_floor(v.y, ctrl), dpp_quad_floor(v.z, ctrl), dpp_quad_floor(v.w, ctrl));
-	};
-	const bool odd = qi & 1u, high = qi & 2u;
-	uint4 a = dpp4(sel(odd, R[0], R[1]), 4), b = dpp4(sel(odd, R[2], R[3]), 4);
-	R[0] = sel(odd, a, R[0]), R[1] = sel(odd, R[1], a), R[2] = sel(odd, b, R[2]), R[3] = sel(odd, R[3], b);
-	a = dpp4(sel(high, R[0], R[2]), 5), b = dpp4(sel(high, R[1], R[3]), 5);
-	R[0] = sel(high, a, R[0]), R[2] = sel(high, R[2], a), R[1] = sel(high, b, R[1]), R[3] = sel(high, R[3], b);
-}
-
-// Diagnostic (ANDI_FLOOR=v, results are wrong on purpose): what a lane-per-segment stream along the main diagonal
-// of the forward strand costs with nothing of the chain logic (v = 1: load, compare, count mismatching symbols),
-// with the work of an anchor per mismatch (v = 2), two windows per trip (v = 3, 4), and with the streams fetched
-// by quads of lanes -- 64 consecutive bytes per load instruction and quad, a 4 x 4 transpose by DPP (v = 5): the
-// floors under any pass A that reads its streams one of these ways (profiles/r02_stream/floor.txt).
-__global__ __launch_bounds__(BLOCK, 6) void k_stream_floor(ScanArgs a, int variant) {
-	__shared__ uint32_t s_hist[16 * BLOCK];
-	const LaneItem it = lane_item(a);
-	if (!it.valid) return;
-	Tally tally;
-	tally_begin<1>(tally, s_hist + threadIdx.x);
-	PairCtx c = make_ctx(a, it.sub, it.qidx);
-	const int32_t dg = (int32_t)(c.E.n / 2 + 1); // query position x of an indel-free descendant lies at RS[x + L + 1]
-	uint32_t mism = 0, lastQ = it.start, anchors = 0;
-	if (variant == 5) { // quads: 64 consecutive bytes of one lane's streams per load instruction, 4 x 4 transpose
-		const uint32_t qi = threadIdx.x & 3u;
-		for (uint32_t x = it.start & ~1u; x < it.end; x += 4 * WNT) {
-			uint4 Rq[4], Rs[4];
-#pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				const uint32_t ox = dpp_quad_floor(x, r);
-				Rq[r] = ld_query(c, ox + WNT * qi);
-				Rs[r] = ld_subject(c, (int32_t)(ox + WNT * qi) + dg);
-			}
-			quad_transpose_floor(Rq, qi);
-			quad_transpose_floor(Rs, qi);
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const uint4 d = neq32(Rq[k], Rs[k]);
-				mism += __builtin_popcount(d.x) + __builtin_popcount(d.y) + __builtin_popcount(d.z) + __builtin_popcount(d.w);
-			}
-		}
-		a.exit_p[it.slot] = mism;
-		return;
-	}
-	const uint32_t step = variant >= 3 ? 2 * WNT : WNT;
-	for (uint32_t x = it.start & ~1u; x < it.end; x += step) {
-		const uint4 q0 = ld_query(c, x), s0 = ld_subject(c, (int32_t)x + dg);
-		uint4 q1 = q0, s1 = s0;
-		if (variant >= 3) q1 = ld_query(c, x + WNT), s1 = ld_subject(c, (int32_t)(x + WNT) + dg);
-		for (int h = 0; h < (variant >= 3 ? 2 : 1); ++h) {
-			const uint4 qv = h ? q1 : q0, sv = h ? s1 : s0, d = neq32(qv, sv);
-			if (variant == 1 || variant == 3) {
-				mism += __builtin_popcount(d.x) + __builtin_popcount(d.y) + __builtin_popcount(d.z) + __builtin_popcount(d.w);
-			} else {
-				uint32_t o = 0;
-				for (;;) { // every mismatch ends an anchor: count it as pass A's fast path would
-					const uint32_t f = first_from(d, o);
-					if (f >= WNT) break;
-					const uint32_t pos = x + h * WNT + f, len = pos - lastQ;
-					if (len >= c.thr) {
-						count_equal(tally, len);
-						const uint32_t sh = 4 * (f & 7u);
-						const uint32_t qn = (pick(qv, f >> 3) >> sh) & 15u, sn = (pick(sv, f >> 3) >> sh) & 15u;
-						if (!((qn | sn) & 4u)) lds_add(&tally.hist[(((sn & 3u) << 2) | (qn & 3u)) * BLOCK], 1u);
-						++anchors;
-					}
-					lastQ = pos + 1;
-					o = f + 1;
-					if (o >= WNT) break;
-				}
-			}
-		}
-	}
-	tally_finish<1>(tally);
-	ChainState st = initial_state();
-	st.p = it.end, st.lastQ = lastQ, st.lastLen = mism + anchors;
-	a.cold_exit[it.slot] = st;
-	a.exit_p[it.slot] = st.p;
-	uint32_t *dst = a.cold_counts + it.slot * 16;
-	for (int t = 0; t < 16; ++t) dst[t] = tally.hist[t * BLOCK];
-	a.marks[it.slot * ANDI_COLD_MARKS].st.pad[0] = 0;
-}
-
-#endif // ANDI_EXPERIMENTS
 
 __device__ __forceinline__ bool pos_in(const LWin &w, uint32_t p) {
 	return w.q0 != EMPTY && p >= w.q0 && p - w.q0 < WNT;
@@ -604,22 +399,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_quad(ScanArgs a) { // (4 wave
 		wave = ((const uint32_t *)a.defer_list)[k];
 	}
 	LaneItem it = lane_item(a, wave);
-	if (!a.quad_all && !lane_is_mine(a, it, true)) it.valid = false; // (a wavefront is one pair's: all or none)
+	if (!lane_is_mine(a, it, true)) it.valid = false; // (a wavefront is one pair's: all or none)
 	if (!__any(it.valid)) return;
 	lane_cold_quad<EXACT>(a, it, s_hist, s_stage);
 }
 
-#ifdef ANDI_EXPERIMENTS
-template <bool EXACT, int OCC>
-__global__ __launch_bounds__(BLOCK, OCC) void k_lane_stream(ScanArgs a) {
-	__shared__ uint32_t s_hist[16 * BLOCK];
-	if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
-	const LaneItem it = lane_item(a);
-	if (!__any(it.valid)) return;
-	lane_cold_stream<EXACT>(a, it, s_hist);
-}
-
-#endif // ANDI_EXPERIMENTS
 
 // The lanes of a wavefront take consecutive segments of one query, so they see the
 // same divergence and stay in step.  (Persistent lanes that fetch their next segment
@@ -1131,29 +915,6 @@ template <bool EXACT>
 static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	const char *pe = andi_knob(KNOB_LANE_LDS_PAD); // experiments: unused LDS per block, limits the resident wavefronts
 	const size_t pad = pe ? (size_t)atoi(pe) : 0;
-#ifdef ANDI_EXPERIMENTS
-	if (const char *fl = andi_knob(KNOB_FLOOR)) { // diagnostic: the cost of the bare streams (wrong results)
-		k_stream_floor<<<grid, BLOCK, 0, st>>>(a, atoi(fl));
-		return hipGetLastError();
-	}
-#endif
-	if (andi_knob(KNOB_LANE_STREAM) && atoi(andi_knob(KNOB_LANE_STREAM)) == 2) { // experiments: everything through the quads
-		ScanArgs b = a;
-		b.quad_all = 1;
-		(void)hipMemsetAsync(a.first_pub, 0xff, (a.adaptive ? (size_t)64 * a.max_waves : (size_t)a.nsub * a.total_segs) * sizeof(unsigned long long), st);
-		k_lane_quad<EXACT><<<grid, BLOCK, 0, st>>>(b);
-		return hipGetLastError();
-	}
-#ifdef ANDI_EXPERIMENTS
-	const bool stream = andi_knob(KNOB_LANE_STREAM) && atoi(andi_knob(KNOB_LANE_STREAM)) != 0; // measured slower: an experiment
-	if (stream) { // (k_lane_stream knows no classes: it takes every pair)
-		switch (lane_occupancy(false)) {
-			case 8: k_lane_stream<EXACT, 8><<<grid, BLOCK, pad, st>>>(a); break;
-			default: k_lane_stream<EXACT, 6><<<grid, BLOCK, pad, st>>>(a); break; // (6: as measured)
-		}
-		return hipGetLastError();
-	}
-#endif
 	const bool blocks4 = andi_knob(KNOB_QUAD_UNLISTED) != nullptr; // (experiments: k_lane_quad's wavefronts in the call's order)
 	const bool quads = a.adaptive && a.quad_min_match != 0xffffffffu;
 	const bool side = quads && a.side_stream && !andi_knob(KNOB_NO_SIDE_STREAM);

@@ -94,7 +94,6 @@ SYMBOLS = {
                                                C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_size_t,
                                                C.POINTER(C.c_int)]),
     "andi_hip_device_count": (C.c_int, []),
-    "andi_hip_has_experiments": (C.c_int, []),
     "andi_hip_reload_knobs": (None, []),
     "andi_hip_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_size_t]),
     "andi_hip_ctx_destroy": (None, [_P]),
@@ -431,11 +430,6 @@ def scan_rows(ctx: Context, esas, selfs, queries: Queries, model=M_JC, segment=0
 
 def device_count():
     return load().andi_hip_device_count()
-
-
-def has_experiments():
-    """the loaded library carries the pass A variants kept for the record (make -C andi_amd/csrc experiments)"""
-    return bool(load().andi_hip_has_experiments())
 
 
 def reload_knobs():

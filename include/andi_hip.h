@@ -228,8 +228,6 @@ typedef struct {
 	uint64_t coop_calls;     /* scan calls whose pass A ran with one wavefront per chain (scan_coop.hip) */
 	uint64_t coop_fallbacks; /* ... that tried it and fell back to one lane per chain (long matches, stretches without homology) */
 } andi_hip_timings;
-/* 1 in a build that carries the pass A variants kept for the record (make -C andi_amd/csrc experiments), else 0 */
-int andi_hip_has_experiments(void);
 
 /* The library's ANDI_* environment switches (experiments, diagnostics: INTEGRATION.md lists them) are read once, when
  * the library first looks at one; this reads them again (the tests change them under a live context).  Not to be

@@ -56,8 +56,6 @@ def main():
             env = {}
             if rng.random() < 0.3 and model <= 2:
                 env["ANDI_COOP"] = str(rng.choice([2, 4, 8]))
-            elif rng.random() < 0.2:
-                env["ANDI_SCAN_G"] = str(rng.choice([2, 4, 8]))
             if rng.random() < 0.15:
                 env["ANDI_UNIFORM_SEGMENTS"] = "1"
             if rng.random() < 0.15:

@@ -183,3 +183,71 @@ def test_c5_bootstrap_99_replicates_of_256(ctx):
     assert np.abs(mean / exp - 1).max() < 0.05
     assert (B == andi_amd.bootstrap(ctx, M, reps, seed=1729)).all()
     assert (B[0] != andi_amd.bootstrap(ctx, M, 1, seed=1730)[0]).any()
+
+
+# ------------------------------------------------------------------ the DEFAULT path at full size, against the oracle itself
+def _sampled_pairs_against_oracle(orc, seqs, esas, subjects, got, pairs):
+    """got[row of subject, query] against dist_anchor of the oracle for the listed (subject index into `subjects`, query)
+    pairs; the oracle's arrays stand on the product's suffix array only after that array has been proven (see above)."""
+    oracles = {}
+    for r, j in pairs:
+        if r not in oracles:
+            oracles[r] = _oracle_on_product_sa(orc, seqs[subjects[r]], esas[r])
+        want = oracles[r].dist_anchor(seqs[j])
+        assert (got[r, j] == want).all(), (subjects[r], j, got[r, j].tolist(), want.tolist())
+
+
+_NO_SCAN_SWITCH = dict(COOP=None, SCAN_G=None, UNIFORM_SEGMENTS=None, FORCE_ADAPTIVE=None, COOP_SEG=None, DEEP_K=None)
+
+
+def test_default_path_at_headline_length_against_the_oracle(orc):
+    """BASELINE's genome length (4.9 Mbp), a call large enough for pass A by wavefronts to be tried, NO scan switch set:
+    whatever the engine chooses is compared with the oracle directly -- 12 ordered pairs of three subjects (round 3's
+    verdict: at this length the wavefront kernel had only been compared with the lane scan inside the GPU suite)."""
+    import andi_amd
+    from andi_amd import synth
+    from conftest import knobs
+    seqs, _ = synth.genome_set(12, 4_900_000, 0.0004, 0.03, seed=20261)
+    subjects = [0, 5, 11]
+    with knobs(**_NO_SCAN_SWITCH):
+        c = andi_amd.Context(0)
+        c.expect_queries(len(seqs) - 1)
+        Q = andi_amd.Queries(c, seqs)
+        esas = [andi_amd.Esa(c, s, sa="device") for s in seqs]
+        c.timings_reset()
+        got = andi_amd.scan_rows(c, esas, list(range(len(seqs))), Q)
+        t = c.timings()
+        assert t["coop_calls"] + t["coop_fallbacks"] == 1, t  # the call was of trial size
+        assert t["fixups"] == 0
+        pairs = [(r, j) for r in range(3) for j in (1, 4, 7, 10)]
+        _sampled_pairs_against_oracle(orc, seqs, [esas[i] for i in subjects], subjects, got[subjects], pairs)
+        for e in esas:
+            e.close()
+        Q.close()
+        c.close()
+
+
+def test_c4_shaped_call_at_full_length_against_the_oracle(orc):
+    """The shape of bench.py's extra.c4_shape -- 8 subject rows of one call, hundreds of queries of 2.1 Mbp each, extended
+    probe-table entries (>= 256 queries per subject) -- on the default path, 10 sampled ordered pairs against the oracle."""
+    import andi_amd
+    from conftest import knobs
+    n, G = 2_100_000, 320
+    seqs = _star_set(G, n, 0.001, 0.015, seed=3085)
+    subjects = [0, 1, 77, 150, 151, 200, 318, 319]
+    with knobs(**_NO_SCAN_SWITCH):
+        c = andi_amd.Context(0)
+        c.expect_queries(G - 1)
+        Q = andi_amd.Queries(c, seqs)
+        esas = [andi_amd.Esa(c, seqs[i], sa="device") for i in subjects]
+        c.timings_reset()
+        got = andi_amd.scan_rows(c, esas, subjects, Q)
+        t = c.timings()
+        assert t["scan_pairs"] == 8 * (G - 1) and t["fixups"] == 0
+        assert t["coop_calls"] + t["coop_fallbacks"] == 1, t
+        pairs = [(0, 3), (0, 160), (0, 319), (2, 0), (2, 78), (2, 250), (7, 5), (7, 100), (7, 200), (7, 318)]
+        _sampled_pairs_against_oracle(orc, seqs, esas, subjects, got, pairs)
+        for e in esas:
+            e.close()
+        Q.close()
+        c.close()

@@ -281,12 +281,10 @@ def test_full_size_properties(ctx, orc):
     assert (got == want).all()
 
 
-@pytest.mark.parametrize("group", ["0", "2", "4", "8"])
-def test_every_scan_implementation_agrees(ctx, orc, knob, group):
-    """ANDI_SCAN_G selects passes A/B: 0 = one lane per chain on packed symbols
-    (scan_lane.hip, the default), 2/4/8 = lane groups on bytes (scan.hip)."""
+def test_contigs_models_and_segment_lengths(ctx, orc):
+    """Passes A/B (one lane per chain on packed symbols, scan_lane.hip) on a set with joined contigs, at two
+    segment lengths, and LogDet / ANI (per-nucleotide anchor counts)."""
     from andi_amd import synth
-    knob("ANDI_SCAN_G", group)
     rng = np.random.default_rng(5)
     a, b = synth.pair(80000, 0.04, seed=3)
     c = synth.to_bytes(synth.mutate_codes(synth.base_codes(80000, 3), 0.003, 11))
@@ -335,31 +333,6 @@ def test_segment_length_per_pair_changes_nothing(ctx, orc, knob):
             knob(k, v)
         got, t = _gpu_rows(ctx, seqs)
         assert (got == want).all(), env
-
-
-@pytest.mark.parametrize("lines", ["2,2", "4,4", "8,4", "8,8"])
-def test_pass_a_in_rounds_agrees(ctx, orc, knob, lines):
-    """ANDI_ROUNDS=QP,SP runs pass A as scan_rounds.hip does it: chains as state machines, all loads of a
-    wavefront in one place, the streams through line buffers in LDS, probe-table entries that carry the
-    symbols behind a K-mer that occurs once.  Same counts, whatever the buffers' sizes and however often
-    the wavefront goes to memory."""
-    import andi_amd
-    from andi_amd import synth
-    if not andi_amd.lib.has_experiments():
-        pytest.skip("scan_rounds.hip is in the experiments build only (make -C andi_amd/csrc experiments; ANDI_HIP_LIB)")
-    knob("ANDI_ROUNDS", lines)
-    rng = np.random.default_rng(6)
-    base = synth.base_codes(90000, 13)
-    a = synth.to_bytes(base)
-    seqs = [a] + [synth.to_bytes(synth.mutate_codes(base, d, 40 + k)) for k, d in enumerate((0.0007, 0.01, 0.05, 0.15))]
-    unit = rand_dna(rng, 2500)
-    rep = rand_dna(rng, 20000) + unit + rand_dna(rng, 9000) + unit + rand_dna(rng, 7000) + unit[::-1].translate(
-        bytes.maketrans(b"ACGT", b"TGCA"))  # a repeat on both strands: K-mers with several occurrences
-    joined = a[:30000] + b"!" + rand_dna(rng, 700) + b"!" + seqs[2][30000:70000]
-    seqs += [rep, rep[:25000] + a[5000:30000], joined, rand_dna(rng, 3000, b"AC"), rand_dna(rng, 50)]
-    for passes in ("1", "3", "50"):
-        knob("ANDI_ROUNDS_PASSES", passes)
-        _check_set(ctx, orc, seqs, segments=(0, 1500, 64))
 
 
 def test_realistic_divergence_structure(ctx, orc):
@@ -449,26 +422,6 @@ def test_bad_stretches_are_stitched_in_pass_b(ctx, orc):
         left[seg] = t["fixups"]
     print("fix-ups left to pass C by segment length:", left)
     assert left[0] + left[300] + left[2048] <= 20, left  # (segments of 64: stretches run into each other, pass C takes what three rounds leave)
-
-
-@pytest.mark.parametrize("variant", ["1", "2"])
-def test_pass_a_variants_agree(ctx, orc, knob, variant):
-    """ANDI_LANE_STREAM=1: pass A with the chain step cut in two (scan_lane.hip: lane_cold_stream) -- every trip
-    the lanes on a diagonal settle one window of it, then the lanes that need one probe together; an experiment
-    (measured slower than the straight-line step).  ANDI_LANE_STREAM=2: EVERY pair through k_lane_quad -- the
-    streams fetched by quads of lanes, comparisons resumed trip after trip -- which by default takes only the pairs
-    with long matches and only with per-pair segment lengths (here also with one segment length for the call, where
-    the lanes of a quad belong to different queries).  Same counts."""
-    import andi_amd
-    from andi_amd import synth
-    if variant == "1" and not andi_amd.lib.has_experiments():
-        pytest.skip("lane_cold_stream is in the experiments build only (make -C andi_amd/csrc experiments; ANDI_HIP_LIB)")
-    knob("ANDI_LANE_STREAM", variant)
-    seqs, _ = synth.realistic_set(5, 150000, 0.0005, 0.08, seed=5, novel_fraction=0.05)
-    seqs.append(seqs[0])  # identical to its subject: one anchor as long as the sequence
-    seqs.append(synth.to_bytes(synth.mutate_codes(synth.realistic_base(150000, 5), 0.0004, 9)))  # long matches
-    _check_set(ctx, orc, seqs, segments=(0, 1024, 77))
-    _check_set(ctx, orc, seqs[:3], model=4)
 
 
 def test_pairs_with_long_matches_take_the_quad_kernel(ctx, orc, knob):
