@@ -109,9 +109,12 @@ struct andi_hip_ctx {
 	size_t sa_ws_bytes = 0;
 	int32_t *sa_pinned = nullptr;
 	uint32_t *h_quad_waves = nullptr; // pinned: the length of k_lane_quad's list of a scan call
-	uint32_t *d_coop_abort = nullptr; // pass A by wavefronts on trial: the word its wavefronts set when the call is not their kind
-	uint32_t *h_coop_abort = nullptr; // pinned copy
-	uint32_t coop_backoff = 0;        // scan calls for which the trial is skipped (it failed recently)
+	hipStream_t coop_stream = nullptr; // routed scan calls: pass A by wavefronts runs beside the lane scan's kernels
+	hipEvent_t coop_fork = nullptr, coop_join = nullptr, l2_fork = nullptr, l2_join = nullptr;
+	uint32_t *h_any_left = nullptr;    // pinned: [0] the wavefront kernel handed some pair back, [1] wavefronts of the lane layout
+	void *scratch2 = nullptr;          // the second lane layout (those pairs), grown on demand
+	size_t scratch2_bytes = 0;
+	unsigned long long *d_route = nullptr; // routed scan calls: query nucleotides whose pass A ran by wavefronts / by lanes, pairs handed back (read with the timings)
 	std::vector<EventPair> pending;
 	andi_hip_timings acc{};
 };
@@ -335,8 +338,14 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_quad_waves, sizeof(uint32_t), hipHostMallocDefault);
-	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_coop_abort, sizeof(uint32_t), hipHostMallocDefault);
-	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_coop_abort, sizeof(uint32_t));
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->coop_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_fork, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_join, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_fork, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_join, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_any_left, 2 * sizeof(uint32_t), hipHostMallocDefault);
+	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_route, 4 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemset(ctx->d_route, 0, 4 * sizeof(unsigned long long));
 	if (e != hipSuccess) {
 		set_err(errbuf, errlen, "context setup: %s", hipGetErrorString(e));
 		andi_hip_ctx_destroy(ctx);
@@ -370,8 +379,17 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->sa_ws) (void)andi_arena::dev_free(ctx->sa_ws);
 	if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
 	if (ctx->h_quad_waves) (void)hipHostFree(ctx->h_quad_waves);
-	if (ctx->h_coop_abort) (void)hipHostFree(ctx->h_coop_abort);
-	if (ctx->d_coop_abort) (void)andi_arena::dev_free(ctx->d_coop_abort);
+	if (ctx->d_route) (void)andi_arena::dev_free(ctx->d_route);
+	if (ctx->scratch2) (void)andi_arena::dev_free(ctx->scratch2);
+	if (ctx->h_any_left) (void)hipHostFree(ctx->h_any_left);
+	if (ctx->coop_stream) {
+		(void)hipStreamSynchronize(ctx->coop_stream);
+		(void)hipStreamDestroy(ctx->coop_stream);
+	}
+	if (ctx->coop_fork) (void)hipEventDestroy(ctx->coop_fork);
+	if (ctx->coop_join) (void)hipEventDestroy(ctx->coop_join);
+	if (ctx->l2_fork) (void)hipEventDestroy(ctx->l2_fork);
+	if (ctx->l2_join) (void)hipEventDestroy(ctx->l2_join);
 	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
 	if (ctx->side_stream) {
 		(void)hipStreamSynchronize(ctx->side_stream);
@@ -844,9 +862,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// length for the call.
 	// Pass A with one wavefront per chain (scan_coop.hip) for the models that split an anchor's length evenly and
 	// thresholds a 32-symbol window can decide.  ANDI_COOP=n: the call's pass A, one (long) segment length for the call.
-	// Unset: ON TRIAL for large calls -- it runs first, on its own segmentation; a wavefront that meets what the
-	// kernel is slow at (a pair with long matches, a stretch without homology) ends the trial and the call takes the
-	// lane scan as if nothing had happened (a context whose trial failed skips the next ones).
+	// Unset: large calls are ROUTED PER PAIR (scan.h) -- the pairs whose sampled matches suit that kernel take it, on a
+	// segmentation of its own; the others, and the pairs it hands back, take the lane scan; passes B and C run per layout.
 	const int coop_mode = andi_coop_enabled();
 	int coop_ok = coop_mode != 0 && model <= ANDI_M_KIMURA && !andi_knob(KNOB_FORCE_REFERENCE);
 	for (size_t s = 0; s < nsub && coop_ok; ++s)
@@ -860,9 +877,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	while (coop_seg > 32768 && q->total_nt * (uint64_t)nsub / coop_seg < 24576) coop_seg /= 2;
 	if (const char *cs = andi_knob(KNOB_COOP_SEG)) // experiments
 		if (atoi(cs) >= 64) coop_seg = (uint32_t)atoi(cs);
-	bool coop_trial = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub / 32768 >= (1u << 14) &&
-					  !andi_knob(KNOB_UNIFORM_SEGMENTS) && !andi_knob(KNOB_FORCE_ADAPTIVE);
-	if (coop_trial && ctx->coop_backoff) --ctx->coop_backoff, coop_trial = false;
+	bool routed = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub / 32768 >= (1u << 14) &&
+				  !andi_knob(KNOB_UNIFORM_SEGMENTS) && !andi_knob(KNOB_FORCE_ADAPTIVE);
 	const bool want_adaptive = !coop && segment == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
 							   !andi_knob(KNOB_UNIFORM_SEGMENTS);
 	if (segment == 0 && coop) {
@@ -931,7 +947,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 								ctx->stream));
 	HIP_TRY(ctx, hipEventRecord(ctx->desc_done, ctx->stream));
 
-	if (any_reference) coop_trial = false;
+	if (any_reference) routed = false;
 	// scratch: per (subject, segment) two states and two count vectors
 	bool adaptive = want_adaptive && !any_reference;
 	uint32_t seg0 = segment / 2; // classes: 1/2, 1, 2, 4 times the call's segment length
@@ -957,13 +973,13 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		if (!fits || (10 * used < 7 * 64 * max_waves && !andi_knob(KNOB_FORCE_ADAPTIVE))) adaptive = false, max_waves = 0;
 	}
 	const size_t pairs_all = nsub * q->nq;
-	// (the trial wants the pairs' sampled classes -- k_pair_estimate runs for the per-pair layout only: calls that do not
+	// (routing wants the pairs' sampled classes -- k_pair_estimate runs for the per-pair layout only: calls that do not
 	// get that layout keep the lane scan)
-	if (!adaptive) coop_trial = false;
-	if (coop_trial && ensure_segmentation(ctx, q, coop_seg, true)) return 1;
-	size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
-	if (coop_trial && slots < nsub * (size_t)q->c_total_segs) slots = nsub * (size_t)q->c_total_segs; // (both layouts carve the same scratch)
-	const size_t need = slots * ANDI_SLOT_BYTES + 128 +
+	if (!adaptive) routed = false;
+	if (routed && ensure_segmentation(ctx, q, coop_seg, true)) return 1;
+	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
+	const size_t slots2 = routed ? nsub * (size_t)q->c_total_segs : 0; // (the wavefront kernel's layout, beside the lane scan's)
+	const size_t need = (slots + slots2) * ANDI_SLOT_BYTES + 256 +
 						(adaptive ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -982,30 +998,33 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.qseg_start = q->d_qseg_start, a.seg2query = q->d_seg2query;
 	a.total_segs = q->total_segs, a.seg = segment;
 	char *p = (char *)ctx->scratch;
-	a.cold_exit = (ChainState *)p;
-	p += slots * sizeof(ChainState);
-	a.true_exit = (ChainState *)p;
-	p += slots * sizeof(ChainState);
-	a.used_entry = (ChainState *)p;
-	p += slots * sizeof(ChainState);
-	a.cold_counts = (uint32_t *)p;
-	p += slots * 16 * sizeof(uint32_t);
-	a.owned = (uint32_t *)p;
-	p += slots * 16 * sizeof(uint32_t);
-	a.marks = (ColdMark *)p;
-	p += slots * ANDI_COLD_MARKS * sizeof(ColdMark);
-	a.exit_p = (uint32_t *)p;
-	p += slots * sizeof(uint32_t);
-	p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-	a.restitch_count = (uint32_t *)p;
-	a.restitch_round = 0;
-	a.defer_count = a.restitch_count + 8;
-	p += 64;
-	a.defer_list = (unsigned long long *)p;
-	p += slots * sizeof(unsigned long long);
-	a.first_pub = (unsigned long long *)p; // (k_lane_quad, per-pair segment lengths only)
-	a.stretch_bad = (uint8_t *)p;          // (pass B: a byte per slot, while first_pub is idle)
-	p += slots * sizeof(unsigned long long);
+	auto carve = [&p](ScanArgs &x, size_t n) { // the per-slot arrays of a layout of n slots
+		x.cold_exit = (ChainState *)p;
+		p += n * sizeof(ChainState);
+		x.true_exit = (ChainState *)p;
+		p += n * sizeof(ChainState);
+		x.used_entry = (ChainState *)p;
+		p += n * sizeof(ChainState);
+		x.cold_counts = (uint32_t *)p;
+		p += n * 16 * sizeof(uint32_t);
+		x.owned = (uint32_t *)p;
+		p += n * 16 * sizeof(uint32_t);
+		x.marks = (ColdMark *)p;
+		p += n * ANDI_COLD_MARKS * sizeof(ColdMark);
+		x.exit_p = (uint32_t *)p;
+		p += n * sizeof(uint32_t);
+		p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+		x.restitch_count = (uint32_t *)p;
+		x.restitch_round = 0;
+		x.defer_count = x.restitch_count + 8;
+		p += 64;
+		x.defer_list = (unsigned long long *)p;
+		p += n * sizeof(unsigned long long);
+		x.first_pub = (unsigned long long *)p; // (k_lane_quad, per-pair segment lengths only)
+		x.stretch_bad = (uint8_t *)p;          // (pass B: a byte per slot, while first_pub is idle)
+		p += n * sizeof(unsigned long long);
+	};
+	carve(a, slots);
 	a.adaptive = adaptive ? 1 : 0;
 	a.seg0 = seg0, a.max_waves = (uint32_t)max_waves;
 	a.max_class = 0; // long segments must not leave the device short of chains
@@ -1031,54 +1050,116 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		a.knock = kn ? (uint32_t)atoi(kn) : 0u;
 	}
 	a.coop = coop && !a.adaptive;
-	a.coop_abort = nullptr, a.coop_classes = 0;
+	a.route = routed ? ANDI_LAYOUT_LANES : 0, a.route_seg = coop_seg, a.route_nt = ctx->d_route;
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 
-	if (a.adaptive) {
-		Timed t(ctx, 2);
-		hipError_t e = andi_launch_pair_layout(a, ctx->stream);
-		t.stop();
-		if (e != hipSuccess) return fail(ctx, "scan layout", e);
-	}
-	bool coop_done = false;
-	if (coop_trial) {
-		// pass A by wavefronts on trial: its own (long) segments in the same scratch; the pairs' classes, if the call
-		// has sampled them, tell it which pairs are not its kind
+	if (routed) {
+		// The call's pairs are routed (scan.h): the wavefront kernel's layout b beside the lane scan's a.  The pairs are
+		// sampled and routed; pass A by wavefronts (on a stream of its own) runs beside the lane scan's kernels; the pairs
+		// it handed back -- rare: the host looks -- get a second lane layout a2; passes B and C once per layout.
 		ScanArgs b = a;
-		b.adaptive = 0, b.coop = 1;
+		b.adaptive = 0, b.coop = 1, b.route = ANDI_LAYOUT_COOP;
 		b.qseg_start = q->c_qseg_start, b.seg2query = q->c_seg2query, b.total_segs = q->c_total_segs, b.seg = coop_seg;
-		b.coop_abort = ctx->d_coop_abort, b.coop_classes = a.adaptive;
-		Timed t(ctx, 1);
-		hipError_t e = hipMemsetAsync(ctx->d_coop_abort, 0, sizeof(uint32_t), ctx->stream);
-		if (e == hipSuccess) e = andi_launch_coop_cold(b, ctx->stream);
-		if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_coop_abort, ctx->d_coop_abort, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
-		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-		if (e != hipSuccess) return fail(ctx, "scan pass A", e);
-		if (*ctx->h_coop_abort == 0) {
+		p = (char *)(a.pair_class + pairs_all);
+		p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+		carve(b, slots2);
+		hipError_t e;
+		{
+			Timed t(ctx, 2);
+			e = hipMemsetAsync(b.restitch_count, 0, 16 * sizeof(uint32_t), ctx->stream);
+			if (e == hipSuccess) e = andi_launch_pair_layout(a, ctx->stream);
 			t.stop();
-			coop_done = true;
-			b.coop_abort = nullptr;
+			if (e != hipSuccess) return fail(ctx, "scan layout", e);
+		}
+		if (andi_knob(KNOB_DEBUG_STITCH)) { // diagnostics: how the pairs were routed
+			std::vector<uint8_t> cls(pairs_all);
+			(void)hipStreamSynchronize(ctx->stream);
+			(void)hipMemcpy(cls.data(), a.pair_class, pairs_all, hipMemcpyDeviceToHost);
+			size_t n_coop = 0, n_quad = 0, n_other = 0;
+			for (size_t i = 0; i < pairs_all; ++i)
+				if (h_self[i / q->nq] != (int64_t)(i % q->nq)) (cls[i] & ANDI_ROUTE_COOP ? n_coop : cls[i] & 0x80u ? n_quad : n_other)++;
+			fprintf(stderr, "route: %zu pairs by wavefronts, %zu k_lane_quad's class, %zu other lanes (unrelated stretches suspected / short query / many pairs far apart)\n", n_coop, n_quad, n_other);
+		}
+		bool any_left = false;
+		{
+			Timed t(ctx, 1);
+			// Which of the two goes first: the lane scan's kernels where its pairs are few -- behind the wavefront kernel a
+			// handful of lane blocks (four wavefronts and their LDS on one CU at once) found no place until that kernel's
+			// tail and ended 0.2 ms after everything else --, the wavefront kernel where they are many (the tree-structured
+			// set, the C4 shape: 0.4 and 1.5 ms the other way round).  The host looks at the layout (one word).
+			e = hipMemcpyAsync(ctx->h_any_left + 1, a.pair_wave0 + pairs_all, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			const bool lanes_first = e == hipSuccess && (uint64_t)ctx->h_any_left[1] * 20 < max_waves;
+			if (e == hipSuccess) e = hipEventRecord(ctx->coop_fork, ctx->stream);
+			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->coop_stream, ctx->coop_fork, 0);
+			if (e == hipSuccess && lanes_first) e = andi_launch_scan_cold(a, ctx->stream);
+			if (e == hipSuccess) e = andi_launch_coop_cold(b, ctx->coop_stream);
+			if (e == hipSuccess) e = hipEventRecord(ctx->coop_join, ctx->coop_stream);
+			if (e == hipSuccess && !lanes_first) e = andi_launch_scan_cold(a, ctx->stream);
+			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->coop_join, 0);
+			if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_any_left, b.restitch_count + ANDI_ROUTE_ANY_LEFT, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			if (e != hipSuccess) return fail(ctx, "scan pass A", e);
+			any_left = ctx->h_any_left[0] != 0;
+			const bool any_lanes = ctx->h_any_left[1] != 0; // (no pair in the lane layout: its passes B and C have nothing to do)
+			ScanArgs a2 = a;
+			if (any_left) { // the pairs handed back: a lane layout of their own (as large as the first at most)
+				const size_t need2 = slots * ANDI_SLOT_BYTES + 256 + pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16;
+				if (ctx->scratch2_bytes < need2) {
+					if (ctx->scratch2) (void)andi_arena::dev_free(ctx->scratch2);
+					ctx->scratch2 = nullptr, ctx->scratch2_bytes = 0;
+					HIP_TRY(ctx, andi_arena::dev_malloc(&ctx->scratch2, need2));
+					ctx->scratch2_bytes = need2;
+				}
+				p = (char *)ctx->scratch2;
+				carve(a2, slots);
+				a2.route = ANDI_LAYOUT_LANES2;
+				a2.pair_waves = (uint32_t *)p;
+				a2.pair_wave0 = a2.pair_waves + pairs_all;
+				a2.pair_bsum = a2.pair_wave0 + pairs_all + 1;
+				a2.side_stream = nullptr; // (its own kernels one after the other: it runs on the side stream itself, below)
+			}
+			t.stop();
+			// Passes B and C once per layout, side by side (each is a chain of small launches); the pairs handed back take
+			// their pass A at the head of their chain.
 			Timed t2(ctx, 2);
-			e = andi_launch_scan_stitch(b, ctx->stream);
-			if (e == hipSuccess) e = andi_launch_scan_reduce(b, ctx->stream);
+			e = hipEventRecord(ctx->l2_fork, ctx->stream);
+			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->coop_stream, ctx->l2_fork, 0);
+			if (e == hipSuccess) e = andi_launch_scan_stitch(b, ctx->coop_stream);
+			if (e == hipSuccess) e = andi_launch_scan_reduce(b, ctx->coop_stream);
+			if (e == hipSuccess) e = hipEventRecord(ctx->coop_join, ctx->coop_stream);
+			if (e == hipSuccess && any_left) {
+				e = hipStreamWaitEvent(ctx->side_stream, ctx->l2_fork, 0);
+				if (e == hipSuccess) e = andi_launch_pair_leftover(a2, ctx->side_stream);
+				if (e == hipSuccess) e = andi_launch_scan_cold(a2, ctx->side_stream);
+				if (e == hipSuccess) e = andi_launch_scan_stitch(a2, ctx->side_stream);
+				if (e == hipSuccess) e = andi_launch_scan_reduce(a2, ctx->side_stream);
+				if (e == hipSuccess) e = hipEventRecord(ctx->l2_join, ctx->side_stream);
+			}
+			if (e == hipSuccess && any_lanes) e = andi_launch_scan_stitch(a, ctx->stream);
+			if (e == hipSuccess && any_lanes) e = andi_launch_scan_reduce(a, ctx->stream);
+			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->coop_join, 0);
+			if (e == hipSuccess && any_left) e = hipStreamWaitEvent(ctx->stream, ctx->l2_join, 0);
+			if (e == hipSuccess) e = andi_launch_route_count(a, ctx->stream);
 			t2.stop();
 			if (e != hipSuccess) return fail(ctx, "scan passes B/C", e);
-			ctx->acc.coop_calls++;
-		} else { // not its kind of call: the lane scan, and no more trials for a while
-			ctx->coop_backoff = 16;
-			ctx->acc.coop_fallbacks++;
-			e = andi_launch_scan_cold(a, ctx->stream);
+		}
+		ctx->acc.coop_calls++;
+		ctx->acc.routed_calls++;
+	} else {
+		if (a.adaptive) {
+			Timed t(ctx, 2);
+			hipError_t e = andi_launch_pair_layout(a, ctx->stream);
+			t.stop();
+			if (e != hipSuccess) return fail(ctx, "scan layout", e);
+		}
+		{
+			Timed t(ctx, 1);
+			hipError_t e = andi_launch_scan_cold(a, ctx->stream);
 			t.stop();
 			if (e != hipSuccess) return fail(ctx, "scan pass A", e);
+			if (a.coop) ctx->acc.coop_calls++;
 		}
-	} else {
-		Timed t(ctx, 1);
-		hipError_t e = andi_launch_scan_cold(a, ctx->stream);
-		t.stop();
-		if (e != hipSuccess) return fail(ctx, "scan pass A", e);
-		if (a.coop) ctx->acc.coop_calls++;
-	}
-	if (!coop_done) {
 		Timed t(ctx, 2);
 		hipError_t e = andi_launch_scan_stitch(a, ctx->stream);
 		if (e == hipSuccess) e = andi_launch_scan_reduce(a, ctx->stream);
@@ -1092,7 +1173,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		fprintf(stderr, "stitch: %zu slots; true chains that left on their own %u; stitched again in rounds: %u %u %u; last list %u\n", slots,
 				h[ANDI_RESTITCH_ROUNDS], h[0], h[1], h[2], h[8]);
 	}
-	((adaptive && !coop_done) ? ctx->acc.adaptive_calls : ctx->acc.uniform_calls)++;
+	(adaptive ? ctx->acc.adaptive_calls : ctx->acc.uniform_calls)++;
 	ctx->acc.scan_pairs += pairs;
 	ctx->acc.scan_query_nt += nt;
 	return 0;
@@ -1128,9 +1209,11 @@ int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t) {
 	if (!ctx || !t) return 1;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	resolve_events(ctx);
-	unsigned long long fx = 0;
+	unsigned long long fx = 0, rt[4] = {0, 0, 0, 0};
 	HIP_TRY(ctx, hipMemcpy(&fx, ctx->d_fixups, sizeof fx, hipMemcpyDeviceToHost));
+	HIP_TRY(ctx, hipMemcpy(rt, ctx->d_route, sizeof rt, hipMemcpyDeviceToHost));
 	ctx->acc.fixups = fx;
+	ctx->acc.coop_query_nt = rt[0], ctx->acc.lane_query_nt = rt[1], ctx->acc.coop_fallbacks = rt[2];
 	*t = ctx->acc;
 	return 0;
 }
@@ -1140,6 +1223,7 @@ void andi_hip_timings_reset(andi_hip_ctx *ctx) {
 	(void)hipStreamSynchronize(ctx->stream);
 	resolve_events(ctx);
 	(void)hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
+	(void)hipMemset(ctx->d_route, 0, 4 * sizeof(unsigned long long));
 	ctx->acc = andi_hip_timings{};
 }
 

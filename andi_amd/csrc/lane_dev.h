@@ -147,6 +147,8 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a, uint32_t wave =
 			it.start = it.seg_in_q * a.seg;
 			it.end = it.start + a.seg < qlen ? it.start + a.seg : qlen;
 			it.valid = a.self[it.sub] != (int64_t)it.qidx;
+			// (a routed call's uniform layout is the wavefront kernel's: the pairs it kept)
+			if (a.route == ANDI_LAYOUT_COOP && (a.pair_class[it.sub * a.nq + it.qidx] & (ANDI_ROUTE_COOP | ANDI_ROUTE_LEFT)) != ANDI_ROUTE_COOP) it.valid = false;
 		}
 		return it;
 	}

@@ -94,8 +94,17 @@ struct ScanArgs {
 	// matches, k_lane_cold for the others) share the device instead of each ending in a tail of its own
 	hipStream_t side_stream;
 	hipEvent_t side_fork, side_join;
-	uint32_t *coop_abort; // pass A by wavefronts on trial (null: it is the call's pass A, come what may): a wavefront that meets what the kernel is slow at -- a pair with long matches, a stretch without homology -- sets the word and all return; the host then takes the lane scan
-	int coop_classes;    // the pairs' classes are valid (k_pair_estimate has run): a call most of whose pairs are of k_lane_quad's class ends the trial at once
+	// Pass A of a call is ROUTED PER PAIR (route != 0; the engine's choice for large calls).  k_pair_estimate samples every
+	// pair; k_pair_route marks the pairs that suit pass A by wavefronts (scan_coop.hip) -- matches neither long (k_lane_quad's
+	// class) nor hardly reaching the anchor threshold, unless such pairs are few; no runs of short matches (unrelated
+	// stretches) -- with ANDI_ROUTE_COOP in their pair_class byte: they get no wavefronts in the lane layout, whose kernels
+	// run beside that kernel.  A wavefront of k_coop_cold that meets what it is slow at all the same (a stretch without
+	// homology, a match longer than its segment) marks its pair ANDI_ROUTE_LEFT and returns, as do the pair's other
+	// wavefronts when they see the mark; such pairs (rare) get a lane layout of their own afterwards (ANDI_ROUTE_L2).
+	// Passes B and C run once per layout, each on its own pairs.
+	int route; // 0: no routing (every pair takes the call's one pass A); else the layout these arguments describe: ANDI_LAYOUT_*
+	uint32_t route_seg;           // the wavefront kernel's segment length in a routed call
+	unsigned long long *route_nt; // [3]: query nucleotides of the pairs whose pass A ran by wavefronts / by lanes, pairs handed back
 	int coop;            // pass A with one wavefront per chain (scan_coop.hip): one segment length, RAW/JC/Kimura, probe-table subjects
 	uint32_t knock;      // diagnostic builds (-DANDI_LANE_STATS): parts of pass A switched off to time them (results are then wrong)
 };
@@ -105,8 +114,11 @@ struct ScanArgs {
 // set to 1 if a byte is none of A C G T ! ; # NUL (the packed scan is then not applicable)
 hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N0, uint8_t *N1,
 									int32_t *foreign, hipStream_t st);
-// adaptive mode: sample every pair's match lengths, choose its segment length, lay out the slots
+// adaptive mode: sample every pair's match lengths, choose its segment length (and, in a routed call, its pass A), lay out the slots
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
+// routed calls: the second lane layout (a2: the pairs pass A by wavefronts handed back); who took what, for the timings
+hipError_t andi_launch_pair_leftover(const ScanArgs &a2, hipStream_t st);
+hipError_t andi_launch_route_count(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 // pass A with one wavefront per chain (scan_coop.hip); andi_coop_enabled(): 0 = off (ANDI_COOP=0), else the window's length in chunks of 2048 symbols
 int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: on trial for calls it suits (the default); n > 0: windows of 2048 n symbols, unconditionally
@@ -130,7 +142,16 @@ hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStr
 #ifndef ANDI_STITCH_MANY
 #define ANDI_STITCH_MANY 4096
 #endif
-static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at the front, defer_count at 8, ANDI_STRAGGLERS at 12, ANDI_QUAD_WAVES at 13");
+static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at the front, defer_count at 8, ANDI_ROUTE_ANY_LEFT at 11, ANDI_STRAGGLERS at 12, ANDI_QUAD_WAVES at 13, ANDI_SPARSE_WAVES at 14, ANDI_ALL_WAVES at 15");
+#define ANDI_ROUTE_COOP 0x40u /* pair_class: the pair takes pass A by wavefronts (routed calls) */
+#define ANDI_ROUTE_LEFT 0x20u /* ... which handed it back */
+#define ANDI_ROUTE_SOFT 0x10u /* (k_pair_estimate to k_pair_route) the lane scan is better at it, if such pairs are more than a few */
+#define ANDI_ROUTE_L2 0x08u   /* a pair handed back: in the second lane layout */
+#define ANDI_LAYOUT_LANES 1   /* ScanArgs.route: the lane scan's pairs */
+#define ANDI_LAYOUT_LANES2 2  /* the pairs pass A by wavefronts handed back */
+#define ANDI_LAYOUT_COOP 3    /* the wavefront kernel's pairs (one segment length) */
+#define ANDI_ROUTE_ANY_LEFT 11 /* restitch_count[this] of the wavefront kernel's layout: some pair was handed back */
+#define ANDI_ALL_WAVES 15      /* restitch_count[this] during the layout: wavefronts of all pairs (beside ANDI_SPARSE_WAVES) */
 #define ANDI_QUAD_WAVES 13 /* restitch_count[this] during pass A: wavefronts on k_lane_quad's list */
 #define ANDI_SPARSE_WAVES 14 /* restitch_count[this] during pass A: wavefronts of pairs whose sampled mean match is below ANDI_SPARSE_MATCH */
 #define ANDI_SPARSE_MATCH 19u

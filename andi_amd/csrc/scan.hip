@@ -445,6 +445,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 		return;
 	}
 
+	if (a.route) { // a routed call: every layout reduces its own pairs
+		const uint32_t cls = a.pair_class[sub * a.nq + qidx];
+		const bool mine = a.route == ANDI_LAYOUT_COOP ? (cls & (ANDI_ROUTE_COOP | ANDI_ROUTE_LEFT)) == ANDI_ROUTE_COOP
+						: a.route == ANDI_LAYOUT_LANES2 ? (cls & ANDI_ROUTE_L2) != 0
+						: !(cls & (ANDI_ROUTE_COOP | ANDI_ROUTE_L2));
+		if (!mine) return;
+	}
 	uint32_t *total = s_hist[0];
 	uint32_t *histT = s_hist[1], *histC = s_hist[2];
 	if (threadIdx.x < 16) total[threadIdx.x] = 0;

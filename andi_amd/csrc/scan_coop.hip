@@ -35,8 +35,8 @@ namespace {
 #define COOP_HCAP (NCH <= 2 ? 64u : 24u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
 constexpr int COOP_WAVES = 1; // wavefronts per block: single wavefronts find a place on a CU the moment one leaves (bench set 5.39 -> 5.24 ms against blocks of two, 5.61 with four); seven per SIMD (72 registers): 4.94
 constexpr uint32_t COOP_KCAP = 32; // stretches of a window that are counted nowhere (more: the window ends before the next one)
-constexpr uint32_t COOP_TRIAL_G = 192;   // on trial: a segment that needs more generic steps than this is in a stretch without homology (clean sets: <= 45)
-constexpr uint32_t COOP_TRIAL_LCP = 16;  // on trial: a match followed through more rounds of 2048 symbols than this is longer than its segment
+constexpr uint32_t COOP_TRIAL_G = 1536;  // routed calls: a segment that needs more generic steps than this lies in long stretches without homology that the sampling missed (clean sets: <= 45; an island of 20 kbp: some 1500) -- the pair is handed back
+constexpr uint32_t COOP_TRIAL_LCP = 16;  // routed calls: a match followed through more rounds of 2048 symbols than this is longer than its segment
 constexpr uint32_t COOP_PARK = 16; // parked lanes (their probe needs lane_probe) that are served together
 constexpr uint32_t COOP_MAX_X = 3;  // anchors off the window's diagonal a walk follows before it gives up
 constexpr uint32_t NOPOS = 0xffffffffu;
@@ -867,7 +867,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 // ------------------------------------------------------------------ the kernel
 template <int NCH>
 #ifndef COOP_OCC
-#define COOP_OCC 7
+#define COOP_OCC 8
 #endif
 __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_coop_cold(ScanArgs a) {
 	__shared__ CoopLds<NCH> s_lds[COOP_WAVES];
@@ -885,18 +885,15 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 	const size_t slot = (size_t)sub * a.total_segs + wseg;
 	const uint32_t n = (uint32_t)c.E.n, thr = c.thr;
 
-	auto give_up = [&]() { // on trial: this is not the kernel's kind of call
-		if (lane == 0) __hip_atomic_store(a.coop_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	// a routed call (scan.h): the pairs k_pair_estimate marked for this kernel; a wavefront that meets what the kernel is slow
+	// at hands its PAIR back to the lane scan -- a mark all the pair's wavefronts look at
+	uint8_t *route = a.route ? a.pair_class + (size_t)sub * a.nq + qidx : nullptr;
+	auto give_up = [&]() {
+		if (lane == 0) a.restitch_count[ANDI_ROUTE_ANY_LEFT] = 1;
+		if (lane == 0) __hip_atomic_store(route, (uint8_t)(__hip_atomic_load(route, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | ANDI_ROUTE_LEFT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	};
-	auto given_up = [&]() { return a.coop_abort && uni(__hip_atomic_load(a.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0; };
-	if (a.coop_abort) {
-		// a call whose pairs mostly have long matches (a quarter of the layout's wavefronts on k_lane_quad's list) is the
-		// lane scan's: its two kernels stream such pairs faster than the windows here
-		// (so is one of pairs so far apart that matches hardly reach the anchor threshold: their true and cold chains
-		// meet slowly, and with long segments pass B has few lanes to take those replays)
-		if (a.coop_classes && 4 * (a.restitch_count[ANDI_QUAD_WAVES] + a.restitch_count[ANDI_SPARSE_WAVES]) > a.pair_wave0[a.nsub * a.nq]) return give_up();
-		if (given_up()) return;
-	}
+	auto given_up = [&]() { return route && (uni(__hip_atomic_load(route, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & (ANDI_ROUTE_COOP | ANDI_ROUTE_LEFT)) != ANDI_ROUTE_COOP; };
+	if (given_up()) return;
 	if (lane < 16) L.hist[lane] = 0;
 	Chain ch;
 	ch.st = seg_in_q == 0 ? initial_state() : cold_state(start, n);
@@ -910,7 +907,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 	while (st.p < end) {
 		CSTAT(CS_G_STEPS, 1);
 		++my_g;
-		if (a.coop_abort) {
+		if (route) {
 			if (my_g > COOP_TRIAL_G + (a.seg >> 12)) return give_up(); // (a few more per window the segment holds)
 			if (given_up()) return;
 		}
@@ -919,7 +916,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 		uint32_t curS = 0, curLen = 0;
 		if (lucky_applies(st, n, thr)) {
 			curS = st.lastS + (st.p - st.lastQ);
-			curLen = coop_lcp(c, st.p, curS, c.qlen - st.p, a.coop_abort ? COOP_TRIAL_LCP : ~0u);
+			curLen = coop_lcp(c, st.p, curS, c.qlen - st.p, route ? COOP_TRIAL_LCP : ~0u);
 			if (curLen == NOPOS) return give_up();
 			found = lucky = curLen >= thr;
 		}

@@ -28,15 +28,21 @@ namespace {
 // are made seg_factor times that (as a power-of-two multiple of seg0, at most 8 seg0).
 // Short segments keep the lanes of a wavefront close together in memory and the work
 // items small; long ones keep the stitching of low-divergence pairs cheap.
-__global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
-	const uint32_t P = a.nsub * a.nq;
-	const uint32_t pair = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-	if (pair >= P) return;
+// (A block of four wavefronts per pair: every one of them takes the 64 samples of the mean -- the same, so that all know
+// what the pair is a candidate for -- and a quarter of the further samples of a routed call: the kernel's time is the
+// chain of dependent probes of one wavefront, 185 us with one wavefront per pair.)
+constexpr uint32_t EST_WAVES = 4; // (calls of a few thousand pairs; one wavefront per pair beyond: the device is full either way)
+__global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
+	__shared__ uint32_t s_shorts, s_runs;
+	const uint32_t est_waves = blockDim.x >> 6;
+	const uint32_t pair = blockIdx.x, wave = threadIdx.x >> 6;
 	const uint32_t sub = pair / a.nq, qidx = pair % a.nq, lane = threadIdx.x & 63u;
 	if (a.self[sub] == (int64_t)qidx) {
-		if (lane == 0) a.pair_class[pair] = 0, a.pair_waves[pair] = 0;
+		if (threadIdx.x == 0) a.pair_class[pair] = 0, a.pair_waves[pair] = 0;
 		return;
 	}
+	if (threadIdx.x == 0) s_shorts = 0, s_runs = 0;
+	__syncthreads();
 	PairCtx c = make_ctx(a, sub, qidx);
 	const uint32_t p = (uint32_t)(((uint64_t)(2 * lane + 1) * c.qlen) >> 7);
 	LWin w;
@@ -55,7 +61,39 @@ __global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
 	// k_lane_quad only if its short matches are no more than its mean explains (matches end at random: a fraction
 	// 1 - exp(-threshold / mean) of the positions sees less than the threshold), within two standard deviations.
 	bool islands = false;
-	if ((sum >> 6) >= a.quad_min_match && (sum >> 6) < ANDI_ISLAND_MEAN_MAX && a.quad_min_match != 0) { // (wave-uniform)
+	const bool quad_cand = (sum >> 6) >= a.quad_min_match && (sum >> 6) < ANDI_ISLAND_MEAN_MAX && a.quad_min_match != 0;
+	// routed calls: would the pair suit pass A by wavefronts?  (one whole segment of that kernel's at least)
+	const bool coop_cand = a.route && (sum >> 6) < 4 * a.quad_min_match && c.qlen >= a.route_seg; // (matches of 512 symbols and more on average: k_lane_quad's, always)
+	if (coop_cand) { // (wave-uniform)
+		// Unrelated stretches are contiguous: where a sample sees less than a threshold's worth of matching symbols, four
+		// more are taken, 128 symbols apart.  Five short ones in a row come about by chance at the fifth power of the rate of
+		// short samples -- a pair 3 % apart sees a third of its samples short anyway, one 6 % apart two thirds: 1 % and 10 %
+		// of them five times --, inside a stretch without homology every time: 512 samples tell 10 % of unrelated
+		// sequence from none at six standard deviations whatever the divergence.  (The excess of short samples over what
+		// the mean match length explains, the test of k_lane_quad's candidates below, is too weak here: it missed one
+		// structured pair in six and suspected one clean pair in nine; three in a row miss the pairs 5 % and more apart.)
+		const uint32_t T = c.thr + 3; // (beyond what chance matches reach: a 13-mer occurs in a 10 Mbp text one time in seven)
+		uint32_t shorts = 0, runs = 0;
+		for (uint32_t k = wave; k < 8; k += est_waves) {
+			const uint32_t pk = (uint32_t)(((uint64_t)(16 * lane + 2 * k + 1) * c.qlen) >> 10);
+			bool all_short = true;
+			for (uint32_t j = 0; j < 5 && all_short; ++j) {
+				const uint32_t pj = pk + 128 * j;
+				LWin wk;
+				wk.q0 = EMPTY, wk.dg = NO_DIAG;
+				all_short = pj + T < c.qlen && lane_probe(c, pj, wk, T + 1).len < T;
+				if (j == 0 && all_short) ++shorts;
+			}
+			if (all_short) ++runs;
+		}
+#pragma unroll
+		for (int d = 32; d; d >>= 1) shorts += (uint32_t)__shfl_xor((int)shorts, d), runs += (uint32_t)__shfl_xor((int)runs, d);
+		if (lane == 0) atomicAdd(&s_shorts, shorts), atomicAdd(&s_runs, runs);
+		__syncthreads(); // (coop_cand is the same in all four wavefronts: they took the same samples)
+		shorts = s_shorts, runs = s_runs;
+		const float f = (float)shorts / 512.f, f5 = f * f * f * f * f, expect = 512.f * f5;
+		islands = (float)runs > expect + 3.f * sqrtf(expect * (1.f - f5)) + 3.f;
+	} else if (quad_cand) { // (wave-uniform; calls that are not routed, and the pairs with the longest matches)
 		uint32_t shorts = r.len < c.thr ? 1u : 0u;
 		for (uint32_t k = 1; k < 4; ++k) {
 			const uint32_t pk = (uint32_t)(((uint64_t)(8 * lane + 2 * k + 1) * c.qlen) >> 9); // between the first samples
@@ -69,17 +107,22 @@ __global__ __launch_bounds__(BLOCK) void k_pair_estimate(ScanArgs a) {
 		const float expect = 256.f * (1.f - __expf(-(float)c.thr / (float)(sum >> 6)));
 		islands = (float)shorts > expect + 2.f * sqrtf(expect * (1.f - expect / 256.f)) + 2.f;
 	}
-	if (lane == 0) {
+	if (threadIdx.x == 0) {
 		const uint32_t want = (sum >> 6) * a.seg_factor; // mean match length * factor
 		uint32_t cls = 0;
 		while (cls < a.max_class && (a.seg0 << cls) < want) ++cls;
 		const uint32_t seg = a.seg0 << cls, nseg = (c.qlen + seg - 1) / seg;
 		// bit 7: the pair's matches are long enough for pass A with the streams fetched by quads (k_lane_quad)
-		a.pair_class[pair] = (uint8_t)(cls | ((sum >> 6) >= a.quad_min_match && !islands ? 0x80u : 0u));
+		// (routed calls) pairs the lane scan is better at -- matches hardly reaching the anchor threshold (divergence beyond
+		// some 6 %: their chains probe at nearly every step and meet their neighbours' slowly; with long segments pass B has
+		// few lanes for those replays), matches of 128 symbols and more (k_lane_quad streams them faster) -- take it where
+		// they are more than a tenth of the call; a few of them ride along with the wavefront kernel (k_pair_route)
+		const bool soft = (sum >> 6) < ANDI_SPARSE_MATCH || (sum >> 6) >= a.quad_min_match;
+		const bool quad = (sum >> 6) >= a.quad_min_match && !(islands && (sum >> 6) < ANDI_ISLAND_MEAN_MAX);
+		a.pair_class[pair] = (uint8_t)(cls | (quad ? 0x80u : 0u) | (coop_cand && !islands ? ANDI_ROUTE_COOP : 0u) | (soft ? ANDI_ROUTE_SOFT : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
-		// pairs whose matches hardly reach the anchor threshold (divergence beyond some 6 %): their chains probe at nearly
-		// every step and meet their neighbours' slowly -- pass A by wavefronts (scan_coop.hip) leaves calls of such pairs alone
-		if ((sum >> 6) < ANDI_SPARSE_MATCH) atomicAdd(&a.restitch_count[ANDI_SPARSE_WAVES], (nseg + 63) / 64);
+		atomicAdd(&a.restitch_count[ANDI_ALL_WAVES], (nseg + 63) / 64);
+		if (soft || !(coop_cand && !islands)) atomicAdd(&a.restitch_count[ANDI_SPARSE_WAVES], (nseg + 63) / 64); // wavefronts the lane scan would like
 	}
 }
 
@@ -133,6 +176,45 @@ __global__ __launch_bounds__(1024) void k_pair_offsets(ScanArgs a) {
 			for (uint32_t k = 0; k < v; ++k) list[base + k] = w0 + k;
 		}
 	}
+}
+
+// routed calls: which pairs take pass A by wavefronts (they get no wavefronts in the lane layout)
+__global__ __launch_bounds__(256) void k_pair_route(ScanArgs a) {
+	const uint32_t P = a.nsub * a.nq, pair = blockIdx.x * 256 + threadIdx.x;
+	if (pair >= P) return;
+	uint32_t cls = a.pair_class[pair];
+	const bool lanes_few = 10 * a.restitch_count[ANDI_SPARSE_WAVES] <= a.restitch_count[ANDI_ALL_WAVES]; // (the lane scan's and those it would like)
+	if ((cls & ANDI_ROUTE_COOP) && (cls & ANDI_ROUTE_SOFT) && !lanes_few) cls &= ~ANDI_ROUTE_COOP;
+	cls &= ~ANDI_ROUTE_SOFT;
+	a.pair_class[pair] = (uint8_t)cls;
+	if (cls & ANDI_ROUTE_COOP) a.pair_waves[pair] = 0;
+}
+
+// routed calls, after pass A: the pairs the wavefront kernel handed back get the wavefronts of the second lane layout
+// (a: that layout's arguments), every other pair none
+__global__ __launch_bounds__(256) void k_pair_leftover(ScanArgs a) {
+	const uint32_t P = a.nsub * a.nq, pair = blockIdx.x * 256 + threadIdx.x;
+	if (pair >= P) return;
+	const uint32_t sub = pair / a.nq, qidx = pair % a.nq;
+	uint32_t cls = a.pair_class[pair], waves = 0;
+	if (a.self[sub] != (int64_t)qidx && (cls & ANDI_ROUTE_COOP) && (cls & ANDI_ROUTE_LEFT)) {
+		cls = (cls & ~(ANDI_ROUTE_COOP | ANDI_ROUTE_LEFT)) | ANDI_ROUTE_L2;
+		const uint32_t seg = a.seg0 << (cls & 3u), nseg = (a.qlen[qidx] + seg - 1) / seg;
+		a.pair_class[pair] = (uint8_t)cls;
+		waves = (nseg + 63) / 64;
+	}
+	a.pair_waves[pair] = waves;
+}
+
+// routed calls: who took what (the context's counters, read with the timings)
+__global__ __launch_bounds__(256) void k_route_count(ScanArgs a) {
+	const uint32_t P = a.nsub * a.nq, pair = blockIdx.x * 256 + threadIdx.x;
+	if (pair >= P) return;
+	const uint32_t sub = pair / a.nq, qidx = pair % a.nq;
+	if (a.self[sub] == (int64_t)qidx) return;
+	const uint32_t cls = a.pair_class[pair];
+	atomicAdd(&a.route_nt[(cls & ANDI_ROUTE_COOP) ? 0 : 1], (unsigned long long)a.qlen[qidx]);
+	if (cls & ANDI_ROUTE_L2) atomicAdd(&a.route_nt[2], 1ull);
 }
 
 // ------------------------------------------------------------------ pass A
@@ -961,17 +1043,41 @@ static hipError_t lane_cold(const ScanArgs &a, dim3 grid, hipStream_t st) {
 	return hipGetLastError();
 }
 
-hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
+static hipError_t pair_offsets(const ScanArgs &a, hipStream_t st) {
 	const uint32_t P = a.nsub * a.nq;
-	(void)hipMemsetAsync(a.restitch_count + ANDI_QUAD_WAVES, 0, 2 * sizeof(uint32_t), st); // k_lane_quad's list is empty (and no pair counted as sparse)
-	k_pair_estimate<<<(P + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, BLOCK, 0, st>>>(a);
-	CHECK_LAUNCH();
 	const unsigned nb = (P + 1023) / 1024;
 	k_pair_block_sums<<<nb, 1024, 0, st>>>(a);
 	CHECK_LAUNCH();
 	k_pair_block_offsets<<<1, 1024, 0, st>>>(a);
 	CHECK_LAUNCH();
 	k_pair_offsets<<<nb, 1024, 0, st>>>(a);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
+	const uint32_t P = a.nsub * a.nq;
+	(void)hipMemsetAsync(a.restitch_count + ANDI_QUAD_WAVES, 0, 3 * sizeof(uint32_t), st); // k_lane_quad's list is empty, no wavefronts counted
+	k_pair_estimate<<<P, P <= 4096 ? 64 * EST_WAVES : 64, 0, st>>>(a);
+	CHECK_LAUNCH();
+	if (a.route) {
+		k_pair_route<<<(P + 255) / 256, 256, 0, st>>>(a);
+		CHECK_LAUNCH();
+	}
+	return pair_offsets(a, st);
+}
+
+hipError_t andi_launch_pair_leftover(const ScanArgs &a2, hipStream_t st) {
+	const uint32_t P = a2.nsub * a2.nq;
+	(void)hipMemsetAsync(a2.restitch_count + ANDI_QUAD_WAVES, 0, 3 * sizeof(uint32_t), st);
+	k_pair_leftover<<<(P + 255) / 256, 256, 0, st>>>(a2);
+	CHECK_LAUNCH();
+	return pair_offsets(a2, st);
+}
+
+hipError_t andi_launch_route_count(const ScanArgs &a, hipStream_t st) {
+	const uint32_t P = a.nsub * a.nq;
+	k_route_count<<<(P + 255) / 256, 256, 0, st>>>(a);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }

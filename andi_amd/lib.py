@@ -70,6 +70,9 @@ class Timings(C.Structure):
         ("uniform_calls", C.c_uint64),
         ("coop_calls", C.c_uint64),
         ("coop_fallbacks", C.c_uint64),
+        ("routed_calls", C.c_uint64),
+        ("coop_query_nt", C.c_uint64),
+        ("lane_query_nt", C.c_uint64),
     ]
 
 

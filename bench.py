@@ -123,6 +123,18 @@ def cpu_baseline(seqs, p_value, model):
     }
 
 
+def pass_a_of(tm):
+    """which kernel(s) ran pass A, and -- in calls routed per pair -- the fraction of the query nucleotides each took"""
+    launches = max(int(tm["scan_launches"]), 1)
+    if tm["routed_calls"]:
+        c, l = float(tm["coop_query_nt"]), float(tm["lane_query_nt"])
+        tot = max(c + l, 1.0)
+        name = "k_coop_cold" if l == 0 else ("k_lane_cold" if c == 0 else "k_coop_cold+lanes")
+        return name, {"k_coop_cold": c / tot, "lanes (k_lane_cold, k_lane_quad)": l / tot,
+                      "pairs_handed_back_per_call": int(tm["coop_fallbacks"]) / max(int(tm["routed_calls"]), 1)}
+    return ("k_coop_cold" if tm["coop_calls"] >= launches else "k_lane_cold"), None
+
+
 def make_set(kind, G, length, dlo, dhi, seed):
     from andi_amd import synth
     if kind == "realistic":
@@ -182,7 +194,7 @@ def secondary(kind, args, model, p_value, G=29, L=None, S=None, dlo=None, dhi=No
     out = {"workload": workload_name(kind, G, S, L, dlo, dhi, args.seed, 1),
            "pairs_per_s": S * (G - 1) / (el / steps), "ms_per_step": 1e3 * el / steps,
            "roofline_frac": alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if scan_ms > 0 else None,
-           "pass_a_kernel": "k_coop_cold" if tm["coop_calls"] >= max(int(tm["scan_launches"]), 1) else "k_lane_cold",
+           "pass_a_kernel": pass_a_of(tm)[0], "pass_a_query_nt_fraction": pass_a_of(tm)[1],
            "index_build_ms": tm["build_ms"] / steps, "scan_cold_pass_ms": tm["scan_ms"] / steps,
            "scan_stitch_reduce_ms": tm["stitch_ms"] / steps, "fixups_per_step": int(tm["fixups"]) // steps}
     ctx.free(M)
@@ -347,8 +359,7 @@ def main():
         del src, dst
 
     # pass A's kernel: one wavefront per chain (scan_coop.hip) where the call suits it, else one lane per chain
-    scan_kernel = "k_scan_cold" if os.environ.get("ANDI_SCAN_G", "0") != "0" else (
-        "k_coop_cold" if tm["coop_calls"] >= max(int(tm["scan_launches"]), 1) else "k_lane_cold")
+    scan_kernel, routed_fraction = pass_a_of(tm)
     out = None
     if rank == 0:
         full = gathered[0] if use_dist else shard.gather_matrix(block, G, rows=S)
@@ -360,7 +371,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload_name(args.set, G, S, args.length, args.dlo, args.dhi, args.seed, world),
                        "genomes": G, "subjects": S, "length": args.length, "model": "JC", "pairs": pairs_total,
-                       "segment": args.segment or ("auto (pass A by wavefronts: 32768 ... 524288 symbols by the size of the call)" if tm["coop_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
+                       "segment": args.segment or ("auto (pass A routed per pair: by wavefronts on segments of 32768 ... 524288 symbols, by lanes on segments chosen per pair, 2048 ... 16384)" if tm["routed_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "measured_copy_GBps": copy_gbps,
@@ -371,7 +382,8 @@ def main():
                                       "scan_stitch_reduce": tm["stitch_ms"] / args.steps,
                                       "fixups": int(tm["fixups"]),
                                       "scan_calls_pass_a_by_wavefronts": int(tm["coop_calls"]),
-                                      "scan_calls_fallen_back_to_lanes": int(tm["coop_fallbacks"]),
+                                      "scan_calls_routed_per_pair": int(tm["routed_calls"]),
+                                      "pass_a_query_nt_fraction": routed_fraction,
                                       "scan_calls_with_per_pair_segments": int(tm["adaptive_calls"]),
                                       "scan_calls_with_one_segment_length": int(tm["uniform_calls"])},
             "end_to_end": {"note": "rank 0, untimed staging of its rows: RS on %d host threads, H2D of RS, suffix arrays "

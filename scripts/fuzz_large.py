@@ -74,7 +74,7 @@ def main():
         ok = bool((got == lane).all() and (forced == lane).all() and (lane[k] == want).all())
         case += 1
         print("case %3d %-9s n=%2d len=%d model=%d  trial: by wavefronts %d, fallen back %d; fix-ups lane/trial %d/%d  %s" % (
-            case, kind, n, length, model, t1["coop_calls"], t1["coop_fallbacks"], t0["fixups"], t1["fixups"], "ok" if ok else "DIFFERENT"), flush=True)
+            case, kind, n, length, model, t1["routed_calls"], t1["coop_fallbacks"], t0["fixups"], t1["fixups"], "ok" if ok else "DIFFERENT"), flush=True)
         if not ok:
             sys.exit(1)
     print("fuzz_large: %d cases, all equal (trial = lane scan = forced kernel, sampled rows = oracle)" % case)

@@ -217,7 +217,7 @@ def test_default_path_at_headline_length_against_the_oracle(orc):
         c.timings_reset()
         got = andi_amd.scan_rows(c, esas, list(range(len(seqs))), Q)
         t = c.timings()
-        assert t["coop_calls"] + t["coop_fallbacks"] == 1, t  # the call was of trial size
+        assert t["routed_calls"] == 1 and t["coop_query_nt"] > 0, t  # a call of the size at which pass A is routed per pair
         assert t["fixups"] == 0
         pairs = [(r, j) for r in range(3) for j in (1, 4, 7, 10)]
         _sampled_pairs_against_oracle(orc, seqs, [esas[i] for i in subjects], subjects, got[subjects], pairs)
@@ -244,7 +244,7 @@ def test_c4_shaped_call_at_full_length_against_the_oracle(orc):
         got = andi_amd.scan_rows(c, esas, subjects, Q)
         t = c.timings()
         assert t["scan_pairs"] == 8 * (G - 1) and t["fixups"] == 0
-        assert t["coop_calls"] + t["coop_fallbacks"] == 1, t
+        assert t["routed_calls"] == 1 and t["coop_query_nt"] > 0, t
         pairs = [(0, 3), (0, 160), (0, 319), (2, 0), (2, 78), (2, 250), (7, 5), (7, 100), (7, 200), (7, 318)]
         _sampled_pairs_against_oracle(orc, seqs, esas, subjects, got, pairs)
         for e in esas:

@@ -79,29 +79,67 @@ def _rows(seqs, env):
         return got, t
 
 
-def test_trial_on_a_large_clean_call_and_fallback_on_a_structured_one():
-    """Unset, ANDI_COOP means ON TRIAL for large calls: on a star set the wavefront kernel is the call's pass A; on
-    genomes with unrelated stretches (and on a set with a pair of k_lane_quad's class) the trial ends and the lane scan
-    takes the call.  Same counts every way."""
+def test_large_calls_are_routed_per_pair():
+    """Unset, ANDI_COOP means: a large call's pass A is ROUTED PER PAIR.  On a star set every pair takes the wavefront
+    kernel; genomes a few substitutions apart are k_lane_quad's class throughout (none takes it); on genomes with unrelated
+    stretches the sampling keeps most pairs away from it and it hands others back.  Same counts every way."""
     os.environ.pop("ANDI_COOP", None)
     star, _ = synth.genome_set(12, 4_900_000, 0.004, 0.03, seed=5)
     lane, t0 = _rows(star, {"ANDI_COOP": "0"})
-    assert t0["coop_calls"] == 0 and t0["coop_fallbacks"] == 0
+    assert t0["coop_calls"] == 0 and t0["routed_calls"] == 0
     got, t = _rows(star, {})
-    assert (t["coop_calls"], t["coop_fallbacks"]) == (1, 0), t
+    assert t["routed_calls"] == 1 and t["coop_fallbacks"] == 0 and t["coop_query_nt"] + t["lane_query_nt"] == 132 * 4_900_000, t
+    assert t["coop_query_nt"] >= 0.9 * 132 * 4_900_000, t  # (pairs more than some 6 % apart are the lane scan's)
     assert (got == lane).all()
     # genomes a few substitutions apart: matches longer than a segment (and k_lane_quad's class throughout)
     base = synth.base_codes(4_900_000, 5)
     close = [synth.to_bytes(synth.mutate_codes(base, 0.00002, 90 + k)) for k in range(12)]
     lane, _ = _rows(close, {"ANDI_COOP": "0"})
     got, t = _rows(close, {})
-    assert (t["coop_calls"], t["coop_fallbacks"]) == (0, 1), t
+    assert t["routed_calls"] == 1 and t["coop_query_nt"] == 0, t
     assert (got == lane).all()
     real, _ = synth.realistic_set(12, 4_900_000, 0.004, 0.03, seed=9)
     lane, _ = _rows(real, {"ANDI_COOP": "0"})
     got, t = _rows(real, {})
-    assert (t["coop_calls"], t["coop_fallbacks"]) == (0, 1), t
+    assert t["routed_calls"] == 1, t
     assert (got == lane).all()
+
+
+def test_mixed_call_clean_close_and_structured_pairs_against_the_oracle():
+    """ONE call whose pairs are of every kind -- clean pairs a few percent apart (the wavefront kernel's), pairs a few
+    substitutions apart (k_lane_quad's), pairs with unrelated stretches, repeats and indels (k_lane_cold's, some of them
+    handed back by the wavefront kernel) -- routed per pair, against the oracle: 16 sampled ordered pairs."""
+    from tests.conftest import verify_suffix_array
+    from oracle import orc
+    os.environ.pop("ANDI_COOP", None)
+    n = 3_400_000
+    base = synth.base_codes(n, 31)
+    clean = [synth.to_bytes(synth.mutate_codes(base, d, 40 + k)) for k, d in enumerate((0.002, 0.01, 0.02, 0.03))]
+    close = [synth.to_bytes(synth.mutate_codes(base, 0.00003, 50 + k)) for k in range(3)]
+    real, _ = synth.realistic_set(5, n, 0.002, 0.03, seed=31)
+    seqs = clean + close + real  # (the structured genomes come from another base: unrelated to the others but for chance)
+    seqs.append(synth.to_bytes(synth.mutate_codes(synth.realistic_base(n, 31), 0.015, 77)))  # a clean relative of the structured ones
+    with knobs(COOP=None):
+        ctx = andi_amd.Context(0)
+        ctx.expect_queries(len(seqs) - 1)
+        Q = andi_amd.Queries(ctx, seqs)
+        esas = [andi_amd.Esa(ctx, s, sa="device") for s in seqs]
+        ctx.timings_reset()
+        got = andi_amd.scan_rows(ctx, esas, list(range(len(seqs))), Q)
+        t = ctx.timings()
+        assert t["routed_calls"] == 1 and t["coop_query_nt"] > 0 and t["lane_query_nt"] > 0, t
+        for i in (1, 5, 8, 12):
+            RS = seqs[i][::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")) + b"#" + seqs[i]
+            verify_suffix_array(RS, esas[i].SA)
+            O = orc.OracleEsa(seqs[i], sa=esas[i].SA)
+            for j in (0, 3, 4, 6, 7, 9, 11, 12):
+                if j != i:
+                    assert (got[i, j] == O.dist_anchor(seqs[j])).all(), (i, j)
+            O.close()
+        for e in esas:
+            e.close()
+        Q.close()
+        ctx.close()
 
 
 def test_ragged_rows_thresholds_and_windows_full_of_heads():
