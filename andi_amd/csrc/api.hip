@@ -30,11 +30,13 @@
 
 // ------------------------------------------------------------------ knobs (knobs.h)
 namespace {
-struct KnobStore {
+// The switches as they were when last read: an immutable snapshot behind an atomic pointer.  andi_hip_reload_knobs
+// publishes a new one and never frees the old (a handful of them in a test session): a string andi_knob returned stays
+// valid whatever other threads do.
+struct KnobSnapshot {
 	std::string value[KNOB_COUNT];
 	bool set[KNOB_COUNT];
-	KnobStore() { read(); }
-	void read() {
+	KnobSnapshot() {
 		static const char *names[KNOB_COUNT] = {
 #define X(n) "ANDI_" #n,
 			ANDI_KNOB_LIST(X)
@@ -47,14 +49,22 @@ struct KnobStore {
 		}
 	}
 };
-KnobStore &knob_store() {
-	static KnobStore s; // (read when the library first looks)
-	return s;
+std::atomic<const KnobSnapshot *> g_knobs{nullptr};
+const KnobSnapshot &knob_store() {
+	const KnobSnapshot *s = g_knobs.load(std::memory_order_acquire);
+	if (!s) { // (read when the library first looks)
+		const KnobSnapshot *fresh = new KnobSnapshot();
+		if (g_knobs.compare_exchange_strong(s, fresh, std::memory_order_acq_rel))
+			s = fresh;
+		else
+			delete fresh;
+	}
+	return *s;
 }
 } // namespace
 
 const char *andi_knob(AndiKnob k) {
-	const KnobStore &s = knob_store();
+	const KnobSnapshot &s = knob_store();
 	return s.set[k] ? s.value[k].c_str() : nullptr;
 }
 
@@ -635,6 +645,7 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 		HIP_TRY(ctx, hipEventSynchronize(ctx->ib_done)); // the previous batch's items have been copied
 	}
 	auto *items = (AndiIndexBatchItem *)ctx->ib_host;
+	const int ext = andi_index_single_ext(ctx->queries_hint);
 	int32_t max_n = 0;
 	for (size_t k = 0; k < count; ++k) {
 		andi_hip_esa *e = esas[k];
@@ -650,7 +661,6 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 	Timed t(ctx, 0);
 	hipError_t err = hipMemcpyAsync(ctx->ib_dev, ctx->ib_host, count * sizeof(AndiIndexBatchItem), hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess) err = hipEventRecord(ctx->ib_done, ctx->stream);
-	const int ext = andi_index_single_ext(ctx->queries_hint);
 	if (err == hipSuccess) err = andi_launch_index_build_batch((const AndiIndexBatchItem *)ctx->ib_dev, (uint32_t)count, max_n, ext, ctx->stream);
 	t.stop();
 	if (err == hipSuccess) err = hipEventRecord(ctx->built, ctx->stream);
@@ -1203,7 +1213,7 @@ int andi_hip_bootstrap(andi_hip_ctx *ctx, const andi_hip_model *M, size_t n, uin
 	return 0;
 }
 
-void andi_hip_reload_knobs(void) { knob_store().read(); }
+void andi_hip_reload_knobs(void) { g_knobs.store(new KnobSnapshot(), std::memory_order_release); }
 
 int andi_hip_timings_get(andi_hip_ctx *ctx, andi_hip_timings *t) {
 	if (!ctx || !t) return 1;
@@ -1498,21 +1508,25 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		// Subject slots: device buffers sized for the longest genome, reused batch after batch (no
 		// allocation inside the loop).  Several subjects per scan call keep the GPU filled; low_memory
 		// keeps one index resident at a time, which is what distMatrixLM trades (src/dist_hack.h:14-16).
-		size_t batch = batch_max;
+		size_t batch = batch_max < rows ? batch_max : rows;
+		auto sets_for = [&](size_t bt) { // (low_memory: one index resident at a time)
+			const size_t nb = (rows + bt - 1) / bt;
+			return o.low_memory ? (size_t)1 : (nb > 2 ? (size_t)3 : (nb > 1 ? (size_t)2 : (size_t)1));
+		};
 		{
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-				const size_t per_slot = 10 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap, D.ctx->queries_hint))) + (1 << 20);
-				while (batch > 1 && 3 * batch * per_slot > free_b / (2 * ndev)) batch /= 2;
+				// a slot: text + padding, suffix array, the records of the device sorter, the packed text twice, the probe table
+				const size_t per_slot = 14 * rs_cap + ((size_t)8 << (2 * pick_deep_k(rs_cap, D.ctx->queries_hint))) + (1 << 20);
+				while (batch > 1 && sets_for(batch) * batch * per_slot > free_b / (2 * ndev)) batch /= 2; // (as many sets as the batches will really have)
 			}
 		}
-		if (batch > rows) batch = rows;
 		const size_t nbatches = (rows + batch - 1) / batch;
 		// Three sets of slots: while batch k is scanned, batch k + 2 is uploaded (no compute units needed) and batch k + 1
 		// is ready; the device's COMPUTE alternates strictly -- suffix sorts and index builds of batch k + 1, then the scan
 		// of batch k -- because side by side the staging kernels starve behind the workgroups of a scan that fills the
 		// device (sorts of 8 subjects: 6 ms alone, 38 ms beside a scan, on a high-priority stream as on a plain one).
-		const size_t sets = o.low_memory ? 1 : (nbatches > 2 ? 3 : (nbatches > 1 ? 2 : 1)); // (low_memory: one index resident at a time)
+		const size_t sets = sets_for(batch);
 		D.slots.assign(sets * batch, nullptr);
 		if (andi_hip_queries_stage(D.ctx, seqs, n, &D.Q)) return bail("staging queries", D.ctx);
 		lap(t_queries);

@@ -120,8 +120,8 @@ hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_pair_leftover(const ScanArgs &a2, hipStream_t st);
 hipError_t andi_launch_route_count(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
-// pass A with one wavefront per chain (scan_coop.hip); andi_coop_enabled(): 0 = off (ANDI_COOP=0), else the window's length in chunks of 2048 symbols
-int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: on trial for calls it suits (the default); n > 0: windows of 2048 n symbols, unconditionally
+// pass A with one wavefront per chain (scan_coop.hip)
+int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: large calls are routed per pair (the default); n = 2, 4, 8: every pair, windows of 2048 n symbols
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStream_t st); // k_lane_quad, one wavefront per block (scan_lane.hip compiled a second time)

@@ -981,11 +981,16 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 
 } // namespace
 
-int andi_coop_enabled(void) { // ANDI_COOP=0: never; n = 2, 4, 8, 16: pass A with one wavefront per chain, windows of 2048 n symbols, whatever the call; unset: on trial (< 0)
+// ANDI_COOP=0: never; 2, 4, 8: pass A with one wavefront per chain for every pair, windows of 2048 n symbols, whatever
+// the call (any other value: 4, with a warning); unset (< 0): large calls are routed per pair (scan.h)
+int andi_coop_enabled(void) {
 	const char *e = andi_knob(KNOB_COOP);
 	if (!e) return -4;
 	const int v = atoi(e);
-	return v == 2 || v == 4 || v == 8 ? v : (v == 0 ? 0 : 4);
+	if (v == 0 || v == 2 || v == 4 || v == 8) return v;
+	static bool warned = false;
+	if (!warned) fprintf(stderr, "andi-hip: ANDI_COOP=%s: windows of 2, 4 or 8 chunks of 2048 symbols; taking 4\n", e), warned = true;
+	return 4;
 }
 
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one segment length for the call, RAW/JC/Kimura

@@ -866,6 +866,10 @@ __device__ __forceinline__ void stitch_stretch(const ScanArgs &a, LaneItem it, u
 			if (!bad) return;
 			E = a.true_exit[it.slot];
 		} else {
+			// (A segment that was not bad and lies right before another stretch's first one is left alone: that stretch's
+			// lane has read this segment's true exit as its entry state, perhaps at this moment -- rewriting it under
+			// its eyes could hand it a torn state.  The next round finds the segment.)
+			if (!bad && it.end < c.qlen && a.stretch_bad[it.slot + 1] != 0) return;
 			E.pad[0] = E.pad[1] = E.pad[2] = 0;
 			const ChainState T = E;
 			(void)stitch_one<EXACT, 3>(a, it, c, T, s_hist, E);
