@@ -49,7 +49,7 @@ struct EsaDev {
 	int32_t thr;
 	int32_t deepK;
 	int32_t mode; // ANDI_MODE_*
-	int32_t deep_ext; // the entries of K-mers that occur once carry the nucleotides behind the occurrence (DEEP_SINGLE)
+	int32_t deep_ext; // the entries of K-mers that occur once carry the nucleotides behind the occurrence (DEEP_SINGLE): 1 up to 13 of them, 2 up to min(4, 16 - K)
 };
 
 #define ANDI_MODE_PROBE 0     /* probe table + suffix-array search (true longest match) */

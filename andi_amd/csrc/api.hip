@@ -140,6 +140,7 @@ struct andi_hip_esa {
 	uint8_t *N0 = nullptr, *N1 = nullptr;
 	uint32_t *rec = nullptr;    // the suffixes' records in suffix-array order, left by the device sorter (sa_device.hip) for the index build
 	bool rec_valid = false;
+	uint16_t *rec2 = nullptr;   // ... and the symbols behind their first deepK (same validity)
 	int32_t *flags = nullptr;   // device, 4 ints
 	int32_t *h_flags = nullptr; // the same 4 ints as the host sees them (flags live in pinned host memory)
 	int32_t deepK = 0;
@@ -150,7 +151,7 @@ struct andi_hip_esa {
 	size_t ref_cap = 0; // same for the reference arrays
 	bool ref_built = false;   // LCP, CLD, FVC, tab valid
 	bool index_built = false; // deep, flags valid
-	bool deep_ext = false;    // the table's entries of K-mers that occur once are in the extended form
+	int deep_ext = 0;         // the form of the table's entries of K-mers that occur once (andi_dev.h: 0 plain, 1 extended, 2 short extended)
 	size_t bytes = 0;
 };
 
@@ -253,7 +254,7 @@ EsaDev esa_view(const andi_hip_esa *e, int mode) {
 	v.S = e->S, v.SA = e->SA, v.LCP = e->LCP, v.CLD = e->CLD, v.FVC = e->FVC, v.tab = e->tab;
 	v.deep = e->deep, v.flags = e->flags;
 	v.N0 = e->N0, v.N1 = e->N1;
-	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.mode = mode, v.deep_ext = e->deep_ext ? 1 : 0;
+	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.mode = mode, v.deep_ext = e->deep_ext;
 	return v;
 }
 
@@ -277,6 +278,7 @@ EsaBuildArgs build_args(const andi_hip_esa *e) {
 	a.S = e->S, a.SA = e->SA, a.LCP = e->LCP, a.CLD = e->CLD, a.FVC = e->FVC, a.tab = e->tab;
 	a.deep = e->deep, a.flags = e->flags, a.deepK = e->deepK;
 	a.rec = e->rec_valid ? e->rec : nullptr;
+	a.rec2 = e->rec_valid ? e->rec2 : nullptr;
 	a.N0 = e->N0, a.N1 = e->N1;
 	a.min_scratch = e->min_scratch;
 	a.n = e->n;
@@ -516,11 +518,12 @@ static int esa_sort_suffixes(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!ctx->sa_pinned) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->sa_pinned, 2 * sizeof(int32_t), hipHostMallocDefault));
 	if (!e->rec && !andi_knob(KNOB_NO_SORTED_RECORDS)) { // (experiments: the index build then gathers from the text, as with a host-made suffix array)
 		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec, (e->cap + 8) * sizeof(uint32_t)));
+		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec2, (e->cap + 8) * sizeof(uint16_t)));
 		e->bytes += (e->cap + 8) * sizeof(uint32_t);
 	}
 	const auto t0 = std::chrono::steady_clock::now();
 	int rounds = 0;
-	hipError_t err = andi_sa_device(e->S, e->n, e->SA, ctx->sa_ws, ctx->sa_ws_bytes, ctx->sa_pinned, ctx->stream, &rounds, e->rec, e->deepK);
+	hipError_t err = andi_sa_device(e->S, e->n, e->SA, ctx->sa_ws, ctx->sa_ws_bytes, ctx->sa_pinned, ctx->stream, &rounds, e->rec, e->deepK, e->rec2);
 	e->rec_valid = err == hipSuccess && e->rec != nullptr;
 	if (err == hipErrorInvalidSymbol) {
 		ctx->err = "a subject holds a byte outside {A,C,G,T,!,;,#}";
@@ -616,12 +619,12 @@ int andi_hip_esa_build_index(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!ctx || !e) return 1;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	Timed t(ctx, 0);
-	const int ext = andi_index_single_ext(ctx->queries_hint);
+	const int ext = andi_index_single_ext(ctx->queries_hint, e->rec_valid);
 	hipError_t err = andi_launch_index_build(build_args(e), ext, ctx->stream);
 	t.stop();
 	if (err == hipSuccess) err = hipEventRecord(ctx->built, ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index", err);
-	e->index_built = true, e->deep_ext = ext != 0, ctx->builds_pending = true;
+	e->index_built = true, e->deep_ext = (ext == 2 && !e->rec_valid) ? 0 : ext, ctx->builds_pending = true; // (the short form forced on a host-made suffix array: plain)
 	return 0;
 }
 
@@ -645,7 +648,6 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 		HIP_TRY(ctx, hipEventSynchronize(ctx->ib_done)); // the previous batch's items have been copied
 	}
 	auto *items = (AndiIndexBatchItem *)ctx->ib_host;
-	const int ext = andi_index_single_ext(ctx->queries_hint);
 	int32_t max_n = 0;
 	for (size_t k = 0; k < count; ++k) {
 		andi_hip_esa *e = esas[k];
@@ -656,16 +658,21 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 		items[k].S = e->S, items[k].SA = e->SA, items[k].deep = e->deep, items[k].N0 = e->N0, items[k].N1 = e->N1;
 		items[k].flags = e->flags, items[k].n = e->n, items[k].deepK = e->deepK;
 		items[k].rec = e->rec_valid ? e->rec : nullptr;
+		items[k].rec2 = e->rec_valid ? e->rec2 : nullptr;
+		items[k].single_ext = andi_index_single_ext(ctx->queries_hint, e->rec_valid);
 		max_n = std::max(max_n, e->n);
 	}
 	Timed t(ctx, 0);
 	hipError_t err = hipMemcpyAsync(ctx->ib_dev, ctx->ib_host, count * sizeof(AndiIndexBatchItem), hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess) err = hipEventRecord(ctx->ib_done, ctx->stream);
-	if (err == hipSuccess) err = andi_launch_index_build_batch((const AndiIndexBatchItem *)ctx->ib_dev, (uint32_t)count, max_n, ext, ctx->stream);
+	if (err == hipSuccess) err = andi_launch_index_build_batch((const AndiIndexBatchItem *)ctx->ib_dev, (uint32_t)count, max_n, ctx->stream);
 	t.stop();
 	if (err == hipSuccess) err = hipEventRecord(ctx->built, ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "andi_hip_esa_build_index_batch", err);
-	for (size_t k = 0; k < count; ++k) esas[k]->index_built = true, esas[k]->deep_ext = ext != 0;
+	for (size_t k = 0; k < count; ++k) {
+		const int ext = items[k].single_ext;
+		esas[k]->index_built = true, esas[k]->deep_ext = (ext == 2 && !esas[k]->rec_valid) ? 0 : ext;
+	}
 	ctx->builds_pending = true;
 	return 0;
 }
@@ -706,11 +713,13 @@ int andi_hip_esa_download_index(andi_hip_ctx *ctx, const andi_hip_esa *e, uint32
 	return 0;
 }
 
+int andi_hip_esa_single_form(const andi_hip_esa *e) { return e && e->index_built ? e->deep_ext : 0; }
+
 void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!e) return;
 	if (ctx) (void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize(); // once for the handle's ten buffers: nothing in flight uses them when they are handed out again
-	void *bufs[] = {e->S, e->SA, e->LCP, e->CLD, e->FVC, e->tab, e->deep, e->Nraw, e->rec, e->min_scratch};
+	void *bufs[] = {e->S, e->SA, e->LCP, e->CLD, e->FVC, e->tab, e->deep, e->Nraw, e->rec, e->rec2, e->min_scratch};
 	for (void *b : bufs) (void)andi_arena::dev_free(b, false);
 	if (e->h_flags) (void)hipHostFree(e->h_flags);
 	delete e;

@@ -23,6 +23,7 @@ struct EsaBuildArgs {
 	uint8_t *N0, *N1;   // 4-bit symbols of the text, two alignments (out; see andi_dev.h)
 	int32_t *flags;     // 4 ints  (out)
 	const uint32_t *rec; // the suffixes' records in suffix-array order if the device sorter made them (sa_device.hip), else null
+	const uint16_t *rec2; // ... and the symbols behind their first deepK (the short extended form of DEEP_SINGLE), or null
 	int32_t deepK;
 	int32_t *min_scratch; // andi_min_tree_entries(n) ints
 	int32_t n;
@@ -36,14 +37,18 @@ struct AndiIndexBatchItem {
 	uint8_t *N0, *N1;
 	int32_t *flags;
 	const uint32_t *rec; // as EsaBuildArgs.rec
+	const uint16_t *rec2;
 	int32_t n, deepK;
+	int32_t single_ext; // the form of this subject's entries of K-mers that occur once (andi_index_single_ext)
 };
 
 size_t andi_min_tree_entries(int32_t n);
-// 1: the index builds launched now write the extended entries of K-mers that occur once (andi_dev.h: DEEP_SINGLE)
-int andi_index_single_ext(size_t queries);
+// the form of the entries of K-mers that occur once the index builds launched now write (andi_dev.h: DEEP_SINGLE):
+// 0 plain, 1 extended (13 symbols behind the occurrence, gathered from the text), 2 short extended (up to 4, from the
+// device sorter's keys: no gather; subjects whose suffix array came from the host get plain entries)
+int andi_index_single_ext(size_t queries, bool sorted_on_device);
 // the scan indexes of `count` subjects (device array of items) in two launches; max_n = the longest text
-hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, int single_ext, hipStream_t st);
+hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, hipStream_t st);
 // (scan_lane.hip) packed symbols of the items' texts, `bytes` source bytes each at most (shorter texts stop at their own end)
 hipError_t andi_launch_pack_symbols_batch(const AndiIndexBatchItem *d_items, uint32_t count, size_t bytes, hipStream_t st);
 // reference arrays LCP, CLD, FVC, tab (esa_init_LCP/_CLD/_FVC/_cache)

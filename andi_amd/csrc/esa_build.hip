@@ -362,7 +362,7 @@ __device__ __forceinline__ uint32_t first_code(bool has, uint32_t L, int K) {
 }
 
 __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
-												  const uint32_t *__restrict__ REC, uint2 *__restrict__ deep,
+												  const uint32_t *__restrict__ REC, const uint16_t *__restrict__ REC2, uint2 *__restrict__ deep,
 												  int32_t *__restrict__ flags, int32_t n, int K, int single_ext, uint32_t block) {
 	__shared__ uint32_t s_first[PT_TILE];   // first code a gap owns (one that owns nothing: its successor's)
 	__shared__ uint32_t s_absent[PT_TILE];  // number of absent codes it owns (they come first)
@@ -378,12 +378,14 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	// the suffixes' records: read in order if the device sorter left them (REC), else made here from one gather each
 	auto make_rec = [&](int32_t j) { return REC ? REC[j] : suffix_rec(N0, SA, j, K); };
+	uint32_t mine2[PT_GAPS]; // the short extended form: what the sorter's keys held behind this thread's suffixes' K-mers (read with the records)
 	{
 		uint32_t mine[PT_GAPS];
 #pragma unroll
 		for (int u = 0; u < PT_GAPS; ++u) {
 			const int64_t g = r0 + threadIdx.x + u * PT_BLOCK;
 			mine[u] = g < n ? make_rec((int32_t)g) : 0u;
+			mine2[u] = (single_ext == 2 && REC2 && g < n) ? REC2[g] : 0u;
 		}
 #pragma unroll
 		for (int u = 0; u < PT_GAPS; ++u) s_rec[threadIdx.x + u * PT_BLOCK + 2] = mine[u];
@@ -448,7 +450,10 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 					// (up to 13) nucleotides that follow it in the text, so that a chance match is settled
 					// without touching the text (costs the build a second gather: +11 %)
 					const uint32_t pos = (uint32_t)SA[r], e0 = pos + full;
-					if (!single_ext) {
+					if (single_ext == 2 && REC2) { // the short extended form: what the sorter's keys held behind the K-mer
+						const uint32_t w = mine2[u];
+						present = make_uint2(pos, DEEP_SINGLE | ((w >> 8) << 2) | ((w & 0xffu) << 6));
+					} else if (single_ext != 1) {
 						present = make_uint2(pos, DEEP_SINGLE | (1u << 2) | (full << 8));
 					} else {
 						const uint64_t w = ld_u64_unaligned((g_u8p)N0 + (e0 >> 1)) >> (4 * (e0 & 1u)); // 15 symbols from e0 on
@@ -576,16 +581,16 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 }
 
 __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
-														  const uint32_t *__restrict__ rec, uint2 *__restrict__ deep,
+														  const uint32_t *__restrict__ rec, const uint16_t *__restrict__ rec2, uint2 *__restrict__ deep,
 														  int32_t *__restrict__ flags, int32_t n, int K, int single_ext) {
-	probe_table_block(N0, SA, rec, deep, flags, n, K, single_ext, blockIdx.x);
+	probe_table_block(N0, SA, rec, rec2, deep, flags, n, K, single_ext, blockIdx.x);
 }
 
 // the tables of several subjects in one launch (blockIdx.y = subject): no launch gaps, one tail
-__global__ __launch_bounds__(PT_BLOCK) void k_probe_table_batch(const AndiIndexBatchItem *__restrict__ items, int single_ext) {
+__global__ __launch_bounds__(PT_BLOCK) void k_probe_table_batch(const AndiIndexBatchItem *__restrict__ items) {
 	const AndiIndexBatchItem it = items[blockIdx.y];
 	if ((int64_t)blockIdx.x * PT_TILE > (int64_t)it.n) return;
-	probe_table_block(it.N0, it.SA, it.rec, it.deep, it.flags, it.n, it.deepK, single_ext, blockIdx.x);
+	probe_table_block(it.N0, it.SA, it.rec, it.rec2, it.deep, it.flags, it.n, it.deepK, it.single_ext, blockIdx.x);
 }
 
 // ---------------------------------------------------------------- host side
@@ -602,12 +607,19 @@ size_t andi_min_tree_entries(int32_t n) {
 // The entries of K-mers that occur once also carry the (up to 13) nucleotides behind the occurrence when a scan is going to
 // read them: pass A in rounds (scan_rounds.hip) and pass A with one wavefront per chain (scan_coop.hip).  Every scan
 // understands both forms (the position is in the same place); the subject's handle remembers which it has.
-int andi_index_single_ext(size_t queries) { // queries: how many the subject is going to meet (0: unknown)
+int andi_index_single_ext(size_t queries, bool sorted_on_device) { // queries: how many the subject is going to meet (0: unknown)
 	if (andi_knob(KNOB_COOP_PLAIN)) return 0; // (experiments)
 	const int coop = andi_coop_enabled();
-	// pass A by wavefronts reads them -- worth the build's extra gather (+ 20 %) when the scan is forced to it, or, on
-	// trial, when the subject meets hundreds of queries
-	return coop > 0 || (coop < 0 && queries >= 256);
+	if (coop == 0) return 0;
+	if (const char *f = andi_knob(KNOB_SINGLE_EXT)) return atoi(f); // (experiments: 0, 1, 2)
+	// Pass A by wavefronts reads them: a chance occurrence of a K-mer off the window's diagonal is then settled by the
+	// entry instead of a look at the text with the parked lanes (bench set: pass A 4.95 -> 4.71 ms).  Four symbols settle
+	// all but one chance occurrence in 256 -- pass A is as fast as with thirteen (bench set 4.71 / 4.67 ms, C4 shape
+	// 28.7 / 28.7) -- and come with the device sorter's records; a subject whose suffix array came from the host gets the
+	// long form (a gather from the text: + 20 % of the build) where it pays: the scan forced to that kernel, or
+	// hundreds of queries.
+	if (sorted_on_device) return 2;
+	return (coop > 0 || queries >= 256) ? 1 : 0;
 }
 
 hipError_t andi_launch_index_build(const EsaBuildArgs &a, int single_ext, hipStream_t st) {
@@ -616,18 +628,18 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, int single_ext, hipStr
 	// symbols for the lane scan: the text, its NUL and 64 bytes of the zero padding behind it
 	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 1, st);
 	if (e != hipSuccess) return e;
-	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_TILE - 1) / PT_TILE), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.rec, a.deep, a.flags, n,
+	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_TILE - 1) / PT_TILE), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.rec, a.rec2, a.deep, a.flags, n,
 																				  a.deepK, single_ext);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
 
-hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, int single_ext, hipStream_t st) {
+hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, hipStream_t st) {
 	if (count == 0) return hipSuccess;
 	hipError_t e = andi_launch_pack_symbols_batch(d_items, count, (size_t)max_n + 1 + 64, st);
 	if (e != hipSuccess) return e;
 	const dim3 grid((unsigned)(((int64_t)max_n + 1 + PT_TILE - 1) / PT_TILE), count);
-	k_probe_table_batch<<<grid, PT_BLOCK, 0, st>>>(d_items, single_ext);
+	k_probe_table_batch<<<grid, PT_BLOCK, 0, st>>>(d_items);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }

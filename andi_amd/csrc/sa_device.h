@@ -10,6 +10,7 @@ size_t andi_sa_device_workspace(int32_t n);
 // order -- what divsufsort() computes at src/esa.c:303.  h_pinned2: two ints of pinned host memory.  Synchronises
 // the stream once per round.  hipErrorInvalidSymbol: the text holds a byte outside {A C G T ! ; #}.
 // rec (n entries, or null): the suffixes' records for a probe table of depth recK, in suffix-array order
-// (esa_build.hip: suffix_rec) -- a by-product of the first round's sorted keys.
+// (esa_build.hip: suffix_rec) -- a by-product of the first round's sorted keys.  rec2 (n entries, or null): from the
+// same keys, the up to four symbols behind each suffix's first recK (andi_dev.h: DEEP_SINGLE, the short extended form).
 hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *workspace, size_t workspace_bytes,
-						  int32_t *h_pinned2, hipStream_t st, int *rounds_out, uint32_t *rec, int recK);
+						  int32_t *h_pinned2, hipStream_t st, int *rounds_out, uint32_t *rec, int recK, uint16_t *rec2 = nullptr);

@@ -108,12 +108,19 @@ __global__ __launch_bounds__(SA_BLOCK) void k_sa_apply(const uint64_t *__restric
 // leading nucleotides and the separator class behind them -- its record, suffix_rec there -- which it would
 // otherwise gather from the text, one random access per suffix.  Made here from the keys, the records are a
 // sequential read for it.  (Symbol codes: NUL 0, '!' 1, '#' 2, ';' 3, A C G T 4..7; symbol j in bits 62-3j..60-3j.)
-__global__ __launch_bounds__(SA_BLOCK) void k_sa_records(const uint64_t *__restrict__ key, int32_t n, int K, uint32_t *__restrict__ rec) {
+__global__ __launch_bounds__(SA_BLOCK) void k_sa_records(const uint64_t *__restrict__ key, int32_t n, int K, uint32_t *__restrict__ rec, uint16_t *__restrict__ rec2) {
 	const int64_t i = (int64_t)blockIdx.x * SA_BLOCK + threadIdx.x;
 	if (i >= n) return;
 	const uint64_t k = key[i] << (63 - SA_KEY_BITS); // symbol j in bits 62-3j..60-3j, as with 21 symbols
 	const uint64_t other = ~k & (0x4924924924924924ull & ~((1ull << (63 - SA_KEY_BITS)) - 1ull)); // top bit of a symbol clear: not a nucleotide
 	uint32_t v = other ? ((uint32_t)__builtin_clzll(other) - 1u) / 3u : (uint32_t)SA_SYMS;
+	if (rec2) { // the nucleotides behind the first K symbols, as far as the key holds them (four at most): how many, their codes (first in the low bits)
+		const uint32_t lite = (uint32_t)(SA_SYMS - K) < 4u ? (uint32_t)(SA_SYMS - K) : 4u;
+		const uint32_t nval = v <= (uint32_t)K ? 0u : (v - (uint32_t)K < lite ? v - (uint32_t)K : lite);
+		uint32_t codes = 0;
+		for (uint32_t j = 0; j < nval; ++j) codes |= ((uint32_t)(k >> (60 - 3 * ((uint32_t)K + j))) & 3u) << (2 * j);
+		rec2[i] = (uint16_t)(codes | (nval << 8));
+	}
 	uint32_t sep = 0;
 	if (v < (uint32_t)K) {
 		const uint32_t sym = (uint32_t)(k >> (60 - 3 * v)) & 7u;
@@ -157,7 +164,7 @@ size_t andi_sa_device_workspace(int32_t n) {
 }
 
 hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *workspace, size_t workspace_bytes,
-						  int32_t *h_pinned2, hipStream_t st, int *rounds_out, uint32_t *rec, int recK) {
+						  int32_t *h_pinned2, hipStream_t st, int *rounds_out, uint32_t *rec, int recK, uint16_t *rec2) {
 	if (n <= 0) return hipSuccess;
 	if (workspace_bytes < andi_sa_device_workspace(n)) return hipErrorInvalidValue;
 	const size_t N = ((size_t)n + 63) & ~(size_t)63;
@@ -190,7 +197,7 @@ hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *worksp
 	for (;;) {
 		size_t tb = tmp_bytes;
 		SA_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keyA, keyB, valA, valB, (int)m, 0, rounds == 0 ? SA_KEY_BITS : 2 * bits, st));
-		if (rounds == 0 && rec) k_sa_records<<<blocks(m), SA_BLOCK, 0, st>>>(keyB, n, recK, rec);
+		if (rounds == 0 && rec) k_sa_records<<<blocks(m), SA_BLOCK, 0, st>>>(keyB, n, recK, rec, rec2);
 		k_sa_heads<<<blocks(m), SA_BLOCK, 0, st>>>(keyB, slots, m, hv);
 		SA_TRY(hipGetLastError());
 		tb = tmp_bytes;

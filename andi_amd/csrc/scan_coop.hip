@@ -304,12 +304,15 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 	const uint32_t diff = (behind ^ ext) & 0x03ffffffu;
 	const uint32_t m = diff ? (uint32_t)__builtin_ctz(diff) >> 1 : 16u; // first differing nucleotide
 	const uint32_t lim = nval < qrem - K ? nval : qrem - K;
+	// how many symbols an entry can hold at all: 13 in the long form, what the sorter's keys had behind the K-mer in the
+	// short one (andi_dev.h); an entry that holds fewer says that the text has no nucleotide there
+	const uint32_t room = E.deep_ext == 2 ? (16u - K < 4u ? 16u - K : 4u) : 13u;
 	r.unique = true, r.pos = x;
 	if (m < lim) {
 		r.len = K + m; // settled by the entry
 	} else if (K + lim >= qrem) {
 		r.len = qrem; // the query ends inside the match
-	} else if (lim == nval && nval < 13) {
+	} else if (lim == nval && nval < room) {
 		r.len = K + lim; // the text has a separator (or its end) there, the query a nucleotide
 	} else {
 		WHY(CS_WHY_LONG);

@@ -112,6 +112,7 @@ SYMBOLS = {
     "andi_hip_esa_flags": (C.c_int, [_P, _P, _P]),
     "andi_hip_esa_download": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "andi_hip_esa_download_index": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int)]),
+    "andi_hip_esa_single_form": (C.c_int, [_P]),
     "andi_hip_esa_free": (None, [_P, _P]),
     "andi_hip_esa_bytes": (C.c_size_t, [_P]),
     "andi_hip_queries_stage": (C.c_int, [_P, C.POINTER(Seq), C.c_size_t, C.POINTER(_P)]),
@@ -344,6 +345,10 @@ class Esa:
         self.ctx._check(load().andi_hip_esa_download_index(self.ctx._h, self._h, table.ctypes.data, C.byref(K)),
                         "esa_download_index")
         return K.value, table
+
+    def single_form(self):
+        """form of the probe table's entries of K-mers that occur once: 0 plain, 1 extended, 2 short extended"""
+        return load().andi_hip_esa_single_form(self._h)
 
     def nbytes(self):
         return load().andi_hip_esa_bytes(self._h)

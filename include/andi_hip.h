@@ -169,6 +169,9 @@ int andi_hip_esa_download(andi_hip_ctx *ctx, const andi_hip_esa *esa, int32_t *L
  * 2 MULTI -- it occurs (y >> 8) + 1 times, at the suffix-array indices x, x + 1, ...; 3 -- search the
  * whole suffix array.  `table` may be NULL (only K is wanted); it needs 8 << 2K bytes. */
 int andi_hip_esa_download_index(andi_hip_ctx *ctx, const andi_hip_esa *esa, uint32_t *table, int *K);
+/* the form of the table's entries of K-mers that occur once (test hook): 0 plain, 1 the up to 13 nucleotides behind the
+ * occurrence in the entry, 2 the up to min(4, 16 - K) the device sorter's keys held (the default for subjects sorted on the device) */
+int andi_hip_esa_single_form(const andi_hip_esa *esa);
 void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *esa);
 size_t andi_hip_esa_bytes(const andi_hip_esa *esa);
 

@@ -240,6 +240,21 @@ def test_probe_table_entries_against_brute_force(ctx, name, seq):
     assert ((kind == 1) == (occurs == 1)).all() and ((kind == 2) == (occurs > 1)).all() and (kind != 3).all()
     once = occurs == 1
     assert (x[once] == where[K][once]).all()
+    form = E.single_form()
+    if form:  # the nucleotides behind the one occurrence, as many as the entry's form holds (andi_dev.h: DEEP_SINGLE)
+        room = 13 if form == 1 else min(4, 16 - K)
+        pos = x[once]
+        nval, ext = (y[once] >> 2) & 15, y[once] >> 6
+        want_n = np.zeros(len(pos), np.int64)
+        want_e = np.zeros(len(pos), np.int64)
+        alive = np.ones(len(pos), bool)
+        tt = np.concatenate([t, np.full(16, 4, np.int64)])
+        for j in range(room):
+            sym = tt[pos + K + j]
+            alive &= sym < 4
+            want_n += alive
+            want_e |= np.where(alive, sym, 0) << (2 * j)
+        assert (nval == want_n).all() and (ext == want_e).all(), name
     many = occurs > 1
     assert ((y[many] >> 8) + 1 == occurs[many]).all()
     first = np.full(4 ** K, n, np.int64)  # smallest suffix-array index among the positions of each K-mer
