@@ -884,7 +884,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// Unset: large calls are ROUTED PER PAIR (scan.h) -- the pairs whose sampled matches suit that kernel take it, on a
 	// segmentation of its own; the others, and the pairs it hands back, take the lane scan; passes B and C run per layout.
 	const int coop_mode = andi_coop_enabled();
-	int coop_ok = coop_mode != 0 && model <= ANDI_M_KIMURA && !andi_knob(KNOB_FORCE_REFERENCE);
+	int coop_ok = coop_mode != 0 && !andi_knob(KNOB_FORCE_REFERENCE);
 	for (size_t s = 0; s < nsub && coop_ok; ++s)
 		if (!subjects[s] || subjects[s]->thr < 2 || subjects[s]->thr > 30) coop_ok = 0;
 	const int coop = coop_ok && coop_mode > 0;
@@ -1305,7 +1305,7 @@ Rccl &rccl() {
 	return r;
 }
 
-char g_last_gather[200] = "none"; // how the last andi_hip_dist_matrix call collected its rows (diagnostic)
+thread_local char g_last_gather[200] = "none"; // how the calling thread's last andi_hip_dist_matrix call collected its rows (diagnostic)
 
 void row_block(size_t total, size_t parts, size_t k, size_t &first, size_t &last) { // as andi_amd/shard.py: row_block
 	const size_t base = total / parts, extra = total % parts;
@@ -1704,10 +1704,18 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		// one process, one node: the communicators bootstrap over the loopback interface unless the caller chose one;
 		// the caller's environment is put back as it was (a later multi-node initialisation in this process must not
 		// inherit the loopback)
-		const bool had_ifname = getenv("NCCL_SOCKET_IFNAME") != nullptr;
-		if (!had_ifname) setenv("NCCL_SOCKET_IFNAME", "lo", 0);
-		bool ok = nccl_ok(R.CommInitAll(comms.data(), (int)ndev, devs.data()), "ncclCommInitAll");
-		if (!had_ifname) unsetenv("NCCL_SOCKET_IFNAME");
+		// (RCCL takes the interface from the process environment and from nowhere else: two of this library's calls are
+		// kept apart by a lock; a caller whose OTHER threads read or write the environment meanwhile sets
+		// NCCL_SOCKET_IFNAME itself before its first call -- the library then leaves the environment alone, andi_hip.h)
+		static std::mutex env_lock;
+		bool ok;
+		{
+			std::lock_guard<std::mutex> guard(env_lock);
+			const bool had_ifname = getenv("NCCL_SOCKET_IFNAME") != nullptr;
+			if (!had_ifname) setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+			ok = nccl_ok(R.CommInitAll(comms.data(), (int)ndev, devs.data()), "ncclCommInitAll");
+			if (!had_ifname) unsetenv("NCCL_SOCKET_IFNAME");
+		}
 		if (ok && hipSetDevice(devs[0]) != hipSuccess) ok = false, err = "hipSetDevice";
 		if (ok && hipMalloc((void **)&d_full, n * n * sizeof(andi_hip_model)) != hipSuccess) ok = false, err = "allocating the gathered matrix";
 		if (ok) {

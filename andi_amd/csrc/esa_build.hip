@@ -608,7 +608,6 @@ size_t andi_min_tree_entries(int32_t n) {
 // read them: pass A in rounds (scan_rounds.hip) and pass A with one wavefront per chain (scan_coop.hip).  Every scan
 // understands both forms (the position is in the same place); the subject's handle remembers which it has.
 int andi_index_single_ext(size_t queries, bool sorted_on_device) { // queries: how many the subject is going to meet (0: unknown)
-	if (andi_knob(KNOB_COOP_PLAIN)) return 0; // (experiments)
 	const int coop = andi_coop_enabled();
 	if (coop == 0) return 0;
 	if (const char *f = andi_knob(KNOB_SINGLE_EXT)) return atoi(f); // (experiments: 0, 1, 2)

@@ -22,7 +22,7 @@
 //      plain loop; tests/test_coop_gpu.py checks this kernel against k_lane_cold slot by slot.
 //
 // Layout: one segment length for the call (slot = subject * total_segs + segment), wavefront w of subject
-// blockIdx.y takes segment w.  RAW/JC/Kimura only (LogDet and ANI count every anchor's nucleotides: scan_lane.hip).
+// blockIdx.y takes segment w.  LogDet and ANI count every anchor's nucleotides (EXACT: src/model.c:256-278).
 #include "lane_chain.h"
 #include "knobs.h"
 
@@ -202,6 +202,30 @@ __device__ __forceinline__ void coop_count_gap(const PairCtx &c, lds_u32 *hist, 
 				lds_add(&hist[(((sw >> k) & 3u) << 2) | ((qw >> k) & 3u)], 1u);
 			}
 		}
+	}
+}
+
+// model_count_equal for LogDet and ANI (src/model.c:256-278): the nucleotides of the anchor Q[q..q+len), with all lanes
+// (add = false: an anchor that was counted and should not have been is taken back)
+__device__ __forceinline__ void coop_count_anchor(const PairCtx &c, lds_u32 *hist, uint32_t q, uint32_t len, bool add = true) {
+	const uint32_t lane = __lane_id(), qe = q & ~1u, end = q + len;
+	uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+	for (uint32_t base = qe; base < end; base += 64 * WNT) {
+		const uint32_t x0 = base + WNT * lane;
+		if (x0 >= end) continue;
+		const uint4 qv = ld_query(c, x0);
+		const uint32_t lo = q > x0 ? q - x0 : 0u, hi = end - x0 < WNT ? end - x0 : WNT;
+		for (uint32_t j = lo >> 3; 8 * j < hi; ++j) {
+			const uint32_t a = lo > 8 * j ? lo - 8 * j : 0u, b = hi - 8 * j < 8 ? hi - 8 * j : 8u;
+			const uint32_t qw = pick(qv, j), ok = symbol_range(a, b) & ~(qw >> 2), b0 = qw, b1 = qw >> 1;
+			n0 += (uint32_t)__builtin_popcount(ok & ~(b0 | b1)), n1 += (uint32_t)__builtin_popcount(ok & b0 & ~b1);
+			n2 += (uint32_t)__builtin_popcount(ok & b1 & ~b0), n3 += (uint32_t)__builtin_popcount(ok & b0 & b1);
+		}
+	}
+	n0 = wave_sum(n0), n1 = wave_sum(n1), n2 = wave_sum(n2), n3 = wave_sum(n3);
+	if (lane == 0) {
+		if (add) lds_add(&hist[0], n0), lds_add(&hist[5], n1), lds_add(&hist[10], n2), lds_add(&hist[15], n3);
+		else lds_add(&hist[0], 0u - n0), lds_add(&hist[5], 0u - n1), lds_add(&hist[10], 0u - n2), lds_add(&hist[15], 0u - n3);
 	}
 }
 
@@ -391,17 +415,21 @@ __device__ __forceinline__ void coop_note_anchor(const ScanArgs &a, size_t slot,
 }
 
 // What an anchor at subject offset curS found at query offset st.p does to the counts (src/process.c:157-190)
-template <int NCH>
+template <int NCH, bool EXACT>
 __device__ __forceinline__ void coop_account(const PairCtx &c, Chain &ch, CoopLds<NCH> &L, uint32_t curS) {
 	ChainState &st = ch.st;
 	const uint32_t endS = st.lastS + st.lastLen, endQ = st.lastQ + st.lastLen;
+	auto count_last = [&]() { // model_count_equal of the last anchor
+		if constexpr (EXACT) coop_count_anchor(c, (lds_u32 *)L.hist, st.lastQ, st.lastLen);
+		else ch.quarter += st.lastLen >> 2, ch.rest += st.lastLen & 3u;
+	};
 	if (curS > endS && st.p - endQ == curS - endS && (curS < c.border) == (st.lastS < c.border)) {
-		ch.quarter += st.lastLen >> 2, ch.rest += st.lastLen & 3u;
+		count_last();
 		coop_count_gap(c, (lds_u32 *)L.hist, endQ, endS, st.p - endQ);
 		CSTAT(CS_G_GAPS, 1);
 		st.lwra = 1;
 	} else {
-		if (st.lwra || st.lastLen >= 2 * c.thr) ch.quarter += st.lastLen >> 2, ch.rest += st.lastLen & 3u;
+		if (st.lwra || st.lastLen >= 2 * c.thr) count_last();
 		st.lwra = 0;
 	}
 }
@@ -409,7 +437,7 @@ __device__ __forceinline__ void coop_account(const PairCtx &c, Chain &ch, CoopLd
 // ------------------------------------------------------------------ mode W
 // The chain stands at a canonical state of diagonal dg: st.p = e0 + 1 behind the anchor [lastQ, e0), e0 a mismatch
 // of the diagonal.  Returns true if the chain moved; st is a genuine loop-top state either way.
-template <int NCH>
+template <int NCH, bool EXACT>
 __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c, Chain &ch, CoopLds<NCH> &L, uint32_t end) {
 	const uint32_t lane = __lane_id(), thr = c.thr, n = (uint32_t)c.E.n;
 	ChainState &st = ch.st;
@@ -757,7 +785,11 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 				}
 				if (a_before == NOPOS) a_before = coop_prev_mismatch(L, wbase, pk) + 1;
 			}
-			if (lw_before || pk - a_before >= 2 * thr) ch.quarter += (pk - a_before) >> 2, ch.rest += (pk - a_before) & 3u;
+			if constexpr (EXACT) { // (the counting pass below counts every anchor's nucleotides: this one is taken back if it does not count)
+				if (!(lw_before || pk - a_before >= 2 * thr)) coop_count_anchor(c, (lds_u32 *)L.hist, a_before, pk - a_before, false);
+			} else {
+				if (lw_before || pk - a_before >= 2 * thr) ch.quarter += (pk - a_before) >> 2, ch.rest += (pk - a_before) & 3u;
+			}
 			extra_anchors += (uni(L.hflag[kk]) >> W_NX_SHIFT) & 7u;
 			if (lane == 0) L.kpos[kn] = pk;
 			++kn;
@@ -795,7 +827,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	// ---- the mismatches behind which a lucky anchor follows at once (all that are in no such stretch), and the
 	// anchors: one ends at every position that starts a gap.  Positions e0 ... cur - 1; lane l takes the NCH words of
 	// positions 32 NCH l ... (what lies before its first word comes from one scan over the lanes).
-	uint32_t q_acc = 0, r_acc = 0, n_acc = 0;
+	uint32_t q_acc = 0, r_acc = 0, n_acc = 0, x_acc[4] = {0, 0, 0, 0};
 	auto in_range = [&](uint32_t x0) { // the positions e0 ... cur - 1 of the word that starts at x0
 		uint32_t rm = ~0u;
 		if (x0 + WNT <= e0 || x0 >= cur) rm = 0;
@@ -824,10 +856,24 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		const uint32_t w = NCH * lane;
 		if (w && wbase + 32 * w > e0) prev_top = ((L.mbits[w - 1] | L.ebits[w - 1]) & in_range(wbase + 32 * (w - 1))) >> 31;
 	}
-	auto fetch = [&](uint32_t jw, uint4 &qv, uint4 &sv) { // the symbols of a word that has single mismatches to count
+	// LogDet / ANI: the nucleotides of every anchor that ends at a gap start of [e0, cur) -- the positions from the start of
+	// the anchor before e0 up to aQ that are in no gap (the part of that anchor that lies before the window: at once)
+	auto anchor_range = [&](uint32_t x0) { // the positions lastQ ... aQ - 1 of the word that starts at x0
+		uint32_t rm = ~0u;
+		if (x0 + WNT <= st.lastQ || x0 >= aQ) rm = 0;
+		if (rm && st.lastQ > x0) rm &= ~0u << (st.lastQ - x0);
+		if (rm && aQ - x0 < WNT) rm &= (1u << (aQ - x0)) - 1u;
+		return rm;
+	};
+	if constexpr (EXACT)
+		if (st.lastQ < wbase) coop_count_anchor(c, (lds_u32 *)L.hist, st.lastQ, (aQ < wbase ? aQ : wbase) - st.lastQ);
+	auto fetch = [&](uint32_t jw, uint4 &qv, uint4 &sv) { // the symbols of a word that has single mismatches (or, LogDet / ANI, anchors) to count
 		const uint32_t w = NCH * lane + jw, x0 = wbase + 32 * w;
 		qv = sv = make_uint4(0, 0, 0, 0);
-		if (jw < (uint32_t)NCH && (L.mbits[w] & ~L.ebits[w] & in_range(x0))) qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
+		if (jw >= (uint32_t)NCH) return;
+		const bool singles = (L.mbits[w] & ~L.ebits[w] & in_range(x0)) != 0;
+		if (singles || (EXACT && anchor_range(x0))) qv = ld_query(c, x0);
+		if (singles) sv = ld_subject_guarded(c, (int64_t)x0 + dg);
 	};
 	uint4 qnext, snext;
 	fetch(0, qnext, snext);
@@ -845,7 +891,18 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			// (the anchor before a stretch that is counted nowhere: the hop above has dealt with it, src/process.c:176-186)
 			bool nowhere = false;
 			for (uint32_t t = 0; t < kn; ++t) nowhere |= L.kpos[t] == x0 + b;
-			if (!nowhere) q_acc += len >> 2, r_acc += len & 3u;
+			if (!EXACT && !nowhere) q_acc += len >> 2, r_acc += len & 3u;
+		}
+		if constexpr (EXACT) { // this word's positions inside anchors, by nucleotide
+			const uint32_t am = anchor_range(x0) & ~u;
+			for (uint32_t j = 0; j < 4 && am; ++j) {
+				uint32_t t = (am >> (8 * j)) & 0xffu; // 8 positions -> bit 4k of a word
+				if (!t) continue;
+				t = (t | (t << 12)) & 0x000f000fu, t = (t | (t << 6)) & 0x03030303u, t = (t | (t << 3)) & ONES;
+				const uint32_t qw = pick(qv, j), ok = t & ~(qw >> 2), b0 = qw, b1 = qw >> 1;
+				x_acc[0] += (uint32_t)__builtin_popcount(ok & ~(b0 | b1)), x_acc[1] += (uint32_t)__builtin_popcount(ok & b0 & ~b1);
+				x_acc[2] += (uint32_t)__builtin_popcount(ok & b1 & ~b0), x_acc[3] += (uint32_t)__builtin_popcount(ok & b0 & b1);
+			}
 		}
 		if (u) before = x0 + 31u - (uint32_t)__builtin_clz(u) + 2u;
 		prev_top = u >> 31;
@@ -857,6 +914,12 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	}
 	TOCK(tph, PH_FINAL);
 	ch.quarter += wave_sum(q_acc), ch.rest += wave_sum(r_acc);
+	if constexpr (EXACT) {
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t v = wave_sum(x_acc[k]);
+			if (lane == 0) lds_add((lds_u32 *)&L.hist[5 * k], v);
+		}
+	}
 	ch.anchors += wave_sum(n_acc) + extra_anchors;
 	{
 		const uint32_t nodes = wave_sum(n_acc);
@@ -868,7 +931,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 }
 
 // ------------------------------------------------------------------ the kernel
-template <int NCH>
+template <int NCH, bool EXACT>
 #ifndef COOP_OCC
 #define COOP_OCC 8
 #endif
@@ -944,7 +1007,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 			found = (v >> 31) && curLen >= thr;
 		}
 		if (found) {
-			coop_account(c, ch, L, curS);
+			coop_account<NCH, EXACT>(c, ch, L, curS);
 			st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
 		}
 		st.p += curLen + 1;
@@ -954,7 +1017,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 		}
 		// ---- windows one after the other while the chain stays canonical on the diagonal and moves
 		if (found && lucky)
-			while (st.p < end && st.lastQ + st.lastLen < c.qlen && coop_window<NCH>(a, c, ch, L, end)) {
+			while (st.p < end && st.lastQ + st.lastLen < c.qlen && coop_window<NCH, EXACT>(a, c, ch, L, end)) {
 				if (given_up()) return;
 			}
 	}
@@ -1000,9 +1063,9 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 	const dim3 grid((a.total_segs + COOP_WAVES - 1) / COOP_WAVES, a.nsub);
 	const int nch = andi_coop_enabled();
 	switch (nch < 0 ? -nch : nch) {
-		case 2: k_coop_cold<2><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
-		case 8: k_coop_cold<8><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
-		default: k_coop_cold<4><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
+		case 2: a.exact_equal ? k_coop_cold<2, true><<<grid, 64 * COOP_WAVES, 0, st>>>(a) : k_coop_cold<2, false><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
+		case 8: a.exact_equal ? k_coop_cold<8, true><<<grid, 64 * COOP_WAVES, 0, st>>>(a) : k_coop_cold<8, false><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
+		default: a.exact_equal ? k_coop_cold<4, true><<<grid, 64 * COOP_WAVES, 0, st>>>(a) : k_coop_cold<4, false><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 	}
 #ifdef ANDI_COOP_STATS
 	if (andi_knob(KNOB_COOP_STATS)) {

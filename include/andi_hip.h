@@ -84,7 +84,11 @@ int andi_hip_abi_version(void);
 /* ------------------------------------------------------------------ */
 int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 						 const andi_hip_opts *opts, char *errbuf, size_t errlen);
-/* how the last call collected its rows: "rccl", "direct" (diagnostic; not thread-safe) */
+/* how the calling thread's last call collected its rows: "rccl", "direct (...)" (diagnostic; per thread).
+ * A call that spans several devices initialises RCCL communicators, and RCCL reads the bootstrap interface from the
+ * process environment only: unless NCCL_SOCKET_IFNAME is set, the library sets it to "lo" around ncclCommInitAll and
+ * takes it back (its own calls serialised by a lock).  A caller with other threads that touch the environment sets
+ * NCCL_SOCKET_IFNAME itself beforehand: the library then never writes the environment. */
 const char *andi_hip_last_gather(void);
 
 /* ------------------------------------------------------------------ */

@@ -5,7 +5,7 @@
       386 batches of slot reuse, 3085 device suffix sorts, a 647 MB matrix.
   c5: 256 genomes x 50 Mbp (d ~ U[1e-3, 5e-2]) + 99 bootstrap matrices on the device.
 
-Evidence written to gpurun_out/r4_<config>_full.json: wall-clock of the call, the ANDI_E2E_TRACE split (stderr of
+Evidence written to gpurun_out/r05_<config>_full.json: wall-clock of the call, the ANDI_E2E_TRACE split (stderr of
 the library, captured), sampled rows against the oracle, and the oracle's OpenMP port timed on a row sample on all
 host cores (checker code: timed as a baseline only).  /root/reference is not needed.
 """
@@ -145,7 +145,7 @@ def main():
                             "mean_total_ratio": float(np.mean(B[0][:, :, :16].astype(np.int64).sum(axis=2)[iu] / np.maximum(1, (tot + tot.T)[iu])))}
         ctx.close()
 
-    path = args.out or os.path.join(ROOT, "gpurun_out", "r4_%s_full.json" % args.config)
+    path = args.out or os.path.join(ROOT, "gpurun_out", "r05_%s_full.json" % args.config)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -56,6 +56,26 @@ def test_strands_contigs_edges():
                 coop, segment, np.argwhere((got != want).any(axis=2))[:8].tolist())
 
 
+@pytest.mark.parametrize("model", [3, 4])
+def test_logdet_and_ani_count_every_anchor(model):
+    """LogDet and ANI count the nucleotides of every anchor (src/model.c:256-278): the wavefront kernel's EXACT form on a
+    divergence ladder, structured genomes (walks with anchors off the diagonal, breaks, generic steps), both strands and
+    joined contigs, at the default and at tiny segments -- 16 counts per pair against the oracle."""
+    base = synth.base_codes(200000, 15)
+    seqs = [synth.to_bytes(synth.mutate_codes(base, d, 30 + k)) for k, d in enumerate((0.0, 0.002, 0.02, 0.06))]
+    seqs.append(_revcomp(seqs[2]))
+    seqs.append(synth.join_contigs(seqs[1], 6))
+    want = orc.dist_matrix(seqs, model=model, threads=4)
+    for coop in (2, 4):
+        for segment in (0, 3000):
+            got = _matrix(seqs, model, coop, segment)
+            assert (got == want).all(), (coop, segment, np.argwhere((got != want).any(axis=2))[:6].tolist())
+    real, _ = synth.realistic_set(4, 300000, 0.002, 0.05, seed=41)
+    want = orc.dist_matrix(real, model=model, threads=4)
+    assert (_matrix(real, model, 4, 0) == want).all()
+    assert (_matrix(real, model, 4, 5000) == want).all()
+
+
 def test_headline_pair_full_length():
     """one pair at BASELINE's genome length, both directions, against the lane scan (itself pinned to the oracle)"""
     seqs, _ = synth.genome_set(3, 4_900_000, 0.0004, 0.03, seed=1729)
