@@ -1070,6 +1070,10 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	a.coop = coop && !a.adaptive;
 	a.route = routed ? ANDI_LAYOUT_LANES : 0, a.route_seg = coop_seg, a.route_nt = ctx->d_route;
+	{
+		const char *gu = andi_knob(KNOB_COOP_GIVEUP); // (tests: hand pairs back early, so that the second lane layout runs)
+		a.route_giveup = gu && atoi(gu) > 0 ? (uint32_t)atoi(gu) : 1024u;
+	}
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 
 	if (routed) {

@@ -35,7 +35,7 @@ namespace {
 #define COOP_HCAP (NCH <= 2 ? 64u : 24u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
 constexpr int COOP_WAVES = 1; // wavefronts per block: single wavefronts find a place on a CU the moment one leaves (bench set 5.39 -> 5.24 ms against blocks of two, 5.61 with four); seven per SIMD (72 registers): 4.94
 constexpr uint32_t COOP_KCAP = 32; // stretches of a window that are counted nowhere (more: the window ends before the next one)
-constexpr uint32_t COOP_TRIAL_G = 1536;  // routed calls: a segment that needs more generic steps than this lies in long stretches without homology that the sampling missed (clean sets: <= 45; an island of 20 kbp: some 1500) -- the pair is handed back
+// (routed calls hand a pair back when one of its segments needs more generic steps than ScanArgs.route_giveup -- 1024: long stretches without homology that the sampling missed (clean sets: <= 45 steps; an island of 20 kbp: some 1500).  Grinding through them instead -- the limit at 16384 -- took the structured set's pass A from 9.4 to 28 ms for 9 of its 812 pairs, and its passes B/C from 6.9 to 15 ms: their true chains cross the islands on long segments, one lane each)
 constexpr uint32_t COOP_TRIAL_LCP = 16;  // routed calls: a match followed through more rounds of 2048 symbols than this is longer than its segment
 constexpr uint32_t COOP_PARK = 16; // parked lanes (their probe needs lane_probe) that are served together
 constexpr uint32_t COOP_MAX_X = 3;  // anchors off the window's diagonal a walk follows before it gives up
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 		CSTAT(CS_G_STEPS, 1);
 		++my_g;
 		if (route) {
-			if (my_g > COOP_TRIAL_G + (a.seg >> 12)) return give_up(); // (a few more per window the segment holds)
+			if (my_g > a.route_giveup + (a.seg >> 12)) return give_up(); // (a few more per window the segment holds)
 			if (given_up()) return;
 		}
 		// ---- one step of mode G (src/process.c:153-197)

@@ -95,7 +95,20 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
 		if (lane == 0) atomicAdd(&s_shorts, shorts), atomicAdd(&s_runs, runs);
 		__syncthreads(); // (coop_cand is the same in all four wavefronts: they took the same samples)
 		shorts = s_shorts, runs = s_runs;
-		const float f = (float)shorts / (float)nsamples, f5 = f * f * f * f * f, expect = (float)nsamples * f5;
+		// The rate f0 of short samples OUTSIDE unrelated stretches: from the short samples that did not turn into a run --
+		// f0 - f0^5 of the samples in homologous sequence, hardly any inside a stretch without homology (Newton on the lower
+		// branch; pairs beyond 6 % or so have no solution there and are taken for suspicious: the lane scan's anyway).
+		// Taking the rate from all short samples let the stretches themselves raise the expectation: one structured pair
+		// in ninety passed, and ground through its islands in generic steps.
+		const float ns = (float)nsamples;
+		float g = (float)(shorts - runs) / ns, f0;
+		if (g > 0.53f) g = 0.53f;
+		f0 = g;
+		for (int it = 0; it < 5; ++it) {
+			const float f4 = f0 * f0 * f0 * f0;
+			f0 -= (f0 - f0 * f4 - g) / (1.f - 5.f * f4);
+		}
+		const float f5 = f0 * f0 * f0 * f0 * f0, expect = ns * f5;
 		islands = (float)runs > expect + 3.f * sqrtf(expect * (1.f - f5)) + 3.f;
 	} else if (quad_cand) { // (wave-uniform; calls that are not routed, and the pairs with the longest matches)
 		uint32_t shorts = r.len < c.thr ? 1u : 0u;

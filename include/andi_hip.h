@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ANDI_HIP_ABI_VERSION 2
+#define ANDI_HIP_ABI_VERSION 3
 
 /* enum in src/global.h:50 */
 enum { ANDI_M_RAW = 0, ANDI_M_JC = 1, ANDI_M_KIMURA = 2, ANDI_M_LOGDET = 3, ANDI_M_ANI = 4 };

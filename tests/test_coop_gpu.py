@@ -125,6 +125,20 @@ def test_large_calls_are_routed_per_pair():
     assert (got == lane).all()
 
 
+def test_pairs_handed_back_take_the_second_lane_layout():
+    """A wavefront that meets long stretches without homology hands its PAIR back to the lane scan, which gives such
+    pairs a second layout of their own.  With the default limit that is rare (the sampling keeps pairs with unrelated
+    stretches away from the kernel), so the genomes here carry only 0.5 % of unrelated sequence -- less than the sampling
+    notices -- and the limit is lowered to 48 generic steps per segment (ANDI_COOP_GIVEUP).  Same counts as the lane
+    scan; pairs were handed back and their layout's passes ran."""
+    os.environ.pop("ANDI_COOP", None)
+    real, _ = synth.realistic_set(12, 4_900_000, 0.004, 0.03, seed=9, novel_fraction=0.005)
+    lane, _ = _rows(real, {"ANDI_COOP": "0"})
+    got, t = _rows(real, {"ANDI_COOP_GIVEUP": "48"})
+    assert t["routed_calls"] == 1 and t["coop_fallbacks"] > 0 and t["lane_query_nt"] > 0, t
+    assert (got == lane).all()
+
+
 def test_mixed_call_clean_close_and_structured_pairs_against_the_oracle():
     """ONE call whose pairs are of every kind -- clean pairs a few percent apart (the wavefront kernel's), pairs a few
     substitutions apart (k_lane_quad's), pairs with unrelated stretches, repeats and indels (k_lane_cold's, some of them
