@@ -1073,6 +1073,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	{
 		const char *gu = andi_knob(KNOB_COOP_GIVEUP); // (tests: hand pairs back early, so that the second lane layout runs)
 		a.route_giveup = gu && atoi(gu) > 0 ? (uint32_t)atoi(gu) : 1024u;
+		const char *sm = andi_knob(KNOB_ROUTE_SOFT); // (experiments)
+		a.route_soft_match = sm && atoi(sm) > 0 ? (uint32_t)atoi(sm) : 512u; // (128 = k_lane_quad's class: tree-structured set 38.1 -> 39.4 % of the roofline at 512, C3-like 45.6 -> 48.1 %, C4 shape the same)
 	}
 	a.exact_equal = (model == ANDI_M_LOGDET || model == ANDI_M_ANI) ? 1 : 0; // src/model.c:247
 

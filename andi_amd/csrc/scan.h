@@ -104,6 +104,7 @@ struct ScanArgs {
 	// Passes B and C run once per layout, each on its own pairs.
 	int route; // 0: no routing (every pair takes the call's one pass A); else the layout these arguments describe: ANDI_LAYOUT_*
 	uint32_t route_seg;           // the wavefront kernel's segment length in a routed call
+	uint32_t route_soft_match;    // mean sampled match from which a pair is better off with k_lane_quad if such pairs are many (k_pair_estimate)
 	uint32_t route_giveup;        // generic steps in one of its segments beyond which a wavefront hands its pair back (scan_coop.hip: COOP_TRIAL_G; ANDI_COOP_GIVEUP: tests)
 	unsigned long long *route_nt; // [3]: query nucleotides of the pairs whose pass A ran by wavefronts / by lanes, pairs handed back
 	int coop;            // pass A with one wavefront per chain (scan_coop.hip): one segment length, RAW/JC/Kimura, probe-table subjects

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
 	bool islands = false;
 	const bool quad_cand = (sum >> 6) >= a.quad_min_match && (sum >> 6) < ANDI_ISLAND_MEAN_MAX && a.quad_min_match != 0;
 	// routed calls: would the pair suit pass A by wavefronts?  (one whole segment of that kernel's at least)
-	const bool coop_cand = a.route && (sum >> 6) < 4 * a.quad_min_match && c.qlen >= a.route_seg; // (matches of 512 symbols and more on average: k_lane_quad's, always)
+	const bool coop_cand = a.route && (sum >> 6) < 512u && c.qlen >= a.route_seg; // (matches of 512 symbols and more on average: k_lane_quad's, always)
 	if (coop_cand) { // (wave-uniform)
 		// Unrelated stretches are contiguous: where a sample sees less than a threshold's worth of matching symbols, four
 		// more are taken, 128 symbols apart.  Five short ones in a row come about by chance at the fifth power of the rate of
@@ -132,9 +132,10 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
 		// bit 7: the pair's matches are long enough for pass A with the streams fetched by quads (k_lane_quad)
 		// (routed calls) pairs the lane scan is better at -- matches hardly reaching the anchor threshold (divergence beyond
 		// some 6 %: their chains probe at nearly every step and meet their neighbours' slowly; with long segments pass B has
-		// few lanes for those replays), matches of 128 symbols and more (k_lane_quad streams them faster) -- take it where
-		// they are more than a tenth of the call; a few of them ride along with the wavefront kernel (k_pair_route)
-		const bool soft = (sum >> 6) < ANDI_SPARSE_MATCH || (sum >> 6) >= a.quad_min_match;
+		// few lanes for those replays) -- take it where they are more than a tenth of the call; a few of them ride along
+		// with the wavefront kernel (k_pair_route).  (Pairs of k_lane_quad's class -- mean match 128 ... 511 -- were treated
+		// the same way at first: the wavefront kernel is the faster one for them, route_soft_match.)
+		const bool soft = (sum >> 6) < ANDI_SPARSE_MATCH || (sum >> 6) >= a.route_soft_match;
 		const bool quad = (sum >> 6) >= a.quad_min_match && !(islands && (sum >> 6) < ANDI_ISLAND_MEAN_MAX);
 		a.pair_class[pair] = (uint8_t)(cls | (quad ? 0x80u : 0u) | (coop_cand && !islands ? ANDI_ROUTE_COOP : 0u) | (soft ? ANDI_ROUTE_SOFT : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
