@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Calls of the size at which pass A by wavefronts goes on trial (scan_coop.hip): random sets of 8-12 genomes of
+"""Calls of the size at which pass A is routed per pair (scan.h: ScanArgs.route): random sets of 8-12 genomes of
 3-5 Mbp (star, tree, structured, close, mixed), every model the kernel takes, through andi_hip_scan_rows --
-the call as it comes (trial), the lane scan (ANDI_COOP=0) and the wavefront kernel forced (ANDI_COOP=4) must agree
+the call as it comes (routed), the lane scan (ANDI_COOP=0) and the wavefront kernel forced (ANDI_COOP=4) must agree
 bit for bit, and one sampled subject row must equal the oracle's.  scripts/fuzz_large.py [seconds] [seed]"""
 import os
 import sys
@@ -73,11 +73,11 @@ def main():
         want = orc.scan_row(orc.OracleEsa(seqs[k]), seqs, k, model, threads=0)
         ok = bool((got == lane).all() and (forced == lane).all() and (lane[k] == want).all())
         case += 1
-        print("case %3d %-9s n=%2d len=%d model=%d  trial: by wavefronts %d, fallen back %d; fix-ups lane/trial %d/%d  %s" % (
+        print("case %3d %-9s n=%2d len=%d model=%d  routed calls %d, pairs handed back %d; fix-ups lane/routed %d/%d  %s" % (
             case, kind, n, length, model, t1["routed_calls"], t1["coop_fallbacks"], t0["fixups"], t1["fixups"], "ok" if ok else "DIFFERENT"), flush=True)
         if not ok:
             sys.exit(1)
-    print("fuzz_large: %d cases, all equal (trial = lane scan = forced kernel, sampled rows = oracle)" % case)
+    print("fuzz_large: %d cases, all equal (routed = lane scan = forced kernel, sampled rows = oracle)" % case)
 
 
 if __name__ == "__main__":
