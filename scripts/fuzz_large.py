@@ -65,7 +65,7 @@ def main():
             b, _ = synth.realistic_set(2, length, 0.002, 0.03, seed=seed + 3)
             seqs = a + b
         seqs = [bytes(s) for s in seqs]
-        model = int(rng.choice([0, 1, 2]))
+        model = int(rng.choice([0, 1, 1, 2, 3, 4]))
         lane, t0 = rows(seqs, model, {"ANDI_COOP": "0"})
         got, t1 = rows(seqs, model, {})
         forced, t2 = rows(seqs, model, {"ANDI_COOP": "4"}) if kind in ("star", "tree") else (lane, t0)

@@ -54,7 +54,7 @@ def main():
         for _ in range(3):
             segment = int(rng.choice([0, 0, 64, 100, 300, 700, 2048, 5000, 40000]))
             env = {}
-            if rng.random() < 0.3 and model <= 2:
+            if rng.random() < 0.3:
                 env["ANDI_COOP"] = str(rng.choice([2, 4, 8]))
             if rng.random() < 0.15:
                 env["ANDI_UNIFORM_SEGMENTS"] = "1"
