@@ -47,9 +47,11 @@ def main():
     t_end = time.time() + budget
     case = 0
     while time.time() < t_end:
-        kind = str(rng.choice(["star", "tree", "realistic", "close", "mixed"]))
-        n = int(rng.integers(8, 13))
+        kind = str(rng.choice(["star", "tree", "realistic", "close", "mixed", "joined", "strands", "sparse"]))
+        n = int(rng.integers(10, 15)) if kind != "sparse" else 12
         length = int(rng.integers(3_000_000, 5_000_000))
+        if rng.random() < 0.8:  # most cases of the size from which a call is routed: n^2 * length >= 2^14 * 32768 symbols
+            length = max(length, (1 << 29) // (n * n) + 100_000)
         seed = int(rng.integers(1, 1 << 30))
         if kind == "star":
             seqs, _ = synth.genome_set(n, length, 0.0004, float(rng.choice([0.01, 0.03, 0.06])), seed=seed)
@@ -60,6 +62,15 @@ def main():
         elif kind == "close":
             base = synth.base_codes(length, seed)
             seqs = [synth.to_bytes(synth.mutate_codes(base, float(rng.choice([2e-5, 2e-4])), seed + 1 + k)) for k in range(n)]
+        elif kind == "joined":  # clean genomes cut into contigs joined by '!' (andi --join): windows with separators
+            a, _ = synth.genome_set(n, length, 0.002, 0.03, seed=seed)
+            seqs = [synth.join_contigs(bytes(s), int(rng.integers(2, 40)), seed=seed + k) for k, s in enumerate(a)]
+        elif kind == "strands":  # every other genome as its reverse complement: the chains run on the other strand of RS
+            a, _ = synth.genome_set(n, length, 0.002, 0.03, seed=seed)
+            rc = bytes.maketrans(b"ACGT", b"TGCA")
+            seqs = [bytes(s) if k % 2 == 0 else bytes(s)[::-1].translate(rc) for k, s in enumerate(a)]
+        elif kind == "sparse":  # a few clean pairs among pairs 8-12 % apart: the far ones are the lane scan's (many of them)
+            seqs, _ = synth.genome_set(n, length, 0.002, 0.06, seed=seed)
         else:
             a, _ = synth.genome_set(n - 2, length, 0.002, 0.03, seed=seed)
             b, _ = synth.realistic_set(2, length, 0.002, 0.03, seed=seed + 3)
@@ -68,7 +79,7 @@ def main():
         model = int(rng.choice([0, 1, 1, 2, 3, 4]))
         lane, t0 = rows(seqs, model, {"ANDI_COOP": "0"})
         got, t1 = rows(seqs, model, {})
-        forced, t2 = rows(seqs, model, {"ANDI_COOP": "4"}) if kind in ("star", "tree") else (lane, t0)
+        forced, t2 = rows(seqs, model, {"ANDI_COOP": "4"}) if kind in ("star", "tree", "joined", "strands") else (lane, t0)
         k = int(rng.integers(0, n))
         want = orc.scan_row(orc.OracleEsa(seqs[k]), seqs, k, model, threads=0)
         ok = bool((got == lane).all() and (forced == lane).all() and (lane[k] == want).all())

@@ -1,0 +1,53 @@
+"""The statistic pass A's routing rests on (andi_amd/csrc/scan_lane.hip: k_pair_estimate), restated on the CPU on the
+oracle's matcher: runs of five short samples tell a pair with unrelated stretches from a clean one whatever the pair's
+divergence.  TEST INFRASTRUCTURE: the oracle is the checker of the model's inputs only; the device code is checked
+against the lane scan and the oracle in tests/test_coop_gpu.py (which pairs go where never changes a result)."""
+import numpy as np
+import pytest
+
+from andi_amd import synth
+from oracle import orc
+
+
+def _suspected(subject: bytes, query: bytes, nsamples=512):
+    """k_pair_estimate's verdict for one ordered pair: (shorts, runs, suspected)"""
+    E = orc.OracleEsa(subject)
+    T = E.threshold + 3
+    qlen = len(query)
+    shorts = runs = 0
+    for i in range(nsamples):
+        p = (2 * i + 1) * qlen // (2 * nsamples)
+        all_short = True
+        for j in range(5):
+            pj = p + 128 * j
+            if not (pj + T < qlen and E.get_match(query[pj:pj + T + 1])[0] < T):
+                all_short = False
+                break
+            if j == 0:
+                shorts += 1
+        runs += all_short
+    E.close()
+    g = min((shorts - runs) / nsamples, 0.53)
+    f0 = g
+    for _ in range(5):
+        f4 = f0 ** 4
+        f0 -= (f0 - f0 * f4 - g) / (1 - 5 * f4)
+    f5 = f0 ** 5
+    expect = nsamples * f5
+    return shorts, runs, runs > expect + 3 * np.sqrt(expect * (1 - f5)) + 3
+
+
+@pytest.mark.parametrize("d", [0.005, 0.02, 0.04, 0.05])
+def test_clean_pairs_are_not_suspected(d):
+    """(up to some 5.5 % apart; beyond, f0 - f0^5 is flat, f0 comes out low and the pair is taken for suspicious: such pairs
+    are the lane scan's anyway where they are many)"""
+    a, b = synth.pair(1_000_000, d, seed=int(d * 1e4))
+    shorts, runs, bad = _suspected(a, b)
+    assert not bad, (d, shorts, runs)
+
+
+@pytest.mark.parametrize("d", [0.004, 0.03, 0.05])
+def test_pairs_with_unrelated_stretches_are(d):
+    seqs, _ = synth.realistic_set(2, 1_000_000, d / 2, d / 2 + 1e-9, seed=7 + int(d * 1e3))
+    shorts, runs, bad = _suspected(seqs[0], seqs[1])
+    assert bad, (d, shorts, runs)
