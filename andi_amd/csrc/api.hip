@@ -1382,9 +1382,11 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	for (size_t a = 0; a < ndev; ++a)
 		for (size_t b = a + 1; b < ndev; ++b) distinct = distinct && devs[a] != devs[b];
 	const char *gather_env = andi_knob(KNOB_GATHER);
-	// RCCL gather: several distinct devices (or forced, to exercise the path on one device), and the matrix fits next to the rest
+	// RCCL gather: several distinct devices (or forced, to exercise the path on the devices there are -- with contexts that
+	// share a device the communicators cannot be made: the route's fallback, every block copied from HBM directly, runs),
+	// and the matrix fits next to the rest
 	bool use_rccl = (ndev > 1 && distinct && !(gather_env && !strcmp(gather_env, "direct"))) ||
-					(distinct && gather_env && !strcmp(gather_env, "rccl"));
+					(gather_env && !strcmp(gather_env, "rccl"));
 	if (use_rccl && n * n * sizeof(andi_hip_model) > ((size_t)32 << 30)) use_rccl = false;
 	if (use_rccl && !rccl().ok) use_rccl = false;
 

@@ -46,6 +46,11 @@ andi_amd.lib.reload_knobs()
 got = andi_amd.dist_matrix(seqs, host_threads=4, num_gpus=-1)
 assert (got == want).all()
 assert andi_amd.lib.last_gather() == "rccl", andi_amd.lib.last_gather()
+# contexts that share a device: the rows stay in HBM as on the RCCL route, the communicators cannot be made (one device
+# twice), and the route's fallback copies every block to the host matrix directly -- the error is kept in the gather string
+got = andi_amd.dist_matrix(seqs, host_threads=4, devices=[0, 0, 0])
+assert (got == want).all()
+assert andi_amd.lib.last_gather().startswith("direct (rccl:"), andi_amd.lib.last_gather()
 del os.environ["ANDI_GATHER"]
 andi_amd.lib.reload_knobs()
 if andi_amd.lib.device_count() > 1:  # several GPUs visible: the same call spans all of them
