@@ -78,6 +78,8 @@ const char *andi_knob(AndiKnob k) {
 // per-pair segment lengths: classes seg/2, seg, 2 seg, 4 seg of the call's length, as long as the scratch they
 // need (whole wavefronts per pair) stays a fraction of the device's memory
 #define ANDI_ADAPTIVE_MAX_PAIRS (1u << 22)
+#define ANDI_ROUTE_MIN_NT (1u << 18) /* query symbols x subjects from which pass A of a call is routed per pair */
+#define ANDI_ROUTE_SMALL_NT (1ull << 30) /* ... below which pass A by wavefronts takes a millisecond or less: a few pairs left to the lane scan would take longer (k_pair_route) */
 // scratch per (subject, segment): three states, two count vectors, the marks, the exit position, a list slot, a published anchor
 #define ANDI_SLOT_BYTES (3 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4 + 8 + 8)
 
@@ -121,7 +123,7 @@ struct andi_hip_ctx {
 	uint32_t *h_quad_waves = nullptr; // pinned: the length of k_lane_quad's list of a scan call
 	hipStream_t coop_stream = nullptr; // routed scan calls: pass A by wavefronts runs beside the lane scan's kernels
 	hipEvent_t coop_fork = nullptr, coop_join = nullptr, l2_fork = nullptr, l2_join = nullptr;
-	uint32_t *h_any_left = nullptr;    // pinned: [0] the wavefront kernel handed some pair back, [1] wavefronts of the lane layout
+	uint32_t *h_any_left = nullptr;    // pinned: [0] the wavefront kernel handed some pair back, [1 ... 6] the layout's counters (restitch_count[ANDI_LANE_WAVES ...]: [1] wavefronts of the lane layout)
 	void *scratch2 = nullptr;          // the second lane layout (those pairs), grown on demand
 	size_t scratch2_bytes = 0;
 	unsigned long long *d_route = nullptr; // routed scan calls: query nucleotides whose pass A ran by wavefronts / by lanes, pairs handed back (read with the timings)
@@ -355,7 +357,7 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_join, hipEventDisableTiming);
-	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_any_left, 2 * sizeof(uint32_t), hipHostMallocDefault);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_any_left, 8 * sizeof(uint32_t), hipHostMallocDefault);
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_route, 4 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_route, 0, 4 * sizeof(unsigned long long));
 	if (e != hipSuccess) {
@@ -892,19 +894,27 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// dependent round trips: segments as long as leave the device four rounds of wavefronts (24576), 32768 ... 524288
 	// symbols (measured: bench set 5.57 / 5.39 / 5.31 / 5.34 ms at 32768 / 65536 / 131072 / 262144, C4 shape 38.6 / 33.5 /
 	// 32.6 / 32.6 / 35.4 / 44.0 ms at 32768 / 131072 / 262144 / 524288 / 2^20 / 2^21 -- whole queries: pairs differ too much)
+	// Small calls: shorter segments still, as long as the device has one round of wavefronts (2048 symbols at least) --
+	// 3 x 1 Mbp (BASELINE's configs[0]): pass A 0.10 ms by wavefronts against 0.66 ms by lanes; 100 x 30 kbp 0.94 against
+	// 2.35 ms per call (profiles/r05_small_calls.txt).
 	uint32_t coop_seg = 524288;
 	while (coop_seg > 32768 && q->total_nt * (uint64_t)nsub / coop_seg < 24576) coop_seg /= 2;
+	while (coop_seg > 2048 && q->total_nt * (uint64_t)nsub / coop_seg < (1u << 14)) coop_seg /= 2;
 	if (const char *cs = andi_knob(KNOB_COOP_SEG)) // experiments
 		if (atoi(cs) >= 64) coop_seg = (uint32_t)atoi(cs);
-	bool routed = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub / 32768 >= (1u << 14) &&
-				  !andi_knob(KNOB_UNIFORM_SEGMENTS) && !andi_knob(KNOB_FORCE_ADAPTIVE);
+	// (the smallest calls -- a few launches' worth of work -- keep the lane scan: routing costs them the sampling kernel
+	// and two looks of the host at the device)
+	bool routed = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub >= ANDI_ROUTE_MIN_NT &&
+				  nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS && !andi_knob(KNOB_UNIFORM_SEGMENTS) && !andi_knob(KNOB_FORCE_ADAPTIVE);
+	if (routed) { // (queries shorter than the wavefront kernel takes -- k_pair_estimate -- are the lane scan's: where they are most of the call, all of it)
+		uint64_t cand_nt = 0;
+		for (size_t i = 0; i < q->nq; ++i)
+			if (q->len[i] >= std::min(coop_seg, ANDI_ROUTE_MIN_QLEN)) cand_nt += q->len[i];
+		if (2 * cand_nt < q->total_nt) routed = false;
+	}
 	const bool want_adaptive = !coop && segment == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
 							   !andi_knob(KNOB_UNIFORM_SEGMENTS);
-	if (segment == 0 && coop) {
-		const uint64_t nt = q->total_nt * (uint64_t)nsub;
-		segment = coop_seg;
-		while (segment > 2048 && nt / segment < (1u << 14)) segment /= 2;
-	}
+	if (segment == 0 && coop) segment = coop_seg;
 	if (segment == 0) {
 		uint64_t nt = q->total_nt * (uint64_t)nsub;
 		segment = ANDI_MIN_SEGMENT;
@@ -992,14 +1002,11 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		if (!fits || (10 * used < 7 * 64 * max_waves && !andi_knob(KNOB_FORCE_ADAPTIVE))) adaptive = false, max_waves = 0;
 	}
 	const size_t pairs_all = nsub * q->nq;
-	// (routing wants the pairs' sampled classes -- k_pair_estimate runs for the per-pair layout only: calls that do not
-	// get that layout keep the lane scan)
-	if (!adaptive) routed = false;
 	if (routed && ensure_segmentation(ctx, q, coop_seg, true)) return 1;
 	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
 	const size_t slots2 = routed ? nsub * (size_t)q->c_total_segs : 0; // (the wavefront kernel's layout, beside the lane scan's)
 	const size_t need = (slots + slots2) * ANDI_SLOT_BYTES + 256 +
-						(adaptive ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
+						(adaptive || routed ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->scratch) (void)andi_arena::dev_free(ctx->scratch);
@@ -1070,6 +1077,10 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	a.coop = coop && !a.adaptive;
 	a.route = routed ? ANDI_LAYOUT_LANES : 0, a.route_seg = coop_seg, a.route_nt = ctx->d_route;
+	uint32_t longest_q = 0;
+	for (size_t i = 0; i < q->nq; ++i) longest_q = std::max(longest_q, (uint32_t)q->len[i]);
+	a.reduce_threads = (longest_q + (a.adaptive ? seg0 : segment) - 1) / (a.adaptive ? seg0 : segment) <= 64 ? 64u : 0u;
+	a.route_all_few = q->total_nt * (uint64_t)nsub < ANDI_ROUTE_SMALL_NT ? 1u : 0u;
 	{
 		const char *gu = andi_knob(KNOB_COOP_GIVEUP); // (tests: hand pairs back early, so that the second lane layout runs)
 		a.route_giveup = gu && atoi(gu) > 0 ? (uint32_t)atoi(gu) : 1024u;
@@ -1085,6 +1096,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		ScanArgs b = a;
 		b.adaptive = 0, b.coop = 1, b.route = ANDI_LAYOUT_COOP;
 		b.qseg_start = q->c_qseg_start, b.seg2query = q->c_seg2query, b.total_segs = q->c_total_segs, b.seg = coop_seg;
+		b.reduce_threads = (longest_q + coop_seg - 1) / coop_seg <= 64 ? 64u : 0u;
 		p = (char *)(a.pair_class + pairs_all);
 		p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
 		carve(b, slots2);
@@ -1112,9 +1124,9 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			// handful of lane blocks (four wavefronts and their LDS on one CU at once) found no place until that kernel's
 			// tail and ended 0.2 ms after everything else --, the wavefront kernel where they are many (the tree-structured
 			// set, the C4 shape: 0.4 and 1.5 ms the other way round).  The host looks at the layout (one word).
-			e = hipMemcpyAsync(ctx->h_any_left + 1, a.pair_wave0 + pairs_all, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+			e = hipMemcpyAsync(ctx->h_any_left + 1, a.restitch_count + ANDI_LANE_WAVES, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
 			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-			const bool lanes_first = e == hipSuccess && (uint64_t)ctx->h_any_left[1] * 20 < max_waves;
+			const bool lanes_first = e == hipSuccess && (uint64_t)ctx->h_any_left[1] * 20 < ctx->h_any_left[1 + ANDI_ALL_WAVES - ANDI_LANE_WAVES];
 			if (e == hipSuccess) e = hipEventRecord(ctx->coop_fork, ctx->stream);
 			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->coop_stream, ctx->coop_fork, 0);
 			if (e == hipSuccess && lanes_first) e = andi_launch_scan_cold(a, ctx->stream);

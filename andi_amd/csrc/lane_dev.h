@@ -147,8 +147,12 @@ __device__ __forceinline__ LaneItem lane_item(const ScanArgs &a, uint32_t wave =
 			it.start = it.seg_in_q * a.seg;
 			it.end = it.start + a.seg < qlen ? it.start + a.seg : qlen;
 			it.valid = a.self[it.sub] != (int64_t)it.qidx;
-			// (a routed call's uniform layout is the wavefront kernel's: the pairs it kept)
-			if (a.route == ANDI_LAYOUT_COOP && (a.pair_class[it.sub * a.nq + it.qidx] & (ANDI_ROUTE_COOP | ANDI_ROUTE_LEFT)) != ANDI_ROUTE_COOP) it.valid = false;
+			if (a.route && it.valid) { // a routed call (scan.h): the pairs of this layout -- the wavefront kernel's, the lane scan's, the pairs handed back
+				const uint32_t cls = a.pair_class[it.sub * a.nq + it.qidx];
+				it.valid = a.route == ANDI_LAYOUT_COOP ? (cls & (ANDI_ROUTE_COOP | ANDI_ROUTE_LEFT)) == ANDI_ROUTE_COOP
+						 : a.route == ANDI_LAYOUT_LANES2 ? (cls & ANDI_ROUTE_L2) != 0
+														 : (cls & (ANDI_ROUTE_COOP | ANDI_ROUTE_L2)) == 0;
+			}
 		}
 		return it;
 	}

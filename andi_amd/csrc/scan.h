@@ -104,6 +104,8 @@ struct ScanArgs {
 	// Passes B and C run once per layout, each on its own pairs.
 	int route; // 0: no routing (every pair takes the call's one pass A); else the layout these arguments describe: ANDI_LAYOUT_*
 	uint32_t route_seg;           // the wavefront kernel's segment length in a routed call
+	uint32_t reduce_threads;      // pass C: threads of a pair's block (64 where no query has more than 64 segments, else the lane scan's block)
+	uint32_t route_all_few;       // small calls: where the lane scan's pairs would be few, the wavefront kernel takes every pair (k_pair_route)
 	uint32_t route_soft_match;    // mean sampled match from which a pair is better off with k_lane_quad if such pairs are many (k_pair_estimate)
 	uint32_t route_giveup;        // generic steps in one of its segments beyond which a wavefront hands its pair back (scan_coop.hip: COOP_TRIAL_G; ANDI_COOP_GIVEUP: tests)
 	unsigned long long *route_nt; // [3]: query nucleotides of the pairs whose pass A ran by wavefronts / by lanes, pairs handed back
@@ -153,6 +155,9 @@ static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at
 #define ANDI_LAYOUT_LANES2 2  /* the pairs pass A by wavefronts handed back */
 #define ANDI_LAYOUT_COOP 3    /* the wavefront kernel's pairs (one segment length) */
 #define ANDI_ROUTE_ANY_LEFT 11 /* restitch_count[this] of the wavefront kernel's layout: some pair was handed back */
+#define ANDI_ROUTE_MIN_QLEN 8192u /* queries shorter than this (and than a segment of the wavefront kernel) are the lane scan's: 1000 x 5 kbp 11.6 ms by wavefronts, 9.3 by lanes; 300 x 10 kbp 1.85 against 2.65 */
+#define ANDI_HARD_WAVES 9 /* restitch_count[this] during the layout: wavefronts of pairs the wavefront kernel is no candidate for (beside ANDI_SPARSE_WAVES, which includes the soft ones) */
+#define ANDI_LANE_WAVES 10 /* restitch_count[this] after the layout of a routed call: wavefronts of the pairs the lane scan keeps (k_pair_route) */
 #define ANDI_ALL_WAVES 15      /* restitch_count[this] during the layout: wavefronts of all pairs (beside ANDI_SPARSE_WAVES) */
 #define ANDI_QUAD_WAVES 13 /* restitch_count[this] during pass A: wavefronts on k_lane_quad's list */
 #define ANDI_SPARSE_WAVES 14 /* restitch_count[this] during pass A: wavefronts of pairs whose sampled mean match is below ANDI_SPARSE_MATCH */

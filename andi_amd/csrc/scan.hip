@@ -472,14 +472,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan_reduce(ScanArgs a) {
 	// every segment k >= 1 was stitched assuming it is entered in the state used_entry[k]: right iff the true chain
 	// left segment k - 1 in that state
 	bool ok = true;
-	for (uint32_t k = 1 + threadIdx.x; k < nseg; k += BLOCK)
+	for (uint32_t k = 1 + threadIdx.x; k < nseg; k += blockDim.x)
 		ok = ok && same_state(a.true_exit[row + k - 1], a.used_entry[row + k]);
 	const bool all_ok = __syncthreads_and(ok);
 	{ // the owned counts of all segments (a segment that turns out wrong below is taken out again)
 		uint32_t sum[16];
 #pragma unroll
 		for (int t = 0; t < 16; ++t) sum[t] = 0;
-		for (uint32_t k = threadIdx.x; k < nseg; k += BLOCK) {
+		for (uint32_t k = threadIdx.x; k < nseg; k += blockDim.x) {
 			const uint4 *o = (const uint4 *)(a.owned + (row + k) * 16);
 #pragma unroll
 			for (int t = 0; t < 4; ++t) {
@@ -604,8 +604,9 @@ hipError_t andi_launch_scan_stitch(const ScanArgs &a, hipStream_t st) {
 }
 
 hipError_t andi_launch_scan_reduce(const ScanArgs &a, hipStream_t st) {
-	dim3 grid(a.nq, a.nsub); // one block per pair
-	k_scan_reduce<<<grid, BLOCK, 0, st>>>(a);
+	dim3 grid(a.nq, a.nsub); // one block per pair (of one wavefront where no query has more than 64 segments: calls of
+	// thousands of short queries -- 90 000 blocks of four wavefronts took 0.7 ms to launch)
+	k_scan_reduce<<<grid, a.reduce_threads == 64 ? 64 : BLOCK, 0, st>>>(a);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }

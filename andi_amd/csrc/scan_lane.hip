@@ -31,29 +31,44 @@ namespace {
 // (A block of four wavefronts per pair: every one of them takes the 64 samples of the mean -- the same, so that all know
 // what the pair is a candidate for -- and a quarter of the further samples of a routed call: the kernel's time is the
 // chain of dependent probes of one wavefront, 185 us with one wavefront per pair.)
-constexpr uint32_t EST_WAVES = 4; // (calls of a few thousand pairs; one wavefront per pair beyond: the device is full either way)
-__global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
+[[maybe_unused]] constexpr uint32_t EST_WAVES = 4; // (calls of a few thousand pairs; one wavefront per pair beyond: the device is full either way)
+constexpr uint32_t EST_WAVES_FEW = 8; // (calls of up to 1024 pairs: a round of further samples per wavefront)
+// (Calls of more pairs than that, `many`: every wavefront of a block its own pair -- 90 000 blocks of one wavefront were
+// launched in 1.1 ms, whatever they sampled.)
+__global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a, bool many) {
 	__shared__ uint32_t s_shorts, s_runs;
-	const uint32_t est_waves = blockDim.x >> 6;
-	const uint32_t pair = blockIdx.x, wave = threadIdx.x >> 6;
-	const uint32_t sub = pair / a.nq, qidx = pair % a.nq, lane = threadIdx.x & 63u;
+	const uint32_t est_waves = many ? 1u : blockDim.x >> 6;
+	const uint32_t pair = many ? blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) : blockIdx.x, wave = many ? 0u : threadIdx.x >> 6;
+	const uint32_t lane = threadIdx.x & 63u;
+	if (pair >= a.nsub * a.nq) return; // (many)
+	const uint32_t sub = pair / a.nq, qidx = pair % a.nq;
+	const bool first = many ? lane == 0 : threadIdx.x == 0; // who writes the pair's results
 	if (a.self[sub] == (int64_t)qidx) {
-		if (threadIdx.x == 0) a.pair_class[pair] = 0, a.pair_waves[pair] = 0;
+		if (first) a.pair_class[pair] = 0, a.pair_waves[pair] = 0;
 		return;
 	}
-	if (threadIdx.x == 0) s_shorts = 0, s_runs = 0;
-	__syncthreads();
+	if (!many) { // (the same branch in every wavefront of the block)
+		if (threadIdx.x == 0) s_shorts = 0, s_runs = 0;
+		__syncthreads();
+	}
 	PairCtx c = make_ctx(a, sub, qidx);
-	const uint32_t p = (uint32_t)(((uint64_t)(2 * lane + 1) * c.qlen) >> 7);
+	// (routed calls, short queries: 32 or 16 samples -- with thousands of pairs of 10 ... 30 kbp the sampling was a
+	// third of the call, at the rate the device serves scattered requests at all)
+	const uint32_t nl_shift = !a.route || c.qlen >= 32768u ? 6u : c.qlen >= 16384u ? 5u : 4u, nl = 1u << nl_shift;
+	const uint32_t p = (uint32_t)(((uint64_t)(2 * lane + 1) * c.qlen) >> (nl_shift + 1));
 	LWin w;
 	w.q0 = EMPTY, w.dg = NO_DIAG;
 	// a pair whose mean is seg0 * 8 / factor gets the longest segments anyway: samples are cut at twice
 	// that (a long match is followed 32 symbols per round trip, and the wavefront waits for its longest)
-	const uint32_t cap = 16 * a.seg0 / (a.seg_factor ? a.seg_factor : 1) / 2 + 32;
-	const Probe r = lane_probe(c, p, w, cap);
+	// (a routed call with one segment length for its lanes asks only whether the mean is below ANDI_SPARSE_MATCH: three round trips)
+	const uint32_t cap = a.adaptive ? 16 * a.seg0 / (a.seg_factor ? a.seg_factor : 1) / 2 + 32 : 96u;
+	Probe r;
+	r.len = 0;
+	if (lane < nl) r = lane_probe(c, p, w, cap);
 	uint32_t sum = r.len < cap ? r.len : cap;
 #pragma unroll
 	for (int d = 32; d; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d);
+	sum <<= 6u - nl_shift; // (as of 64 samples)
 	// A pair whose matches are long on average may still spend most of its chain steps where it has none: 10 % of
 	// unrelated sequence (genomic islands: a step every 13 nucleotides there) are most of the steps of a pair with
 	// a mismatch every 500, and probing is what k_lane_quad is slow at (the realistic set: pass A 11.2 ms with
@@ -63,7 +78,8 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
 	bool islands = false;
 	const bool quad_cand = (sum >> 6) >= a.quad_min_match && (sum >> 6) < ANDI_ISLAND_MEAN_MAX && a.quad_min_match != 0;
 	// routed calls: would the pair suit pass A by wavefronts?  (one whole segment of that kernel's at least)
-	const bool coop_cand = a.route && (sum >> 6) < 512u && c.qlen >= a.route_seg; // (matches of 512 symbols and more on average: k_lane_quad's, always)
+	// (one whole segment of that kernel's at least, or a query of a few windows: with many short queries a wavefront's chain is a query)
+	const bool coop_cand = a.route && (sum >> 6) < 512u && c.qlen >= (a.route_seg < ANDI_ROUTE_MIN_QLEN ? a.route_seg : ANDI_ROUTE_MIN_QLEN); // (matches of 512 symbols and more on average: k_lane_quad's, always)
 	if (coop_cand) { // (wave-uniform)
 		// Unrelated stretches are contiguous: where a sample sees less than a threshold's worth of matching symbols, four
 		// more are taken, 128 symbols apart.  Five short ones in a row come about by chance at the fifth power of the rate of
@@ -76,11 +92,14 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
 		// (calls of thousands of pairs: 256 samples -- one wavefront per pair there, and the chain of its dependent probes is
 		// what the kernel takes: 0.77 -> 0.4 ms for the C4 shape's 24 680 pairs; 10 % of unrelated sequence still stand out
 		// by four standard deviations)
-		const uint32_t nrounds = est_waves > 1 ? 8u : 4u, nsamples = 64u * nrounds;
+		// (short queries: a sample per 2048 symbols at most -- the follow-ups of one span 640)
+		uint32_t nrounds = est_waves > 1 ? 8u : 4u;
+		while (nrounds > 1 && c.qlen < nrounds * (64u * 2048u)) nrounds >>= 1;
+		const uint32_t nsamples = nl * nrounds;
 		uint32_t shorts = 0, runs = 0;
 		for (uint32_t k = wave; k < nrounds; k += est_waves) {
-			const uint32_t pk = (uint32_t)(((uint64_t)(2 * nrounds * lane + 2 * k + 1) * c.qlen) / (128u * nrounds));
-			bool all_short = true;
+			const uint32_t pk = (uint32_t)(((uint64_t)(2 * nrounds * lane + 2 * k + 1) * c.qlen) / (2u * nl * nrounds));
+			bool all_short = lane < nl;
 			for (uint32_t j = 0; j < 5 && all_short; ++j) {
 				const uint32_t pj = pk + 128 * j;
 				LWin wk;
@@ -92,9 +111,11 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
 		}
 #pragma unroll
 		for (int d = 32; d; d >>= 1) shorts += (uint32_t)__shfl_xor((int)shorts, d), runs += (uint32_t)__shfl_xor((int)runs, d);
-		if (lane == 0) atomicAdd(&s_shorts, shorts), atomicAdd(&s_runs, runs);
-		__syncthreads(); // (coop_cand is the same in all four wavefronts: they took the same samples)
-		shorts = s_shorts, runs = s_runs;
+		if (!many) {
+			if (lane == 0) atomicAdd(&s_shorts, shorts), atomicAdd(&s_runs, runs);
+			__syncthreads(); // (coop_cand is the same in all wavefronts of the block: they took the same samples)
+			shorts = s_shorts, runs = s_runs;
+		}
 		// The rate f0 of short samples OUTSIDE unrelated stretches: from the short samples that did not turn into a run --
 		// f0 - f0^5 of the samples in homologous sequence, hardly any inside a stretch without homology (Newton on the lower
 		// branch; pairs beyond 6 % or so have no solution there and are taken for suspicious: the lane scan's anyway).
@@ -110,7 +131,7 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
 		}
 		const float f5 = f0 * f0 * f0 * f0 * f0, expect = ns * f5;
 		islands = (float)runs > expect + 3.f * sqrtf(expect * (1.f - f5)) + 3.f;
-	} else if (quad_cand) { // (wave-uniform; calls that are not routed, and the pairs with the longest matches)
+	} else if (quad_cand && nl == 64) { // (wave-uniform; calls that are not routed, and the pairs with the longest matches)
 		uint32_t shorts = r.len < c.thr ? 1u : 0u;
 		for (uint32_t k = 1; k < 4; ++k) {
 			const uint32_t pk = (uint32_t)(((uint64_t)(8 * lane + 2 * k + 1) * c.qlen) >> 9); // between the first samples
@@ -124,7 +145,7 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
 		const float expect = 256.f * (1.f - __expf(-(float)c.thr / (float)(sum >> 6)));
 		islands = (float)shorts > expect + 2.f * sqrtf(expect * (1.f - expect / 256.f)) + 2.f;
 	}
-	if (threadIdx.x == 0) {
+	if (first) {
 		const uint32_t want = (sum >> 6) * a.seg_factor; // mean match length * factor
 		uint32_t cls = 0;
 		while (cls < a.max_class && (a.seg0 << cls) < want) ++cls;
@@ -139,8 +160,6 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_pair_estimate(ScanArgs a) {
 		const bool quad = (sum >> 6) >= a.quad_min_match && !(islands && (sum >> 6) < ANDI_ISLAND_MEAN_MAX);
 		a.pair_class[pair] = (uint8_t)(cls | (quad ? 0x80u : 0u) | (coop_cand && !islands ? ANDI_ROUTE_COOP : 0u) | (soft ? ANDI_ROUTE_SOFT : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
-		atomicAdd(&a.restitch_count[ANDI_ALL_WAVES], (nseg + 63) / 64);
-		if (soft || !(coop_cand && !islands)) atomicAdd(&a.restitch_count[ANDI_SPARSE_WAVES], (nseg + 63) / 64); // wavefronts the lane scan would like
 	}
 }
 
@@ -196,16 +215,59 @@ __global__ __launch_bounds__(1024) void k_pair_offsets(ScanArgs a) {
 	}
 }
 
+// routed calls: the wavefronts of all pairs, of those the lane scan would like (not marked for the wavefront kernel, or
+// soft), and of those it gets whatever the others do -- what k_pair_route decides by.  (A sum per block: a million pairs
+// adding to three words one by one took 30 ms.)
+__global__ __launch_bounds__(1024) void k_pair_totals(ScanArgs a) {
+	__shared__ uint32_t s_sum[3];
+	const uint32_t P = a.nsub * a.nq, pair = blockIdx.x * 1024 + threadIdx.x;
+	if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+	__syncthreads();
+	uint32_t all = 0, sparse = 0, hard = 0;
+	if (pair < P) {
+		const uint32_t cls = a.pair_class[pair];
+		all = a.pair_waves[pair]; // (none for a query that is the subject itself)
+		hard = (cls & ANDI_ROUTE_COOP) ? 0u : all;
+		sparse = (cls & ANDI_ROUTE_SOFT) ? all : hard;
+	}
+#pragma unroll
+	for (int d = 32; d; d >>= 1) {
+		all += (uint32_t)__shfl_xor((int)all, d);
+		sparse += (uint32_t)__shfl_xor((int)sparse, d);
+		hard += (uint32_t)__shfl_xor((int)hard, d);
+	}
+	if ((threadIdx.x & 63u) == 0) atomicAdd(&s_sum[0], all), atomicAdd(&s_sum[1], sparse), atomicAdd(&s_sum[2], hard);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_sum[0]) atomicAdd(&a.restitch_count[ANDI_ALL_WAVES], s_sum[0]);
+		if (s_sum[1]) atomicAdd(&a.restitch_count[ANDI_SPARSE_WAVES], s_sum[1]);
+		if (s_sum[2]) atomicAdd(&a.restitch_count[ANDI_HARD_WAVES], s_sum[2]);
+	}
+}
+
 // routed calls: which pairs take pass A by wavefronts (they get no wavefronts in the lane layout)
-__global__ __launch_bounds__(256) void k_pair_route(ScanArgs a) {
-	const uint32_t P = a.nsub * a.nq, pair = blockIdx.x * 256 + threadIdx.x;
-	if (pair >= P) return;
+__device__ __forceinline__ uint32_t route_pair(const ScanArgs &a, uint32_t pair) {
 	uint32_t cls = a.pair_class[pair];
 	const bool lanes_few = 10 * a.restitch_count[ANDI_SPARSE_WAVES] <= a.restitch_count[ANDI_ALL_WAVES]; // (the lane scan's and those it would like)
 	if ((cls & ANDI_ROUTE_COOP) && (cls & ANDI_ROUTE_SOFT) && !lanes_few) cls &= ~ANDI_ROUTE_COOP;
 	cls &= ~ANDI_ROUTE_SOFT;
+	// Small calls (route_all_few): pass A by wavefronts takes a fraction of a millisecond, and a lane's chain over one
+	// segment as long as it ever does -- six pairs of 9900 left to the lane scan (100 x 30 kbp) made pass A 1.1 ms instead
+	// of 0.6.  Where the lane scan's pairs are that few, the wavefront kernel takes them all (and hands back what it must).
+	if (a.route_all_few && lanes_few && 20 * a.restitch_count[ANDI_HARD_WAVES] <= a.restitch_count[ANDI_ALL_WAVES] && a.self[pair / a.nq] != (int64_t)(pair % a.nq))
+		cls |= ANDI_ROUTE_COOP;
 	a.pair_class[pair] = (uint8_t)cls;
 	if (cls & ANDI_ROUTE_COOP) a.pair_waves[pair] = 0;
+	return a.pair_waves[pair];
+}
+
+__global__ __launch_bounds__(256) void k_pair_route(ScanArgs a) {
+	const uint32_t P = a.nsub * a.nq, pair = blockIdx.x * 256 + threadIdx.x;
+	uint32_t mine = 0; // wavefronts the pair keeps in the lane layout
+	if (pair < P) mine = route_pair(a, pair);
+#pragma unroll
+	for (int d = 32; d; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d);
+	if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&a.restitch_count[ANDI_LANE_WAVES], mine); // (the host looks: which kernel goes first)
 }
 
 // routed calls, after pass A: the pairs the wavefront kernel handed back get the wavefronts of the second lane layout
@@ -227,12 +289,25 @@ __global__ __launch_bounds__(256) void k_pair_leftover(ScanArgs a) {
 // routed calls: who took what (the context's counters, read with the timings)
 __global__ __launch_bounds__(256) void k_route_count(ScanArgs a) {
 	const uint32_t P = a.nsub * a.nq, pair = blockIdx.x * 256 + threadIdx.x;
-	if (pair >= P) return;
-	const uint32_t sub = pair / a.nq, qidx = pair % a.nq;
-	if (a.self[sub] == (int64_t)qidx) return;
-	const uint32_t cls = a.pair_class[pair];
-	atomicAdd(&a.route_nt[(cls & ANDI_ROUTE_COOP) ? 0 : 1], (unsigned long long)a.qlen[qidx]);
-	if (cls & ANDI_ROUTE_L2) atomicAdd(&a.route_nt[2], 1ull);
+	unsigned long long nt[2] = {0, 0};
+	uint32_t back = 0;
+	if (pair < P && a.self[pair / a.nq] != (int64_t)(pair % a.nq)) {
+		const uint32_t cls = a.pair_class[pair];
+		nt[(cls & ANDI_ROUTE_COOP) ? 0 : 1] = a.qlen[pair % a.nq];
+		back = (cls & ANDI_ROUTE_L2) ? 1u : 0u;
+	}
+	// (a sum per wavefront: 90 000 pairs adding to two words one by one took a millisecond)
+#pragma unroll
+	for (int d = 32; d; d >>= 1) {
+		nt[0] += (unsigned long long)__shfl_xor((long long)nt[0], d);
+		nt[1] += (unsigned long long)__shfl_xor((long long)nt[1], d);
+		back += (uint32_t)__shfl_xor((int)back, d);
+	}
+	if ((threadIdx.x & 63u) == 0) {
+		if (nt[0]) atomicAdd(&a.route_nt[0], nt[0]);
+		if (nt[1]) atomicAdd(&a.route_nt[1], nt[1]);
+		if (back) atomicAdd(&a.route_nt[2], (unsigned long long)back);
+	}
 }
 
 // ------------------------------------------------------------------ pass A
@@ -1077,14 +1152,17 @@ static hipError_t pair_offsets(const ScanArgs &a, hipStream_t st) {
 
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
 	const uint32_t P = a.nsub * a.nq;
-	(void)hipMemsetAsync(a.restitch_count + ANDI_QUAD_WAVES, 0, 3 * sizeof(uint32_t), st); // k_lane_quad's list is empty, no wavefronts counted
-	k_pair_estimate<<<P, P <= 4096 ? 64 * EST_WAVES : 64, 0, st>>>(a);
+	(void)hipMemsetAsync(a.restitch_count + ANDI_HARD_WAVES, 0, 7 * sizeof(uint32_t), st); // k_lane_quad's list is empty, no wavefronts counted
+	if (P <= 4096) k_pair_estimate<<<P, P <= 1024 ? 64 * EST_WAVES_FEW : 64 * EST_WAVES, 0, st>>>(a, false);
+	else k_pair_estimate<<<(P + 3) / 4, 256, 0, st>>>(a, true);
 	CHECK_LAUNCH();
 	if (a.route) {
+		k_pair_totals<<<(P + 1023) / 1024, 1024, 0, st>>>(a);
+		CHECK_LAUNCH();
 		k_pair_route<<<(P + 255) / 256, 256, 0, st>>>(a);
 		CHECK_LAUNCH();
 	}
-	return pair_offsets(a, st);
+	return a.adaptive ? pair_offsets(a, st) : hipSuccess; // (a routed call with one segment length for its lanes: the marks only)
 }
 
 hipError_t andi_launch_pair_leftover(const ScanArgs &a2, hipStream_t st) {
@@ -1092,7 +1170,7 @@ hipError_t andi_launch_pair_leftover(const ScanArgs &a2, hipStream_t st) {
 	(void)hipMemsetAsync(a2.restitch_count + ANDI_QUAD_WAVES, 0, 3 * sizeof(uint32_t), st);
 	k_pair_leftover<<<(P + 255) / 256, 256, 0, st>>>(a2);
 	CHECK_LAUNCH();
-	return pair_offsets(a2, st);
+	return a2.adaptive ? pair_offsets(a2, st) : hipSuccess;
 }
 
 hipError_t andi_launch_route_count(const ScanArgs &a, hipStream_t st) {

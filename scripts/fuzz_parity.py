@@ -52,10 +52,12 @@ def main():
         model = int(rng.choice([0, 1, 1, 2, 3, 4]))
         want = orc.dist_matrix(seqs, model=model, threads=0)
         for _ in range(3):
-            segment = int(rng.choice([0, 0, 64, 100, 300, 700, 2048, 5000, 40000]))
+            segment = int(rng.choice([0, 0, 0, 0, 64, 100, 300, 700, 2048, 5000, 40000]))  # 0: the engine's choice -- pass A routed per pair from 2^18 symbols
             env = {}
             if rng.random() < 0.3:
                 env["ANDI_COOP"] = str(rng.choice([2, 4, 8]))
+            elif rng.random() < 0.3:  # routed calls: wavefronts hand their pairs back early (the second lane layout runs)
+                env["ANDI_COOP_GIVEUP"] = str(rng.choice([4, 48]))
             if rng.random() < 0.15:
                 env["ANDI_UNIFORM_SEGMENTS"] = "1"
             if rng.random() < 0.15:
@@ -82,8 +84,9 @@ def main():
                 lib.reload_knobs()
             ok = bool((got == want).all())
             cases += 1
-            print("case %4d %-9s n=%d len=%-7d model=%d segment=%-5d sa=%-6s %-40s fixups=%-5d %s" % (
+            print("case %4d %-9s n=%d len=%-7d model=%d segment=%-5d sa=%-6s %-40s fixups=%-5d %s %s" % (
                 cases, kind, len(seqs), len(seqs[0]), model, segment, sa, " ".join("%s=%s" % kv for kv in env.items()), t["fixups"],
+                "routed (%s layout, %d%% by wavefronts, %d handed back)" % ("per-pair" if t["adaptive_calls"] else "uniform", 100 * t["coop_query_nt"] // max(t["coop_query_nt"] + t["lane_query_nt"], 1), t["coop_fallbacks"]) if t["routed_calls"] else "",
                 "ok" if ok else "DIFFERENT"), flush=True)
             if not ok:
                 bad = np.argwhere((got != want).any(axis=2))

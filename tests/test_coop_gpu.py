@@ -139,6 +139,50 @@ def test_pairs_handed_back_take_the_second_lane_layout():
     assert (got == lane).all()
 
 
+def test_small_calls_are_routed_too():
+    """Small calls are routed as well (from 2^18 query symbols x subjects), on shorter segments of the wavefront kernel:
+    BASELINE's configs[0] shape (3 x 1 Mbp: per-pair segments for the lanes), a call of many short genomes (one segment
+    length for the lanes: the routing marks alone decide what a lane of that layout does), the same with structured
+    genomes and an early hand-back (the second lane layout in its one-segment-length form), ragged lengths around the
+    shortest query the wavefront kernel takes; calls of queries below that length keep the lane scan.  All against the
+    oracle, every model the kernel counts differently for."""
+    os.environ.pop("ANDI_COOP", None)
+    star, _ = synth.genome_set(3, 1_000_000, 0.0004, 0.03, seed=3)
+    got, t = _rows(star, {})
+    assert t["routed_calls"] == 1 and t["adaptive_calls"] == 1 and t["coop_query_nt"] == 6_000_000, t
+    assert (got == orc.dist_matrix(star, model=orc.M_JC, threads=3)).all()
+    many, _ = synth.genome_set(60, 20_000, 0.001, 0.04, seed=4)
+    want = orc.dist_matrix(many, model=orc.M_JC, threads=4)
+    got, t = _rows(many, {})
+    assert t["routed_calls"] == 1 and t["uniform_calls"] == 1 and t["coop_query_nt"] > 0, t
+    assert (got == want).all()
+    lane, t0 = _rows(many, {"ANDI_COOP": "0"})
+    assert t0["routed_calls"] == 0 and (lane == want).all()
+    real, _ = synth.realistic_set(40, 30_000, 0.002, 0.03, seed=6, novel_fraction=0.02)
+    want = orc.dist_matrix(real, model=orc.M_JC, threads=4)
+    got, t = _rows(real, {})
+    assert t["routed_calls"] == 1 and (got == want).all(), t
+    got, t = _rows(real, {"ANDI_COOP_GIVEUP": "4"})
+    assert t["routed_calls"] == 1 and t["uniform_calls"] == 1 and t["coop_fallbacks"] > 0, t
+    assert (got == want).all()
+    rng = np.random.default_rng(8)
+    base = synth.base_codes(40_000, 9)
+    ragged = []
+    for k in range(50):  # 2 ... 40 kbp: some below the shortest query the wavefront kernel takes, joined contigs among them
+        codes = synth.mutate_codes(base, float(rng.uniform(0.001, 0.05)), 200 + k)
+        b = synth.to_bytes(codes[: int(rng.integers(2_000, 40_000))])
+        ragged.append(synth.join_contigs(b, 3, seed=k) if k % 7 == 0 else b)
+    for model in (orc.M_RAW, orc.M_LOGDET):
+        want = orc.dist_matrix(ragged, model=model, threads=4)
+        with knobs(COOP=None):
+            got = andi_amd.dist_matrix(ragged, model=model)
+        assert (got == want).all(), model
+    short, _ = synth.genome_set(150, 3_000, 0.001, 0.04, seed=5)
+    got, t = _rows(short, {})
+    assert t["routed_calls"] == 0, t
+    assert (got == orc.dist_matrix(short, model=orc.M_JC, threads=4)).all()
+
+
 def test_mixed_call_clean_close_and_structured_pairs_against_the_oracle():
     """ONE call whose pairs are of every kind -- clean pairs a few percent apart (the wavefront kernel's), pairs a few
     substitutions apart (k_lane_quad's), pairs with unrelated stretches, repeats and indels (k_lane_cold's, some of them
