@@ -371,7 +371,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload_name(args.set, G, S, args.length, args.dlo, args.dhi, args.seed, world),
                        "genomes": G, "subjects": S, "length": args.length, "model": "JC", "pairs": pairs_total,
-                       "segment": args.segment or ("auto (pass A routed per pair: by wavefronts on segments of 32768 ... 524288 symbols, by lanes on segments chosen per pair, 2048 ... 16384)" if tm["routed_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
+                       "segment": args.segment or ("auto (pass A routed per pair: by wavefronts on segments of 32768 ... 524288 symbols (shorter in small calls), by lanes on segments chosen per pair, 2048 ... 16384)" if tm["routed_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "measured_copy_GBps": copy_gbps,
