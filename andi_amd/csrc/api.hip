@@ -1080,10 +1080,14 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	uint32_t longest_q = 0;
 	for (size_t i = 0; i < q->nq; ++i) longest_q = std::max(longest_q, (uint32_t)q->len[i]);
 	a.reduce_threads = (longest_q + (a.adaptive ? seg0 : segment) - 1) / (a.adaptive ? seg0 : segment) <= 64 ? 64u : 0u;
-	a.route_all_few = q->total_nt * (uint64_t)nsub < ANDI_ROUTE_SMALL_NT ? 1u : 0u;
+	{
+		const char *rs = andi_knob(KNOB_ROUTE_SMALL); // (experiments: log2 of the size below which a call is small)
+		const uint64_t small_nt = rs && atoi(rs) > 0 && atoi(rs) < 63 ? 1ull << atoi(rs) : ANDI_ROUTE_SMALL_NT;
+		a.route_all_few = q->total_nt * (uint64_t)nsub < small_nt ? 1u : 0u;
+	}
 	{
 		const char *gu = andi_knob(KNOB_COOP_GIVEUP); // (tests: hand pairs back early, so that the second lane layout runs)
-		a.route_giveup = gu && atoi(gu) > 0 ? (uint32_t)atoi(gu) : 1024u;
+		a.route_giveup = gu && atoi(gu) > 0 ? (uint32_t)atoi(gu) : a.route_all_few ? 256u : 1024u; // (small calls route pairs the sampling cannot judge: a lower limit)
 		const char *sm = andi_knob(KNOB_ROUTE_SOFT); // (experiments)
 		a.route_soft_match = sm && atoi(sm) > 0 ? (uint32_t)atoi(sm) : 512u; // (128 = k_lane_quad's class: tree-structured set 38.1 -> 39.4 % of the roofline at 512, C3-like 45.6 -> 48.1 %, C4 shape the same)
 	}

@@ -150,6 +150,7 @@ static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at
 #define ANDI_ROUTE_COOP 0x40u /* pair_class: the pair takes pass A by wavefronts (routed calls) */
 #define ANDI_ROUTE_LEFT 0x20u /* ... which handed it back */
 #define ANDI_ROUTE_SOFT 0x10u /* (k_pair_estimate to k_pair_route) the lane scan is better at it, if such pairs are more than a few */
+#define ANDI_ROUTE_GUESS 0x04u /* (k_pair_estimate to k_pair_route, small calls) marked for the wavefront kernel although the sampling cannot judge the pair: not where the call has pairs with unrelated stretches */
 #define ANDI_ROUTE_L2 0x08u   /* a pair handed back: in the second lane layout */
 #define ANDI_LAYOUT_LANES 1   /* ScanArgs.route: the lane scan's pairs */
 #define ANDI_LAYOUT_LANES2 2  /* the pairs pass A by wavefronts handed back */
@@ -157,6 +158,7 @@ static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at
 #define ANDI_ROUTE_ANY_LEFT 11 /* restitch_count[this] of the wavefront kernel's layout: some pair was handed back */
 #define ANDI_ROUTE_MIN_QLEN 8192u /* queries shorter than this (and than a segment of the wavefront kernel) are the lane scan's: 1000 x 5 kbp 11.6 ms by wavefronts, 9.3 by lanes; 300 x 10 kbp 1.85 against 2.65 */
 #define ANDI_HARD_WAVES 9 /* restitch_count[this] during the layout: wavefronts of pairs the wavefront kernel is no candidate for (beside ANDI_SPARSE_WAVES, which includes the soft ones) */
+#define ANDI_ISLAND_WAVES 11 /* restitch_count[this] of the lane layout during the layout: wavefronts of pairs in which the sampling saw unrelated stretches (ANDI_ROUTE_LEFT is their mark until k_pair_route) */
 #define ANDI_LANE_WAVES 10 /* restitch_count[this] after the layout of a routed call: wavefronts of the pairs the lane scan keeps (k_pair_route) */
 #define ANDI_ALL_WAVES 15      /* restitch_count[this] during the layout: wavefronts of all pairs (beside ANDI_SPARSE_WAVES) */
 #define ANDI_QUAD_WAVES 13 /* restitch_count[this] during pass A: wavefronts on k_lane_quad's list */

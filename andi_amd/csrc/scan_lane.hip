@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 	// such pairs in k_lane_quad, 10.6 ms without).  So a candidate is sampled at 192 more positions, and goes to
 	// k_lane_quad only if its short matches are no more than its mean explains (matches end at random: a fraction
 	// 1 - exp(-threshold / mean) of the positions sees less than the threshold), within two standard deviations.
-	bool islands = false;
+	bool islands = false, guess = false;
 	const bool quad_cand = (sum >> 6) >= a.quad_min_match && (sum >> 6) < ANDI_ISLAND_MEAN_MAX && a.quad_min_match != 0;
 	// routed calls: would the pair suit pass A by wavefronts?  (one whole segment of that kernel's at least)
 	// (one whole segment of that kernel's at least, or a query of a few windows: with many short queries a wavefront's chain is a query)
@@ -131,6 +131,18 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 		}
 		const float f5 = f0 * f0 * f0 * f0 * f0, expect = ns * f5;
 		islands = (float)runs > expect + 3.f * sqrtf(expect * (1.f - f5)) + 3.f;
+		// (small calls: pairs so far apart that nearly every sample is short -- runs of five tell nothing there -- are the
+		// wavefront kernel's: what it hands back costs a small call less than the lanes' chains cost every such pair)
+		// (... and so are the pairs near the top of f0 - f0^5, 4 ... 7 % apart, where the rate has no well-conditioned solution:
+		// nine clean pairs of ninety 6 % apart were suspected and made pass A of 10 x 1 Mbp 1.65 instead of 0.6 ms)
+		// (Unless the runs exceed even what the rate of ALL short samples explains -- an upper bound of f0 that the stretches
+		// themselves raise, good enough up to 7 % or so: 12 x 1 Mbp of structured genomes went by wavefronts without it,
+		// 7.3 ms per call against 4.0; what passes both is left to the kernel's own limit of generic steps.)
+		if (a.route_all_few && ((sum >> 6) < ANDI_SPARSE_MATCH || (float)(shorts - runs) >= 0.45f * ns)) {
+			const float fa = (float)shorts / ns, fa5 = fa * fa * fa * fa * fa, most = ns * fa5;
+			islands = (float)runs > most + 3.f * sqrtf(most * (1.f - fa5)) + 3.f;
+			guess = !islands; // (k_pair_route: only in calls whose other pairs show no unrelated stretches either)
+		}
 	} else if (quad_cand && nl == 64) { // (wave-uniform; calls that are not routed, and the pairs with the longest matches)
 		uint32_t shorts = r.len < c.thr ? 1u : 0u;
 		for (uint32_t k = 1; k < 4; ++k) {
@@ -158,7 +170,8 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 		// the same way at first: the wavefront kernel is the faster one for them, route_soft_match.)
 		const bool soft = (sum >> 6) < ANDI_SPARSE_MATCH || (sum >> 6) >= a.route_soft_match;
 		const bool quad = (sum >> 6) >= a.quad_min_match && !(islands && (sum >> 6) < ANDI_ISLAND_MEAN_MAX);
-		a.pair_class[pair] = (uint8_t)(cls | (quad ? 0x80u : 0u) | (coop_cand && !islands ? ANDI_ROUTE_COOP : 0u) | (soft ? ANDI_ROUTE_SOFT : 0u));
+		a.pair_class[pair] = (uint8_t)(cls | (quad ? 0x80u : 0u) | (coop_cand && !islands ? ANDI_ROUTE_COOP : 0u) | (soft ? ANDI_ROUTE_SOFT : 0u) |
+										 (coop_cand && islands ? ANDI_ROUTE_LEFT : 0u) | (coop_cand && guess ? ANDI_ROUTE_GUESS : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
 	}
 }
@@ -219,29 +232,32 @@ __global__ __launch_bounds__(1024) void k_pair_offsets(ScanArgs a) {
 // soft), and of those it gets whatever the others do -- what k_pair_route decides by.  (A sum per block: a million pairs
 // adding to three words one by one took 30 ms.)
 __global__ __launch_bounds__(1024) void k_pair_totals(ScanArgs a) {
-	__shared__ uint32_t s_sum[3];
+	__shared__ uint32_t s_sum[4];
 	const uint32_t P = a.nsub * a.nq, pair = blockIdx.x * 1024 + threadIdx.x;
-	if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+	if (threadIdx.x < 4) s_sum[threadIdx.x] = 0;
 	__syncthreads();
-	uint32_t all = 0, sparse = 0, hard = 0;
+	uint32_t all = 0, sparse = 0, hard = 0, isl = 0;
 	if (pair < P) {
 		const uint32_t cls = a.pair_class[pair];
 		all = a.pair_waves[pair]; // (none for a query that is the subject itself)
 		hard = (cls & ANDI_ROUTE_COOP) ? 0u : all;
 		sparse = (cls & ANDI_ROUTE_SOFT) ? all : hard;
+		isl = (cls & ANDI_ROUTE_LEFT) ? all : 0u; // (until k_pair_route: unrelated stretches seen)
 	}
 #pragma unroll
 	for (int d = 32; d; d >>= 1) {
 		all += (uint32_t)__shfl_xor((int)all, d);
 		sparse += (uint32_t)__shfl_xor((int)sparse, d);
 		hard += (uint32_t)__shfl_xor((int)hard, d);
+		isl += (uint32_t)__shfl_xor((int)isl, d);
 	}
-	if ((threadIdx.x & 63u) == 0) atomicAdd(&s_sum[0], all), atomicAdd(&s_sum[1], sparse), atomicAdd(&s_sum[2], hard);
+	if ((threadIdx.x & 63u) == 0) atomicAdd(&s_sum[0], all), atomicAdd(&s_sum[1], sparse), atomicAdd(&s_sum[2], hard), atomicAdd(&s_sum[3], isl);
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		if (s_sum[0]) atomicAdd(&a.restitch_count[ANDI_ALL_WAVES], s_sum[0]);
 		if (s_sum[1]) atomicAdd(&a.restitch_count[ANDI_SPARSE_WAVES], s_sum[1]);
 		if (s_sum[2]) atomicAdd(&a.restitch_count[ANDI_HARD_WAVES], s_sum[2]);
+		if (s_sum[3]) atomicAdd(&a.restitch_count[ANDI_ISLAND_WAVES], s_sum[3]);
 	}
 }
 
@@ -249,12 +265,18 @@ __global__ __launch_bounds__(1024) void k_pair_totals(ScanArgs a) {
 __device__ __forceinline__ uint32_t route_pair(const ScanArgs &a, uint32_t pair) {
 	uint32_t cls = a.pair_class[pair];
 	const bool lanes_few = 10 * a.restitch_count[ANDI_SPARSE_WAVES] <= a.restitch_count[ANDI_ALL_WAVES]; // (the lane scan's and those it would like)
-	if ((cls & ANDI_ROUTE_COOP) && (cls & ANDI_ROUTE_SOFT) && !lanes_few) cls &= ~ANDI_ROUTE_COOP;
-	cls &= ~ANDI_ROUTE_SOFT;
+	// (small calls: the soft pairs are the wavefront kernel's as well -- 3 x 1 Mbp 10 % apart, BASELINE's configs[0]: pass A
+	// 0.34 ms by wavefronts, 2.0 ms by lanes, whose chains take a segment's few hundred steps one after the other)
+	if ((cls & ANDI_ROUTE_COOP) && (cls & ANDI_ROUTE_SOFT) && !lanes_few && !a.route_all_few) cls &= ~ANDI_ROUTE_COOP;
+	// (small calls: the pairs the sampling could not judge stay with the lane scan where a twentieth of the call shows
+	// unrelated stretches -- structured genomes: 12 x 1 Mbp took 5.4 ms with such pairs tried by wavefronts and handed
+	// back, 3.9 ms by lanes)
+	if ((cls & ANDI_ROUTE_GUESS) && 20 * a.restitch_count[ANDI_ISLAND_WAVES] > a.restitch_count[ANDI_ALL_WAVES]) cls &= ~ANDI_ROUTE_COOP;
+	cls &= ~(ANDI_ROUTE_SOFT | ANDI_ROUTE_LEFT | ANDI_ROUTE_GUESS);
 	// Small calls (route_all_few): pass A by wavefronts takes a fraction of a millisecond, and a lane's chain over one
 	// segment as long as it ever does -- six pairs of 9900 left to the lane scan (100 x 30 kbp) made pass A 1.1 ms instead
 	// of 0.6.  Where the lane scan's pairs are that few, the wavefront kernel takes them all (and hands back what it must).
-	if (a.route_all_few && lanes_few && 20 * a.restitch_count[ANDI_HARD_WAVES] <= a.restitch_count[ANDI_ALL_WAVES] && a.self[pair / a.nq] != (int64_t)(pair % a.nq))
+	if (a.route_all_few && 20 * a.restitch_count[ANDI_HARD_WAVES] <= a.restitch_count[ANDI_ALL_WAVES] && a.self[pair / a.nq] != (int64_t)(pair % a.nq))
 		cls |= ANDI_ROUTE_COOP;
 	a.pair_class[pair] = (uint8_t)cls;
 	if (cls & ANDI_ROUTE_COOP) a.pair_waves[pair] = 0;

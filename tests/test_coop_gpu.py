@@ -151,6 +151,10 @@ def test_small_calls_are_routed_too():
     got, t = _rows(star, {})
     assert t["routed_calls"] == 1 and t["adaptive_calls"] == 1 and t["coop_query_nt"] == 6_000_000, t
     assert (got == orc.dist_matrix(star, model=orc.M_JC, threads=3)).all()
+    far, _ = synth.genome_set(3, 1_000_000, 0.05, 0.05, seed=13)  # configs[0] itself: pairs 10 % apart -- the sampling cannot judge them
+    got, t = _rows(far, {})
+    assert t["routed_calls"] == 1 and t["coop_query_nt"] == 6_000_000 and t["coop_fallbacks"] == 0, t
+    assert (got == orc.dist_matrix(far, model=orc.M_JC, threads=3)).all()
     many, _ = synth.genome_set(60, 20_000, 0.001, 0.04, seed=4)
     want = orc.dist_matrix(many, model=orc.M_JC, threads=4)
     got, t = _rows(many, {})
