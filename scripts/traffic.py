@@ -11,19 +11,26 @@ import sys
 summary, bench, kept_as = sys.argv[1:4]
 line = json.loads(open(bench).read().strip().splitlines()[-1])
 kernel = line["roofline"]["kernel"]
-fetch = write = None
+# a routed call's pass A ("k_coop_cold+lanes") is the wavefront kernel beside the lane scan's: their counters are added
+parts = ["k_coop_cold", "k_lane_cold", "k_lane_quad"] if "+lanes" in kernel else [kernel]
+fetch = write = 0.0
+seen = []
 name = None
 for ln in open(summary):
     if ln.startswith("=="):
         name = ln[2:].strip()
         continue
-    if name and kernel in name:
+    if name and any(p in name for p in parts):
         m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", ln)
         if m:
             if m.group(1) == "FETCH_SIZE":
-                fetch = float(m.group(2))
+                fetch += float(m.group(2))
             else:
-                write = float(m.group(2))
+                write += float(m.group(2))
+            if name not in seen:
+                seen.append(name)
+if not seen:
+    sys.exit("traffic.py: no FETCH_SIZE / WRITE_SIZE of %s in %s" % (kernel, summary))
 raw = (fetch + write) * 1024.0
 stream = line["roofline"]["algorithmic_bytes_per_launch"] / 2.0 if "coop" in kernel else 0.0  # 1 B per query nt
 cfg = line["config"]
@@ -32,5 +39,5 @@ print(json.dumps({
     "_note": "HBM-side bytes per launch of pass A from rocprofv3 --pmc (separate passes for FETCH_SIZE and WRITE_SIZE; KiB * 1024), "
              "collected with scripts/pmc.sh on MI355X by scripts/evidence.sh; correction per MI355X_MICROARCH.md (see scripts/traffic.py)",
     key: {"hbm_bytes_per_launch": raw + stream / 2.0, "raw_bytes": raw, "kernel": kernel,
-          "source": "%s: FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB" % (kept_as, fetch, write),
+          "source": "%s: FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB (%s)" % (kept_as, fetch, write, " + ".join(seen)),
           "correction": "+ half of the coalesced window stream (%.2f GB per launch)" % (stream / 1e9) if stream else "none"}}, indent=1))
