@@ -79,6 +79,7 @@ const char *andi_knob(AndiKnob k) {
 // need (whole wavefronts per pair) stays a fraction of the device's memory
 #define ANDI_ADAPTIVE_MAX_PAIRS (1u << 22)
 #define ANDI_ROUTE_MIN_NT (1u << 18) /* query symbols x subjects from which pass A of a call is routed per pair */
+#define ANDI_ROUTE_TINY_NT (1u << 25) /* ... below which it is not routed but takes pass A by wavefronts for every pair */
 #define ANDI_ROUTE_SMALL_NT (1ull << 30) /* ... below which pass A by wavefronts takes a millisecond or less: a few pairs left to the lane scan would take longer (k_pair_route) */
 // scratch per (subject, segment): three states, two count vectors, the marks, the exit position, a list slot, a published anchor
 #define ANDI_SLOT_BYTES (3 * sizeof(ChainState) + 2 * 16 * sizeof(uint32_t) + ANDI_COLD_MARKS * sizeof(ColdMark) + 4 + 8 + 8)
@@ -889,7 +890,16 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	int coop_ok = coop_mode != 0 && !andi_knob(KNOB_FORCE_REFERENCE);
 	for (size_t s = 0; s < nsub && coop_ok; ++s)
 		if (!subjects[s] || subjects[s]->thr < 2 || subjects[s]->thr > 30) coop_ok = 0;
-	const int coop = coop_ok && coop_mode > 0;
+	const uint64_t call_nt = q->total_nt * (uint64_t)nsub;
+	// TINY calls (less than two rounds of wavefronts on 2048-symbol segments): that kernel for every pair, without the
+	// sampling -- whatever a pair is like, a wavefront's chain over 2048 symbols is no longer than a lane's over 4096, and
+	// the device has the wavefronts to spare (structured genomes 3 x 1 Mbp ... 5 x 1.3 Mbp: 2.1 ... 3.3 ms by wavefronts,
+	// 2.65 ... 3.4 by lanes; clean ones 3 x 1 Mbp: 0.34 against 0.54 routed, 0.96 by lanes)
+	uint64_t tiny_nt = ANDI_ROUTE_TINY_NT;
+	if (const char *rt = andi_knob(KNOB_ROUTE_TINY)) // (tests, experiments: log2 of that size; 1: no call is tiny, small ones are routed)
+		if (atoi(rt) > 0 && atoi(rt) < 63) tiny_nt = 1ull << atoi(rt);
+	bool tiny = coop_ok && coop_mode < 0 && segment == 0 && call_nt >= ANDI_ROUTE_MIN_NT && call_nt < tiny_nt &&
+				!andi_knob(KNOB_UNIFORM_SEGMENTS) && !andi_knob(KNOB_FORCE_ADAPTIVE);
 	// A wavefront needs far fewer chains in flight than a lane, and every segment costs it a cold start of a dozen
 	// dependent round trips: segments as long as leave the device four rounds of wavefronts (24576), 32768 ... 524288
 	// symbols (measured: bench set 5.57 / 5.39 / 5.31 / 5.34 ms at 32768 / 65536 / 131072 / 262144, C4 shape 38.6 / 33.5 /
@@ -904,14 +914,16 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		if (atoi(cs) >= 64) coop_seg = (uint32_t)atoi(cs);
 	// (the smallest calls -- a few launches' worth of work -- keep the lane scan: routing costs them the sampling kernel
 	// and two looks of the host at the device)
-	bool routed = coop_ok && coop_mode < 0 && segment == 0 && q->total_nt * (uint64_t)nsub >= ANDI_ROUTE_MIN_NT &&
+	bool routed = coop_ok && coop_mode < 0 && segment == 0 && call_nt >= ANDI_ROUTE_MIN_NT &&
 				  nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS && !andi_knob(KNOB_UNIFORM_SEGMENTS) && !andi_knob(KNOB_FORCE_ADAPTIVE);
-	if (routed) { // (queries shorter than the wavefront kernel takes -- k_pair_estimate -- are the lane scan's: where they are most of the call, all of it)
+	if (routed || tiny) { // (queries shorter than the wavefront kernel takes -- k_pair_estimate -- are the lane scan's: where they are most of the call, all of it)
 		uint64_t cand_nt = 0;
 		for (size_t i = 0; i < q->nq; ++i)
 			if (q->len[i] >= std::min(coop_seg, ANDI_ROUTE_MIN_QLEN)) cand_nt += q->len[i];
-		if (2 * cand_nt < q->total_nt) routed = false;
+		if (2 * cand_nt < q->total_nt) routed = tiny = false;
 	}
+	if (tiny) routed = false;
+	const int coop = coop_ok && (coop_mode > 0 || tiny);
 	const bool want_adaptive = !coop && segment == 0 && nsub * q->nq <= ANDI_ADAPTIVE_MAX_PAIRS &&
 							   !andi_knob(KNOB_UNIFORM_SEGMENTS);
 	if (segment == 0 && coop) segment = coop_seg;

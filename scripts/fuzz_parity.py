@@ -56,8 +56,11 @@ def main():
             env = {}
             if rng.random() < 0.3:
                 env["ANDI_COOP"] = str(rng.choice([2, 4, 8]))
-            elif rng.random() < 0.3:  # routed calls: wavefronts hand their pairs back early (the second lane layout runs)
-                env["ANDI_COOP_GIVEUP"] = str(rng.choice([4, 48]))
+            else:
+                if rng.random() < 0.6:  # no call is tiny: calls of this size are routed per pair (else: the wavefront kernel for every pair)
+                    env["ANDI_ROUTE_TINY"] = "1"
+                    if rng.random() < 0.4:  # routed calls: wavefronts hand their pairs back early (the second lane layout runs)
+                        env["ANDI_COOP_GIVEUP"] = str(rng.choice([4, 48]))
             if rng.random() < 0.15:
                 env["ANDI_UNIFORM_SEGMENTS"] = "1"
             if rng.random() < 0.15:
@@ -86,7 +89,7 @@ def main():
             cases += 1
             print("case %4d %-9s n=%d len=%-7d model=%d segment=%-5d sa=%-6s %-40s fixups=%-5d %s %s" % (
                 cases, kind, len(seqs), len(seqs[0]), model, segment, sa, " ".join("%s=%s" % kv for kv in env.items()), t["fixups"],
-                "routed (%s layout, %d%% by wavefronts, %d handed back)" % ("per-pair" if t["adaptive_calls"] else "uniform", 100 * t["coop_query_nt"] // max(t["coop_query_nt"] + t["lane_query_nt"], 1), t["coop_fallbacks"]) if t["routed_calls"] else "",
+                "routed (%s layout, %d%% by wavefronts, %d handed back)" % ("per-pair" if t["adaptive_calls"] else "uniform", 100 * t["coop_query_nt"] // max(t["coop_query_nt"] + t["lane_query_nt"], 1), t["coop_fallbacks"]) if t["routed_calls"] else "by wavefronts" if t["coop_calls"] else "",
                 "ok" if ok else "DIFFERENT"), flush=True)
             if not ok:
                 bad = np.argwhere((got != want).any(axis=2))

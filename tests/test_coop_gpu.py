@@ -140,7 +140,8 @@ def test_pairs_handed_back_take_the_second_lane_layout():
 
 
 def test_small_calls_are_routed_too():
-    """Small calls are routed as well (from 2^18 query symbols x subjects), on shorter segments of the wavefront kernel:
+    """Small calls are routed as well (from 2^25 query symbols x subjects; TINY ones, from 2^18, take the wavefront kernel
+    for every pair without sampling), on shorter segments of the wavefront kernel:
     BASELINE's configs[0] shape (3 x 1 Mbp: per-pair segments for the lanes), a call of many short genomes (one segment
     length for the lanes: the routing marks alone decide what a lane of that layout does), the same with structured
     genomes and an early hand-back (the second lane layout in its one-segment-length form), ragged lengths around the
@@ -148,13 +149,24 @@ def test_small_calls_are_routed_too():
     oracle, every model the kernel counts differently for."""
     os.environ.pop("ANDI_COOP", None)
     star, _ = synth.genome_set(3, 1_000_000, 0.0004, 0.03, seed=3)
-    got, t = _rows(star, {})
+    want = orc.dist_matrix(star, model=orc.M_JC, threads=3)
+    got, t = _rows(star, {})  # a TINY call (below 2^25 symbols): the wavefront kernel for every pair, no sampling
+    assert t["routed_calls"] == 0 and t["coop_calls"] == 1, t
+    assert (got == want).all()
+    got, t = _rows(star, {"ANDI_ROUTE_TINY": "1"})  # the same call routed
     assert t["routed_calls"] == 1 and t["adaptive_calls"] == 1 and t["coop_query_nt"] == 6_000_000, t
-    assert (got == orc.dist_matrix(star, model=orc.M_JC, threads=3)).all()
+    assert (got == want).all()
     far, _ = synth.genome_set(3, 1_000_000, 0.05, 0.05, seed=13)  # configs[0] itself: pairs 10 % apart -- the sampling cannot judge them
+    want = orc.dist_matrix(far, model=orc.M_JC, threads=3)
     got, t = _rows(far, {})
+    assert t["routed_calls"] == 0 and t["coop_calls"] == 1 and (got == want).all(), t
+    got, t = _rows(far, {"ANDI_ROUTE_TINY": "1"})
     assert t["routed_calls"] == 1 and t["coop_query_nt"] == 6_000_000 and t["coop_fallbacks"] == 0, t
-    assert (got == orc.dist_matrix(far, model=orc.M_JC, threads=3)).all()
+    assert (got == want).all()
+    mixed = [star[0], star[1], synth.unrelated(700_000, 5), star[0][:90_000], star[2][400_000:]]  # tiny, with an unrelated genome and fragments
+    got, t = _rows(mixed, {})
+    assert t["routed_calls"] == 0 and t["coop_calls"] == 1, t
+    assert (got == orc.dist_matrix(mixed, model=orc.M_JC, threads=4)).all()
     many, _ = synth.genome_set(60, 20_000, 0.001, 0.04, seed=4)
     want = orc.dist_matrix(many, model=orc.M_JC, threads=4)
     got, t = _rows(many, {})

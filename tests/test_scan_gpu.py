@@ -34,6 +34,19 @@ def _check_set(ctx, orc, seqs, segments=(0,), model=1):
                                want[tuple(bad[0])] if len(bad) else None)
 
 
+@pytest.fixture(autouse=True)
+def _lane_scan(monkeypatch):
+    """This module is about the lane scan (scan_lane.hip, scan.hip): ANDI_COOP=0 keeps the calls of its small sets away
+    from the wavefront kernel, which the engine would otherwise choose for them (tests/test_coop_gpu.py, test_configs_gpu.py
+    and the fuzz test run the engine's own choice)."""
+    import os
+    from andi_amd.lib import reload_knobs
+    if not os.environ.get("ANDI_TESTS_ENGINE_CHOICE"):  # (set: the module's sets through the engine's own choice instead -- parity holds either way)
+        monkeypatch.setenv("ANDI_COOP", "0")
+        reload_knobs()
+    yield
+
+
 def test_pair_ladder(ctx, orc):
     """test/test_random.sh's divergence ladder, counts bit-exact instead of +-5.5 %."""
     from andi_amd import synth
