@@ -909,7 +909,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	// 2.35 ms per call (profiles/r05_small_calls.txt).
 	uint32_t coop_seg = 524288;
 	while (coop_seg > 32768 && q->total_nt * (uint64_t)nsub / coop_seg < 24576) coop_seg /= 2;
-	while (coop_seg > 2048 && q->total_nt * (uint64_t)nsub / coop_seg < (1u << 14)) coop_seg /= 2;
+	while (coop_seg > 2048 && q->total_nt * (uint64_t)nsub / coop_seg < 12000u) coop_seg /= 2; // (8 x 1 Mbp: 0.38 ms at 4096 -- 15 600 wavefronts --, 0.46 at 2048; 12 x 1 Mbp: 0.65 at 8192 -- 17 600 --, 0.74 at 4096)
 	if (const char *cs = andi_knob(KNOB_COOP_SEG)) // experiments
 		if (atoi(cs) >= 64) coop_seg = (uint32_t)atoi(cs);
 	// (the smallest calls -- a few launches' worth of work -- keep the lane scan: routing costs them the sampling kernel
