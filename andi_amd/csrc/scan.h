@@ -94,7 +94,7 @@ struct ScanArgs {
 	// matches, k_lane_cold for the others) share the device instead of each ending in a tail of its own
 	hipStream_t side_stream;
 	hipEvent_t side_fork, side_join;
-	// Pass A of a call is ROUTED PER PAIR (route != 0; the engine's choice for large calls).  k_pair_estimate samples every
+	// Pass A of a call is ROUTED PER PAIR (route != 0; the engine's choice from 2^25 query symbols x subjects; api.hip).  k_pair_estimate samples every
 	// pair; k_pair_route marks the pairs that suit pass A by wavefronts (scan_coop.hip) -- matches neither long (k_lane_quad's
 	// class) nor hardly reaching the anchor threshold, unless such pairs are few; no runs of short matches (unrelated
 	// stretches) -- with ANDI_ROUTE_COOP in their pair_class byte: they get no wavefronts in the lane layout, whose kernels
@@ -125,7 +125,7 @@ hipError_t andi_launch_pair_leftover(const ScanArgs &a2, hipStream_t st);
 hipError_t andi_launch_route_count(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 // pass A with one wavefront per chain (scan_coop.hip)
-int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: large calls are routed per pair (the default); n = 2, 4, 8: every pair, windows of 2048 n symbols
+int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: the engine chooses -- tiny calls every pair, others routed per pair (the default); n = 2, 4, 8: every pair, windows of 2048 n symbols
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStream_t st); // k_lane_quad, one wavefront per block (scan_lane.hip compiled a second time)

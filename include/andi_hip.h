@@ -232,9 +232,9 @@ typedef struct {
 	uint64_t sa_rounds;      /* sorting rounds of those builds */
 	uint64_t adaptive_calls; /* scan calls that chose the segment length per pair */
 	uint64_t uniform_calls;  /* ... one segment length for the call */
-	uint64_t coop_calls;     /* scan calls in which pass A by wavefronts (scan_coop.hip) ran: for every pair (ANDI_COOP=n) or for the pairs routed to it */
+	uint64_t coop_calls;     /* scan calls in which pass A by wavefronts (scan_coop.hip) ran: for every pair (ANDI_COOP=n; by default calls of 2^18 ... 2^25 query symbols x subjects) or for the pairs routed to it */
 	uint64_t coop_fallbacks; /* routed calls: PAIRS that kernel handed back to the lane scan (a stretch without homology, a match longer than a segment) */
-	uint64_t routed_calls;   /* scan calls whose pass A was routed per pair (large calls, by default) */
+	uint64_t routed_calls;   /* scan calls whose pass A was routed per pair (by default calls of 2^25 query symbols x subjects and more) */
 	uint64_t coop_query_nt;  /* routed calls: query nucleotides of the pairs whose pass A ran by wavefronts ... */
 	uint64_t lane_query_nt;  /* ... and by lanes */
 } andi_hip_timings;
