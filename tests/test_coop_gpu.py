@@ -181,6 +181,23 @@ def test_small_calls_are_routed_too():
     got, t = _rows(real, {"ANDI_COOP_GIVEUP": "4"})
     assert t["routed_calls"] == 1 and t["uniform_calls"] == 1 and t["coop_fallbacks"] > 0, t
     assert (got == want).all()
+    # more than 4096 pairs: the sampling kernel takes four pairs per block; structured genomes, hand-backs forced
+    lots, _ = synth.realistic_set(80, 20_000, 0.002, 0.04, seed=16, novel_fraction=0.05)
+    want = orc.dist_matrix(lots, model=orc.M_KIMURA, threads=4)
+    for env in ({}, {"ANDI_COOP_GIVEUP": "4"}):
+        with knobs(**{k[len("ANDI_"):]: v for k, v in env.items()}):
+            ctx = andi_amd.Context(0)
+            Q = andi_amd.Queries(ctx, lots)
+            esas = [andi_amd.Esa(ctx, x, sa="device") for x in lots]
+            ctx.timings_reset()
+            got = andi_amd.scan_rows(ctx, esas, list(range(len(lots))), Q, model=andi_amd.M_KIMURA)
+            t = ctx.timings()
+            for e in esas:
+                e.close()
+            Q.close()
+            ctx.close()
+        assert t["routed_calls"] == 1 and t["uniform_calls"] == 1 and (got == want).all(), (env, t)
+        assert not env or t["coop_fallbacks"] > 0, t
     rng = np.random.default_rng(8)
     base = synth.base_codes(40_000, 9)
     ragged = []
