@@ -28,13 +28,14 @@ namespace {
 // are made seg_factor times that (as a power-of-two multiple of seg0, at most 8 seg0).
 // Short segments keep the lanes of a wavefront close together in memory and the work
 // items small; long ones keep the stitching of low-divergence pairs cheap.
-// (A block of four wavefronts per pair: every one of them takes the 64 samples of the mean -- the same, so that all know
-// what the pair is a candidate for -- and a quarter of the further samples of a routed call: the kernel's time is the
-// chain of dependent probes of one wavefront, 185 us with one wavefront per pair.)
-[[maybe_unused]] constexpr uint32_t EST_WAVES = 4; // (calls of a few thousand pairs; one wavefront per pair beyond: the device is full either way)
+// (A block of several wavefronts per pair: every one of them takes the samples of the mean -- the same, so that all know
+// what the pair is a candidate for -- and its share of the further samples of a routed call: the kernel's time is the
+// chain of dependent probes of one wavefront, 185 us with one wavefront per pair, 100 us with eight.)
+[[maybe_unused]] constexpr uint32_t EST_WAVES = 4; // (calls of up to 4096 pairs)
 constexpr uint32_t EST_WAVES_FEW = 8; // (calls of up to 1024 pairs: a round of further samples per wavefront)
-// (Calls of more pairs than that, `many`: every wavefront of a block its own pair -- 90 000 blocks of one wavefront were
-// launched in 1.1 ms, whatever they sampled.)
+// (Calls of more pairs than that, `many`: the device is full with one wavefront per pair; four pairs share a block.  What
+// the pairs add up -- the layout's wavefront counts -- is k_pair_totals' business: 90 000 pairs adding to three words one
+// by one from here took a millisecond, a million 30 ms.)
 __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a, bool many) {
 	__shared__ uint32_t s_shorts, s_runs;
 	const uint32_t est_waves = many ? 1u : blockDim.x >> 6;
@@ -52,8 +53,8 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 		__syncthreads();
 	}
 	PairCtx c = make_ctx(a, sub, qidx);
-	// (routed calls, short queries: 32 or 16 samples -- with thousands of pairs of 10 ... 30 kbp the sampling was a
-	// third of the call, at the rate the device serves scattered requests at all)
+	// (routed calls, short queries: 32 or 16 samples -- a sample per kbp still; calls of thousands of such queries are
+	// mostly sampling otherwise)
 	const uint32_t nl_shift = !a.route || c.qlen >= 32768u ? 6u : c.qlen >= 16384u ? 5u : 4u, nl = 1u << nl_shift;
 	const uint32_t p = (uint32_t)(((uint64_t)(2 * lane + 1) * c.qlen) >> (nl_shift + 1));
 	LWin w;
