@@ -1140,9 +1140,14 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			// handful of lane blocks (four wavefronts and their LDS on one CU at once) found no place until that kernel's
 			// tail and ended 0.2 ms after everything else --, the wavefront kernel where they are many (the tree-structured
 			// set, the C4 shape: 0.4 and 1.5 ms the other way round).  The host looks at the layout (one word).
-			e = hipMemcpyAsync(ctx->h_any_left + 1, a.restitch_count + ANDI_LANE_WAVES, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
-			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-			const bool lanes_first = e == hipSuccess && (uint64_t)ctx->h_any_left[1] * 20 < ctx->h_any_left[1 + ANDI_ALL_WAVES - ANDI_LANE_WAVES];
+			// (Small calls do not look: the wavefront kernel first, the lane layout's passes whether it has pairs or not --
+			// a look costs them 40 us of their few hundred.)
+			const bool look = !a.route_all_few;
+			ctx->h_any_left[1] = 1;
+			e = hipSuccess;
+			if (look) e = hipMemcpyAsync(ctx->h_any_left + 1, a.restitch_count + ANDI_LANE_WAVES, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+			if (look && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			const bool lanes_first = look && e == hipSuccess && (uint64_t)ctx->h_any_left[1] * 20 < ctx->h_any_left[1 + ANDI_ALL_WAVES - ANDI_LANE_WAVES];
 			if (e == hipSuccess) e = hipEventRecord(ctx->coop_fork, ctx->stream);
 			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->coop_stream, ctx->coop_fork, 0);
 			if (e == hipSuccess && lanes_first) e = andi_launch_scan_cold(a, ctx->stream);
