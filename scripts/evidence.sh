@@ -25,8 +25,8 @@ for shape in "c4shape_8x3085x2.1Mbp --genomes 3085 --subjects 8 --length 2100000
 done
 # small calls: the step as it comes, by lanes only, and with the wavefront kernel forced
 {
-  echo "# bench.py --steps 5 --warmup 1 on small shapes: default (routed per pair) / ANDI_COOP=0 (lane scan only) / ANDI_COOP=4 (wavefront kernel forced)"
-  for shape in "3 --length 1000000" "3 --length 1000000 --dlo 0.05 --dhi 0.05" "3 --length 200000" "10 --length 500000" "10 --length 1000000 --dlo 0.03 --dhi 0.03" "29 --length 100000" "29 --length 500000" "100 --length 30000" "300 --length 10000" "1000 --length 5000" "8 --length 4900000" "12 --length 1000000 --set realistic" "12 --length 1000000 --set tree"; do
+  echo "# bench.py --steps 5 --warmup 1 on small shapes: default (tiny calls: wavefront kernel for every pair; others routed per pair) / ANDI_COOP=0 (lane scan only) / ANDI_COOP=4 (wavefront kernel forced)"
+  for shape in "3 --length 1000000" "3 --length 1000000 --dlo 0.05 --dhi 0.05" "3 --length 200000" "10 --length 500000" "10 --length 1000000 --dlo 0.03 --dhi 0.03" "29 --length 100000" "29 --length 500000" "100 --length 30000" "300 --length 10000" "1000 --length 5000" "8 --length 4900000" "3 --length 1000000 --set realistic" "5 --length 1300000 --set realistic" "12 --length 1000000 --set realistic" "12 --length 1000000 --set tree"; do
     BENCH_ARGS="--genomes $shape" bash scripts/dev/ab.sh "X=1" "ANDI_COOP=0" "ANDI_COOP=4" | sed "s/^/--genomes $shape: /"
   done
 } > gpurun_out/${tag}_small_calls.txt 2>&1
