@@ -296,6 +296,23 @@ int andi_hip_abi_version(void) {
 	return ANDI_HIP_ABI_VERSION;
 }
 
+size_t andi_hip_trim(void) {
+	int ndev = 0, cur = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess) {
+		(void)hipGetLastError();
+		return 0;
+	}
+	(void)hipGetDevice(&cur);
+	size_t freed = 0;
+	for (int d = 0; d < ndev && d < 64; ++d) {
+		if (hipSetDevice(d) != hipSuccess) continue;
+		(void)hipDeviceSynchronize(); // (as hipFree: nothing in flight lies in a chunk that goes)
+		freed += andi_arena::trim(d);
+	}
+	(void)hipSetDevice(cur);
+	return freed;
+}
+
 void andi_hip_default_opts(andi_hip_opts *o) {
 	if (!o) return;
 	memset(o, 0, sizeof *o);
@@ -1583,9 +1600,14 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		for (size_t b = 0; b < sets * batch; ++b)
 			if (esa_reserve(D.prep, rs_cap, &D.slots[b])) return bail("allocating subject slots", D.prep);
 		if (andi_hip_sync(D.prep)) return bail("allocating subject slots", D.prep);
+		double t_reserve = 0, t_pinned = 0;
+		lap(t_reserve);
 		if (hipHostMalloc((void **)&D.pinned, rs_cap + 1, hipHostMallocDefault) != hipSuccess) D.pinned = nullptr; // (then from where RS lies)
+		lap(t_pinned);
 		if (andi_hip_dev_alloc(D.ctx, (use_rccl ? rows : batch) * n * sizeof(andi_hip_model), (void **)&D.d_rows)) return bail("row buffer", D.ctx);
 		lap(t_slots);
+		t_slots += t_reserve + t_pinned;
+		if (trace && d == 0) fprintf(stderr, "andi_hip_dist_matrix trace: slots = device buffers of %zu slots %.1f ms + pinned upload buffer %.1f ms + row buffer %.1f ms\n", sets * batch, t_reserve, t_pinned, t_slots - t_reserve - t_pinned);
 
 		// hand-over between the two stages
 		std::mutex pm;

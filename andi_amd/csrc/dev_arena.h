@@ -7,8 +7,12 @@
 // start addresses without packing them does nothing: it is the number of mappings, not their alignment).  So the
 // engine's device buffers come from chunks of ANDI_ARENA_MB MiB (default 2048; 0: plain hipMalloc), first fit with
 // coalescing; a request of more than half a chunk, or one that no chunk can be found or made for, goes to hipMalloc.
-// One arena per device, shared by the contexts on it (the chunks are released with the last of them).  Freeing
-// waits for the device like hipFree does, so a block is never handed out again while a kernel may still use it.
+// One arena per device, shared by the contexts on it.  The chunks outlive the contexts (round 4): a process that calls
+// the seam again finds them -- on some boxes of the pool a fresh hipMalloc of the 6.5 GB a 29-genome job takes costs
+// 0.3 s (the driver clears what it hands out), every call, which was three quarters of the seam's wall time there;
+// andi_hip_trim() gives the unused chunks back, ANDI_ARENA_KEEP=0 releases them with a device's last context as
+// before.  Freeing waits for the device like hipFree does, so a block is never handed out again while a kernel may
+// still use it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "knobs.h"
@@ -136,11 +140,34 @@ inline void retain(int dev) {
 	++A.contexts;
 }
 
+inline bool keep_chunks() {
+	const char *e = andi_knob(KNOB_ARENA_KEEP);
+	return !e || atoi(e) != 0;
+}
+
+// the chunks of a device nobody holds a block of go back to the driver; returns the bytes given back
+inline size_t trim(int dev) {
+	Arena &A = of_device(dev);
+	std::lock_guard<std::mutex> lock(A.mu);
+	size_t freed = 0;
+	for (size_t i = 0; i < A.chunks.size();) {
+		if (A.chunks[i].used == 0) {
+			freed += A.chunks[i].size;
+			(void)hipFree(A.chunks[i].base);
+			A.chunks.erase(A.chunks.begin() + (long)i);
+		} else {
+			++i;
+		}
+	}
+	return freed;
+}
+
 inline void release(int dev) {
 	Arena &A = of_device(dev);
 	std::lock_guard<std::mutex> lock(A.mu);
 	if (--A.contexts > 0) return;
 	A.contexts = 0;
+	if (keep_chunks()) return; // (andi_hip_trim, or the process's end)
 	for (size_t i = 0; i < A.chunks.size();) {
 		if (A.chunks[i].used == 0) {
 			(void)hipFree(A.chunks[i].base);

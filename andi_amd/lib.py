@@ -81,6 +81,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "andi_hip_default_opts": (None, [C.POINTER(Opts)]),
     "andi_hip_abi_version": (C.c_int, []),
+    "andi_hip_trim": (C.c_size_t, []),
     "andi_hip_dist_matrix": (C.c_int, [_P, C.POINTER(Seq), C.c_size_t, C.POINTER(Opts), C.c_char_p, C.c_size_t]),
     "andi_hip_last_gather": (C.c_char_p, []),
     "andi_hip_subject_prepare": (C.c_int, [C.c_char_p, C.c_size_t, C.c_double, C.POINTER(_P),
@@ -438,6 +439,11 @@ def scan_rows(ctx: Context, esas, selfs, queries: Queries, model=M_JC, segment=0
 
 def device_count():
     return load().andi_hip_device_count()
+
+
+def trim():
+    """Give the device-memory chunks nobody holds a block of back to the driver; returns the bytes released."""
+    return int(load().andi_hip_trim())
 
 
 def reload_knobs():

@@ -411,12 +411,39 @@ def main():
         t0 = time.time()
         M1w = andi_amd.dist_matrix(seqs, p_value=p_value, model=model)  # the same call again: arena chunks, pinned buffers, code objects are there
         e2e_warm = time.time() - t0
+        # once more with the library's own split of the call (ANDI_E2E_TRACE: the driver threads time their stages, with a
+        # device wait behind each -- a little slower than the calls above): where the time goes on THIS box.  The host is
+        # shared with other jobs (load average below); the stages that run on host cores feel it.
+        traced = None
+        try:
+            import tempfile
+            os.environ["ANDI_E2E_TRACE"] = "1"
+            andi_amd.lib.reload_knobs()
+            sys.stderr.flush()
+            saved, tmp = os.dup(2), tempfile.TemporaryFile()
+            os.dup2(tmp.fileno(), 2)
+            try:
+                t0 = time.time()
+                andi_amd.dist_matrix(seqs, p_value=p_value, model=model)
+                dt = time.time() - t0
+            finally:
+                os.dup2(saved, 2)
+                os.close(saved)
+            tmp.seek(0)
+            lines = [ln.strip() for ln in tmp.read().decode(errors="replace").splitlines() if "andi_hip_dist_matrix trace" in ln]
+            traced = {"wall_s": dt, "split": lines}
+        except Exception as ex:  # diagnostics only
+            traced = {"error": str(ex)}
+        finally:
+            os.environ.pop("ANDI_E2E_TRACE", None)
+            andi_amd.lib.reload_knobs()
         t0 = time.time()
         M2 = andi_amd.dist_matrix(seqs, p_value=p_value, model=model, sa_on_host=True)
         e2e_host = time.time() - t0
         out["end_to_end"].update({
             "dist_matrix_e2e_s": e2e, "dist_matrix_pairs_per_s": pairs_total / e2e,
             "dist_matrix_e2e_warm_s": e2e_warm, "dist_matrix_warm_pairs_per_s": pairs_total / e2e_warm,
+            "dist_matrix_traced_call": traced, "host_load_average": list(os.getloadavg()),
             "dist_matrix_e2e_s_suffix_arrays_on_host": e2e_host, "host_cores": os.cpu_count(),
             "dist_matrix_equals_step": bool((M1 == full).all() and (M1w == full).all() and (M2 == full).all())})
     if rank == 0 and world > 1:

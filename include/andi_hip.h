@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ANDI_HIP_ABI_VERSION 3
+#define ANDI_HIP_ABI_VERSION 4
 
 /* enum in src/global.h:50 */
 enum { ANDI_M_RAW = 0, ANDI_M_JC = 1, ANDI_M_KIMURA = 2, ANDI_M_LOGDET = 3, ANDI_M_ANI = 4 };
@@ -75,6 +75,13 @@ typedef struct {
 
 void andi_hip_default_opts(andi_hip_opts *o);
 int andi_hip_abi_version(void);
+
+/* Device memory: the library carves its buffers out of large chunks (2 GiB, ANDI_ARENA_MB) that stay with the process
+ * when the last context on a device is destroyed, so that the next call of the seam does not pay the driver for them
+ * again (on some hosts 0.3 s per call for a 29-genome job).  This gives the chunks nobody holds a block of back to the
+ * driver -- all devices; waits for each --, and returns the bytes released.  (ANDI_ARENA_KEEP=0: released with a
+ * device's last context, as up to ABI 3.) */
+size_t andi_hip_trim(void);
 
 /* ------------------------------------------------------------------ */
 /* The seam: replaces distMatrix / distMatrixLM (src/dist_hack.h:34-96) */

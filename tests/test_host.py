@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.andi_hip_abi_version() == 3  # 2: opts.num_gpus, opts.devices; timings.adaptive_calls.  3: timings.routed_calls ...; andi_hip_esa_single_form
+    assert L.andi_hip_abi_version() == 4  # 2: opts.num_gpus, opts.devices; timings.adaptive_calls.  3: timings.routed_calls ...; andi_hip_esa_single_form.  4: andi_hip_trim (chunks outlive contexts)
     assert C.sizeof(lib.Model) == 68 and C.sizeof(lib.Interval) == 16
 
 
