@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <sys/mman.h>
 #include <vector>
 
 #include "andi_dev.h"
@@ -820,6 +821,155 @@ void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q) {
 	delete q;
 }
 
+// 4-bit symbols of a byte string, as the device's pack kernel makes them (scan_lane.hip: symbol_of, in_alphabet): byte j of
+// `out` = symbol 2j | symbol 2j+1 << 4, the NUL behind an odd length included; (len + 1) / 2 bytes.  Eight bytes at a time
+// where they are all nucleotides (what genomes are made of); returns 1 if a byte lies outside {A,C,G,T,!,;,#,NUL}.
+extern "C" int andi_hip_pack_symbols(const unsigned char *src, size_t len, unsigned char *out) {
+	static const struct Lut {
+		uint8_t v[256];
+		Lut() {
+			for (int c = 0; c < 256; ++c) {
+				const uint8_t ch = (uint8_t)c;
+				const uint32_t sym = ch >= 'A' ? (uint32_t)(((ch & 6u) ^ ((ch & 6u) >> 1)) >> 1) : (ch == '!' ? 4u : ch == ';' ? 5u : ch == '#' ? 6u : 7u);
+				const bool in = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == '!' || ch == ';' || ch == '#' || ch == 0;
+				v[c] = (uint8_t)(sym | (in ? 0u : 0x80u));
+			}
+		}
+	} lut;
+	uint32_t bad = 0;
+	size_t k = 0;
+	const uint64_t ones = 0x0101010101010101ull;
+	for (; k + 8 <= len; k += 8) {
+		uint64_t x;
+		memcpy(&x, src + k, 8);
+		const uint64_t t = ((x >> 1) ^ (x >> 2)) & (3 * ones); // a nucleotide's code, per byte: ((c & 6) ^ ((c & 6) >> 1)) >> 1
+		const uint64_t b0 = t & ones, b1 = (t >> 1) & ones;
+		const uint64_t mc = b0 & ~b1, mg = b1 & ~b0, mt = b0 & b1;      // C, G, T (no carries: the sums stay below 0x55)
+		const uint64_t expect = 0x41 * ones + 2 * mc + 6 * mg + 0x13 * mt; // the letter that code belongs to
+		if (x == expect) {                                                // eight nucleotides: four bytes of symbols
+			uint64_t z = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;            // 16-bit lanes: symbol 2j | symbol 2j+1 << 4
+			z = (z | (z >> 8)) & 0x0000ffff0000ffffull;
+			const uint32_t o = (uint32_t)(z | (z >> 16));
+			memcpy(out + k / 2, &o, 4);
+		} else {
+			for (size_t j = k; j < k + 8; j += 2) {
+				const uint32_t lo = lut.v[src[j]], hi = lut.v[src[j + 1]];
+				bad |= lo | hi;
+				out[j / 2] = (uint8_t)((lo & 7u) | ((hi & 7u) << 4));
+			}
+		}
+	}
+	for (; k + 1 < len; k += 2) {
+		const uint32_t lo = lut.v[src[k]], hi = lut.v[src[k + 1]];
+		bad |= lo | hi;
+		out[k / 2] = (uint8_t)((lo & 7u) | ((hi & 7u) << 4));
+	}
+	if (k < len) { // an odd length: the NUL behind the string is the last byte's other symbol
+		const uint32_t lo = lut.v[src[k]];
+		bad |= lo;
+		out[k / 2] = (uint8_t)((lo & 7u) | (7u << 4));
+	}
+	return (bad & 0x80u) ? 1 : 0;
+}
+
+// The seam's queries, packed ONCE on the host (round 4): every device uploads the 4-bit pool -- a quarter of what the
+// byte pool and its packed copy were, from one host copy shared by the device threads -- and unpacks the bytes the rare
+// byte-wise paths read (k_unpack_symbols).  C4's 6.5 GB of queries took 0.35 s per device as bytes from pageable memory.
+struct PackedQueries {
+	std::vector<uint64_t> off;
+	std::vector<uint32_t> len;
+	uint64_t total_nt = 0;
+	size_t pool_bytes = 0;
+	uint8_t *nib = nullptr; // pool_bytes / 2 bytes: the pool as the device's pack kernel would leave it
+	int foreign = 0;        // a byte outside the alphabet (the scan refuses the queries then)
+	std::string err;
+	std::atomic<int> users{0}; // devices that have not staged yet: the last one lets the host copy go (gigabytes: not at the call's end)
+	void release() {
+		free(nib);
+		nib = nullptr;
+	}
+	~PackedQueries() { release(); }
+};
+
+static int pack_queries_host(const andi_hip_seq *seqs, size_t n, int threads, PackedQueries &P) {
+	if (!seqs || n == 0 || n >= (size_t)UINT32_MAX) {
+		P.err = "andi_hip_queries_stage: bad arguments";
+		return 1;
+	}
+	P.off.resize(n), P.len.resize(n);
+	uint64_t cursor = 0;
+	for (size_t i = 0; i < n; ++i) { // (the layout of andi_hip_queries_stage)
+		if (!seqs[i].seq || seqs[i].len == 0 || seqs[i].len > (size_t)(INT32_MAX - 1) / 2) {
+			P.err = "andi_hip_queries_stage: empty or oversized sequence";
+			return 1;
+		}
+		P.off[i] = cursor, P.len[i] = (uint32_t)seqs[i].len, P.total_nt += seqs[i].len;
+		cursor += (seqs[i].len + 1 + 255) & ~(uint64_t)255;
+	}
+	P.pool_bytes = cursor + ANDI_PAD;
+	// (2 MiB-aligned and advised as huge pages: 256 threads touching gigabytes of fresh 4 KiB pages queue up in the kernel --
+	// C5's 6.4 GB took 1.3 s to pack that way)
+	const size_t nib_bytes = (P.pool_bytes / 2 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+	P.nib = (uint8_t *)aligned_alloc((size_t)2 << 20, nib_bytes);
+#ifdef MADV_HUGEPAGE
+	if (P.nib) (void)madvise(P.nib, nib_bytes, MADV_HUGEPAGE);
+#endif
+	if (!P.nib) {
+		P.err = "andi_hip_dist_matrix: out of host memory for the packed queries";
+		return 1;
+	}
+	std::atomic<size_t> next{0};
+	std::atomic<int> foreign{0};
+	auto work = [&]() {
+		for (;;) {
+			const size_t i = next.fetch_add(1);
+			if (i >= n) return;
+			const size_t len = seqs[i].len, end = (i + 1 < n ? (size_t)P.off[i + 1] : P.pool_bytes) / 2;
+			uint8_t *dst = P.nib + P.off[i] / 2; // (offsets are multiples of 256)
+			const size_t w = (len + 1) / 2;
+			if (andi_hip_pack_symbols((const unsigned char *)seqs[i].seq, len, dst)) foreign.store(1);
+			memset(dst + w, 0x77, end - (P.off[i] / 2 + w)); // NUL, NUL up to the next sequence (the pool's end)
+		}
+	};
+	// (two dozen threads keep up with the host's memory; all 256 cores packing starved the devices' context creation, which
+	// runs beside this: C5's contexts 1.3 -> 2.8 s)
+	const int nt = std::max(1, std::min(std::min(threads, 24), (int)std::min<size_t>(n, 256)));
+	std::vector<std::thread> ts;
+	for (int t = 1; t < nt; ++t) ts.emplace_back(work);
+	work();
+	for (auto &t : ts) t.join();
+	P.foreign = foreign.load();
+	return 0;
+}
+
+static int queries_stage_packed(andi_hip_ctx *ctx, const PackedQueries &P, andi_hip_queries **out) {
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	auto *q = new andi_hip_queries;
+	const size_t n = P.off.size();
+	q->nq = n, q->off = P.off, q->len = P.len, q->total_nt = P.total_nt;
+	hipError_t err = hipSuccess;
+	auto chk = [&](hipError_t x) {
+		if (err == hipSuccess) err = x;
+	};
+	chk(dmalloc(&q->pool, P.pool_bytes));
+	chk(dmalloc(&q->nib, P.pool_bytes / 2 + 64));
+	chk(hipHostMalloc((void **)&q->h_foreign, sizeof(int32_t), hipHostMallocDefault));
+	chk(dmalloc(&q->d_off, n));
+	chk(dmalloc(&q->d_len, n));
+	if (err == hipSuccess) *q->h_foreign = P.foreign;
+	if (err == hipSuccess) err = hipMemcpyAsync(q->nib, P.nib, P.pool_bytes / 2, hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess) err = andi_launch_unpack_symbols(q->nib, P.pool_bytes, q->pool, ctx->stream);
+	if (err == hipSuccess) err = hipMemcpyAsync(q->d_off, q->off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess) err = hipMemcpyAsync(q->d_len, q->len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+	if (err != hipSuccess) {
+		andi_hip_queries_free(ctx, q);
+		return fail(ctx, "andi_hip_dist_matrix: staging the packed queries", err);
+	}
+	*out = q;
+	return 0;
+}
+
 static int ensure_segmentation(andi_hip_ctx *ctx, andi_hip_queries *q, uint32_t seg, bool coop = false) {
 	uint32_t &have = coop ? q->c_seg : q->seg, &total_out = coop ? q->c_total_segs : q->total_segs;
 	uint32_t *&d_start = coop ? q->c_qseg_start : q->d_qseg_start, *&d_s2q = coop ? q->c_seg2query : q->d_seg2query;
@@ -1552,6 +1702,25 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	const bool trace = andi_knob(KNOB_E2E_TRACE) != nullptr; // diagnostics: where the call's wall time goes (device 0's driver)
 	auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	const double t_call = now_ms();
+	// the queries as 4-bit symbols, packed once for all devices while their contexts come up (ANDI_QUERIES_BYTES: every
+	// device uploads the bytes and packs them itself, as up to round 3)
+	// One device: the bytes as they lie (measured on one GPU, same box: C4's queries 0.51 s as bytes, 0.10 s packed -- but the
+	// pack's pass over the host's memory and the release of its copy gave the 0.3 s back; C5 was slower packed).
+	const bool pack_on_host = andi_knob(KNOB_QUERIES_BYTES) == nullptr && (ndev > 1 || andi_knob(KNOB_QUERIES_PACKED) != nullptr);
+	PackedQueries PQ;
+	PQ.users.store((int)ndev);
+	std::mutex pq_mu;
+	std::condition_variable pq_cv;
+	bool pq_done = false;
+	int pq_rc = 0;
+	std::thread packer;
+	if (pack_on_host)
+		packer = std::thread([&] {
+			const int rc = pack_queries_host(seqs, n, threads, PQ);
+			std::lock_guard<std::mutex> lk(pq_mu);
+			pq_rc = rc, pq_done = true;
+			pq_cv.notify_all();
+		});
 	auto drive = [&](size_t d) {
 		Dev &D = dv[d];
 		char eb[256] = "";
@@ -1595,7 +1764,21 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		// device (sorts of 8 subjects: 6 ms alone, 38 ms beside a scan, on a high-priority stream as on a plain one).
 		const size_t sets = sets_for(batch);
 		D.slots.assign(sets * batch, nullptr);
-		if (andi_hip_queries_stage(D.ctx, seqs, n, &D.Q)) return bail("staging queries", D.ctx);
+		if (pack_on_host) {
+			{
+				std::unique_lock<std::mutex> lk(pq_mu);
+				pq_cv.wait(lk, [&] { return pq_done; });
+			}
+			if (pq_rc) {
+				snprintf(eb, sizeof eb, "%s", PQ.err.c_str());
+				return bail("staging queries", nullptr);
+			}
+			const int rc = queries_stage_packed(D.ctx, PQ, &D.Q);
+			if (PQ.users.fetch_sub(1) == 1) PQ.release(); // (every device has its copy)
+			if (rc) return bail("staging queries", D.ctx);
+		} else if (andi_hip_queries_stage(D.ctx, seqs, n, &D.Q)) {
+			return bail("staging queries", D.ctx);
+		}
 		lap(t_queries);
 		for (size_t b = 0; b < sets * batch; ++b)
 			if (esa_reserve(D.prep, rs_cap, &D.slots[b])) return bail("allocating subject slots", D.prep);
@@ -1746,6 +1929,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	}
 	cv.notify_all();
 	for (auto &t : pool) t.join();
+	if (packer.joinable()) packer.join();
 	for (auto *p : ready) {
 		andi_hip_free(p->RS);
 		delete p;

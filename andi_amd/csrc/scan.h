@@ -116,6 +116,7 @@ struct ScanArgs {
 // 4-bit symbols of `bytes` source bytes (a NUL-padded pool or text) into N0 and, if not
 // null, the one-symbol-shifted copy N1; `bytes` is rounded up to a multiple of 16; *foreign is
 // set to 1 if a byte is none of A C G T ! ; # NUL (the packed scan is then not applicable)
+hipError_t andi_launch_unpack_symbols(const uint8_t *N0, size_t bytes, uint8_t *dst, hipStream_t st); // a byte pool from its 4-bit symbols
 hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N0, uint8_t *N1,
 									int32_t *foreign, hipStream_t st);
 // adaptive mode: sample every pair's match lengths, choose its segment length (and, in a routed call, its pass A), lay out the slots

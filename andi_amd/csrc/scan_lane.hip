@@ -1062,6 +1062,25 @@ __global__ __launch_bounds__(256) void k_pack_symbols(const uint8_t *__restrict_
 	pack_symbols_block(src, pairs, N0, N1, foreign);
 }
 
+// the other way round: the bytes of a pool from its 4-bit symbols (the seam's queries come packed from the host; the
+// rare byte-wise paths still read bytes).  One thread: 16 symbols -> 16 bytes.
+__global__ __launch_bounds__(256) void k_unpack_symbols(const uint2 *__restrict__ N0, int64_t pairs, uint4 *__restrict__ dst) {
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= pairs) return;
+	const uint2 v = N0[j];
+	const uint64_t letters = 0x00233b2154474341ull; // "ACGT!;#\0": byte k = the letter of symbol k
+	uint32_t out[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const uint32_t w = (k < 2 ? v.x : v.y) >> (16 * (k & 1)); // four symbols
+		uint32_t o = 0;
+#pragma unroll
+		for (int t = 0; t < 4; ++t) o |= (uint32_t)((letters >> (8 * ((w >> (4 * t)) & 7u))) & 0xffu) << (8 * t);
+		out[k] = o;
+	}
+	dst[j] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
 __global__ __launch_bounds__(256) void k_pack_symbols_batch(const AndiIndexBatchItem *__restrict__ items) {
 	const AndiIndexBatchItem it = items[blockIdx.y];
 	pack_symbols_block(it.S, ((int64_t)it.n + 1 + 64 + 15) / 16, (uint2 *)it.N0, (uint2 *)it.N1, it.flags + 1);
@@ -1090,6 +1109,14 @@ hipError_t andi_launch_pack_symbols_batch(const AndiIndexBatchItem *d_items, uin
 	const int64_t pairs = (int64_t)((bytes + 15) / 16);
 	if (pairs == 0 || count == 0) return hipSuccess;
 	k_pack_symbols_batch<<<dim3((unsigned)((pairs + 255) / 256), count), 256, 0, st>>>(d_items);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_unpack_symbols(const uint8_t *N0, size_t bytes, uint8_t *dst, hipStream_t st) { // bytes: of dst, a multiple of 16
+	const int64_t pairs = (int64_t)(bytes / 16);
+	if (pairs == 0) return hipSuccess;
+	k_unpack_symbols<<<(unsigned)((pairs + 255) / 256), 256, 0, st>>>((const uint2 *)N0, pairs, (uint4 *)dst);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }

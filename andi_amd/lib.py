@@ -82,6 +82,7 @@ SYMBOLS = {
     "andi_hip_default_opts": (None, [C.POINTER(Opts)]),
     "andi_hip_abi_version": (C.c_int, []),
     "andi_hip_trim": (C.c_size_t, []),
+    "andi_hip_pack_symbols": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p]),
     "andi_hip_dist_matrix": (C.c_int, [_P, C.POINTER(Seq), C.c_size_t, C.POINTER(Opts), C.c_char_p, C.c_size_t]),
     "andi_hip_last_gather": (C.c_char_p, []),
     "andi_hip_subject_prepare": (C.c_int, [C.c_char_p, C.c_size_t, C.c_double, C.POINTER(_P),
@@ -439,6 +440,14 @@ def scan_rows(ctx: Context, esas, selfs, queries: Queries, model=M_JC, segment=0
 
 def device_count():
     return load().andi_hip_device_count()
+
+
+def pack_symbols(seq: bytes):
+    """(4-bit symbols of seq as a numpy uint8 array, whether a byte lies outside the alphabet) -- the host packer of the seam."""
+    import numpy as np
+    out = np.empty((len(seq) + 1) // 2, np.uint8)
+    bad = load().andi_hip_pack_symbols(seq, len(seq), out.ctypes.data_as(C.c_void_p))
+    return out, bool(bad)
 
 
 def trim():

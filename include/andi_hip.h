@@ -83,6 +83,12 @@ int andi_hip_abi_version(void);
  * device's last context, as up to ABI 3.) */
 size_t andi_hip_trim(void);
 
+/* Host helper: the 4-bit symbols of a byte string as the engine keeps its texts (A C G T ! ; # NUL = 0 ... 7; byte j of out
+ * = symbol 2j | symbol 2j+1 << 4, the NUL behind an odd length included): (len + 1) / 2 bytes.  Returns 1 if a byte lies
+ * outside that alphabet (src/sequence.c:260-282 never produces one).  The seam packs its queries with it, once for all
+ * devices; no GPU is touched. */
+int andi_hip_pack_symbols(const unsigned char *src, size_t len, unsigned char *out);
+
 /* ------------------------------------------------------------------ */
 /* The seam: replaces distMatrix / distMatrixLM (src/dist_hack.h:34-96) */
 /* as called from calculate_distances (src/process.c:247-251).         */

@@ -217,3 +217,28 @@ def test_integration_patch_applies_to_the_reference(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     text = (tmp_path / "src" / "process.c").read_text()
     assert "distMatrixHIP(M, sequences, n);" in text and "HAVE_ANDI_HIP" in (tmp_path / "configure.ac").read_text()
+
+
+def test_host_packer_equals_the_alphabet_table():
+    """andi_hip_pack_symbols (the seam packs its queries with it, eight nucleotides at a time) against the table the device's
+    pack kernel uses: A C G T ! ; # NUL = 0 ... 7, two symbols per byte, NUL behind an odd length; bytes outside flagged."""
+    from andi_amd import lib
+    code = np.full(256, 7, np.uint8)
+    for ch, v in ((b"A", 0), (b"C", 1), (b"G", 2), (b"T", 3), (b"!", 4), (b";", 5), (b"#", 6)):
+        code[ch[0]] = v
+    for c in range(0x41, 256):
+        code[c] = ((c & 6) ^ ((c & 6) >> 1)) >> 1  # (scan_lane.hip: symbol_of -- what a byte outside the alphabet becomes)
+    inside = set(b"ACGT!;#\0")
+    rng = np.random.default_rng(3)
+    cases = [b"A", b"AC", b"ACG", b"ACGTACGT", b"ACGTACGTA", rand_dna(np.random.default_rng(5), 1000), rand_dna(np.random.default_rng(6), 4097)]
+    cases.append(b"!".join(rand_dna(np.random.default_rng(50 + k), int(rng.integers(1, 40))) for k in range(60)))           # separators at every alignment
+    cases.append(bytes(rng.choice(list(b"ACGTN"), 3000).astype(np.uint8)))                             # N: outside
+    cases.append(bytes(rng.integers(0, 256, 5000).astype(np.uint8)))                                   # any byte
+    cases.append(rand_dna(np.random.default_rng(9), 777) + b"acgt" + rand_dna(np.random.default_rng(10), 100))                                       # lower case: outside
+    cases.append(rand_dna(np.random.default_rng(11), 64) + b"#" + rand_dna(np.random.default_rng(12), 63) + b";" + rand_dna(np.random.default_rng(13), 5))
+    for seq in cases:
+        got, bad = lib.pack_symbols(seq)
+        a = np.frombuffer(seq + (b"\0" if len(seq) % 2 else b""), np.uint8)
+        want = (code[a[0::2]] & 7) | ((code[a[1::2]] & 7) << 4)
+        assert (got == want).all(), seq[:40]
+        assert bad == any(c not in inside for c in seq), seq[:40]

@@ -80,6 +80,31 @@ def test_errors_come_back_through_errbuf():
         andi_amd.dist_matrix(seqs, devices=[0, 99])
     with pytest.raises(andi_amd.AndiHipError):
         andi_amd.dist_matrix(seqs[:2] + [b""], devices=[0, 0])
+    # a byte outside the alphabet: refused whether the device packs the queries (one device) or the host did (several)
+    bad = seqs[:2] + [seqs[2][:5000] + b"N" + seqs[2][5000:]]
+    for kw in ({}, {"devices": [0, 0]}):
+        with pytest.raises(andi_amd.AndiHipError, match="outside"):
+            andi_amd.dist_matrix(bad, **kw)
+
+
+def test_queries_packed_on_the_host_equal_the_device_packed_ones(orc):
+    """Several devices: the queries are packed once on the host and every device uploads the 4-bit pool (and unpacks the
+    bytes); one device: the bytes, packed on the device.  ANDI_QUERIES_PACKED / ANDI_QUERIES_BYTES force either; ragged
+    lengths (odd ones), joined contigs, every model's counts."""
+    import andi_amd
+    from andi_amd import synth
+    from conftest import knobs
+    seqs = _set()
+    seqs[3] = seqs[3][:-1]  # an odd length
+    seqs[5] = synth.join_contigs(seqs[5], 7, seed=3)
+    seqs.append(seqs[1][:777])
+    for model in (andi_amd.M_JC, andi_amd.M_LOGDET):
+        want = orc.dist_matrix(seqs, model=model, threads=0)
+        with knobs(QUERIES_PACKED=1):
+            assert (andi_amd.dist_matrix(seqs, model=model, host_threads=4) == want).all()
+        with knobs(QUERIES_BYTES=1):
+            assert (andi_amd.dist_matrix(seqs, model=model, host_threads=4, devices=[0, 0]) == want).all()
+        assert (andi_amd.dist_matrix(seqs, model=model, host_threads=4, devices=[0, 0, 0]) == want).all()
 
 
 _TRIM_SCRIPT = r"""
