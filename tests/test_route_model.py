@@ -37,6 +37,31 @@ def _suspected(subject: bytes, query: bytes, nsamples=512):
     return shorts, runs, runs > expect + 3 * np.sqrt(expect * (1 - f5)) + 3
 
 
+def _mean_match(subject: bytes, query: bytes):
+    """the mean of the 64 sampled longest matches (k_pair_estimate's first samples)"""
+    E = orc.OracleEsa(subject)
+    qlen = len(query)
+    total = 0
+    for i in range(64):
+        p = (2 * i + 1) * qlen // 128
+        total += E.get_match(query[p:p + 1100])[0]
+    E.close()
+    return total / 64
+
+
+def _small_call_verdict(shorts, runs, suspected, mean, nsamples=512):
+    """The same pair in a SMALL call (k_pair_estimate with route_all_few): where the mean sampled match is below 19, or the
+    rate of non-run short samples is 0.45 and more -- pairs some 4 % and more apart, which the first test cannot judge --
+    the pair is suspected only if its runs exceed what the rate of ALL short samples explains (an upper bound of f0);
+    returns (suspected, guessed)."""
+    if not (mean < 19 or (shorts - runs) >= 0.45 * nsamples):
+        return suspected, False
+    fa = shorts / nsamples
+    most = nsamples * fa ** 5
+    bad = runs > most + 3 * np.sqrt(most * (1 - fa ** 5)) + 3
+    return bad, not bad
+
+
 @pytest.mark.parametrize("d", [0.005, 0.02, 0.04, 0.05])
 def test_clean_pairs_are_not_suspected(d):
     """(up to some 5.5 % apart; beyond, f0 - f0^5 is flat, f0 comes out low and the pair is taken for suspicious: such pairs
@@ -51,3 +76,20 @@ def test_pairs_with_unrelated_stretches_are(d):
     seqs, _ = synth.realistic_set(2, 1_000_000, d / 2, d / 2 + 1e-9, seed=7 + int(d * 1e3))
     shorts, runs, bad = _suspected(seqs[0], seqs[1])
     assert bad, (d, shorts, runs)
+
+
+@pytest.mark.parametrize("d", [0.06, 0.08, 0.1])
+def test_small_calls_take_clean_pairs_far_apart_for_the_wavefront_kernel(d):
+    """Beyond 5.5 % the first test suspects every pair; a small call asks the second question, and clean pairs pass it
+    (marked as a guess: dropped again where the call has pairs with stretches clearly seen)."""
+    a, b = synth.pair(1_000_000, d, seed=int(d * 1e4))
+    shorts, runs, bad = _suspected(a, b)
+    small_bad, guessed = _small_call_verdict(shorts, runs, bad, _mean_match(a, b))
+    assert not small_bad and guessed, (d, shorts, runs, bad)
+
+
+def test_small_calls_still_see_stretches_in_pairs_moderately_far_apart():
+    seqs, _ = synth.realistic_set(2, 1_000_000, 0.03, 0.03 + 1e-9, seed=19)  # 6 % apart, 10 % unrelated sequence
+    shorts, runs, bad = _suspected(seqs[0], seqs[1])
+    small_bad, _ = _small_call_verdict(shorts, runs, bad, _mean_match(seqs[0], seqs[1]))
+    assert bad and small_bad, (shorts, runs)
