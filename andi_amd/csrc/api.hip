@@ -306,6 +306,7 @@ size_t andi_hip_trim(void) {
 	(void)hipGetDevice(&cur);
 	size_t freed = 0;
 	for (int d = 0; d < ndev && d < 64; ++d) {
+		if (!andi_arena::has_chunks(d)) continue; // (a device the library never used is not touched)
 		if (hipSetDevice(d) != hipSuccess) continue;
 		(void)hipDeviceSynchronize(); // (as hipFree: nothing in flight lies in a chunk that goes)
 		freed += andi_arena::trim(d);

@@ -145,6 +145,12 @@ inline bool keep_chunks() {
 	return !e || atoi(e) != 0;
 }
 
+inline bool has_chunks(int dev) {
+	Arena &A = of_device(dev);
+	std::lock_guard<std::mutex> lock(A.mu);
+	return !A.chunks.empty();
+}
+
 // the chunks of a device nobody holds a block of go back to the driver; returns the bytes given back
 inline size_t trim(int dev) {
 	Arena &A = of_device(dev);
