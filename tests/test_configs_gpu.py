@@ -197,7 +197,7 @@ def _sampled_pairs_against_oracle(orc, seqs, esas, subjects, got, pairs):
         assert (got[r, j] == want).all(), (subjects[r], j, got[r, j].tolist(), want.tolist())
 
 
-_NO_SCAN_SWITCH = dict(COOP=None, SCAN_G=None, UNIFORM_SEGMENTS=None, FORCE_ADAPTIVE=None, COOP_SEG=None, DEEP_K=None)
+_NO_SCAN_SWITCH = dict(COOP=None, UNIFORM_SEGMENTS=None, FORCE_ADAPTIVE=None, COOP_SEG=None, DEEP_K=None)
 
 
 def test_default_path_at_headline_length_against_the_oracle(orc):
@@ -251,3 +251,35 @@ def test_c4_shaped_call_at_full_length_against_the_oracle(orc):
             e.close()
         Q.close()
         c.close()
+
+
+def test_headline_set_every_ordered_pair_against_the_oracle(orc):
+    """BASELINE's 1-GPU config as bench.py runs it -- 29 genomes x 4.9 Mbp, d ~ U[0.0004, 0.03] from a common base, JC,
+    the same seed -- on the default path (no scan switch set; device suffix arrays, routed pass A): ALL 812 ordered pairs,
+    17 x u32 each, against the oracle's own matrix (its own suffix sorter: nothing of the product is fed to it).  bench.py
+    makes the same comparison after its timed region (`parity_vs_cpu_baseline`); round 4's verdict asked for it in the
+    suite."""
+    import os
+    import andi_amd
+    from andi_amd import synth
+    from conftest import knobs
+    seqs, _ = synth.genome_set(29, 4_900_000, 0.0004, 0.03, seed=1729)
+    want = orc.dist_matrix(seqs, model=orc.M_JC, threads=min(29, os.cpu_count() or 1))
+    with knobs(**_NO_SCAN_SWITCH):
+        c = andi_amd.Context(0)
+        c.expect_queries(len(seqs) - 1)
+        Q = andi_amd.Queries(c, seqs)
+        esas = [andi_amd.Esa(c, s, sa="device") for s in seqs]
+        c.timings_reset()
+        got = andi_amd.scan_rows(c, esas, list(range(len(seqs))), Q)
+        t = c.timings()
+        assert t["scan_pairs"] == 812 and t["fixups"] == 0
+        assert t["routed_calls"] == 1 and t["coop_query_nt"] > 0, t
+        bad = np.argwhere((got != want).any(axis=2))
+        assert len(bad) == 0, bad[:8]
+        for e in esas:
+            e.close()
+        Q.close()
+        c.close()
+    # and the one-call seam on the same set
+    assert (andi_amd.dist_matrix(seqs, model=andi_amd.M_JC) == want).all()

@@ -19,3 +19,15 @@ def test_random_cases_against_the_oracle():
     assert "all equal to the oracle" in tail, tail
     cases = int(tail.split("fuzz:")[1].split("cases")[0])
     assert cases >= 50, tail
+
+
+def test_random_routed_large_calls():
+    """A minute of scripts/fuzz_large.py: calls of the size at which pass A is routed per pair (10-14 genomes of 3-5 Mbp:
+    star, tree, structured, close, joined, both strands, mixed) -- the call as it comes, the lane scan and the forced
+    wavefront kernel agree bit for bit and a sampled subject row equals the oracle's."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_large.py"), "60", "4712"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    tail = "\n".join(r.stdout.splitlines()[-5:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    assert "all equal" in tail, tail
+    assert int(tail.split("fuzz_large:")[1].split("cases")[0]) >= 3, tail

@@ -155,3 +155,54 @@ def test_estimators_edge_cases(orc):
     raw = 10 / 110
     assert orc.estimate(m, orc.M_RAW) == raw
     assert orc.estimate(m, orc.M_JC) == -0.75 * np.log(1.0 - (4.0 / 3.0) * raw)
+
+
+# ---- the reference's shell tests that hold an expectation for dist_anchor + the estimators: pinned on
+# the ORACLE here (tests/test_cli.py holds the product's CLI to the same expectations on the GPU box).  The reference's
+# scripts draw random seeds (RANDOM_SEED unset => test_fasta -s 0 = a seed from the clock), so the expectation holds
+# for ANY seed; three seeds each, sequences from andi_amd/synth.py (the generator's model, test/test_fasta.cxx:73-118).
+def _tf(length, seed, d=0.1):
+    """`test_fasta -s seed -l length -d d`: S0 (the base) and S1 (d substitutions per site from it)."""
+    from andi_amd import synth
+    return synth.pair(length, d, seed=seed)
+
+
+def _raw(orc, a, b):
+    M = orc.dist_matrix([a, b], model=orc.M_RAW, threads=2)
+    return orc.estimate(M[0, 1].astype(np.uint64) + M[1, 0], orc.M_RAW), M
+
+
+@pytest.mark.parametrize("seed", [1, 23, 777])
+def test_join_three_and_two_contigs(orc, seed):
+    # test/test_join.sh:15-38: three contigs (1000, 1000, 10000 nt) per genome, joined by -j ('!'): RAW within 0.03 of 0.1
+    p1, p2, p3 = _tf(1000, seed), _tf(1000, seed + 2), _tf(10000, seed + 3)
+    d, _ = _raw(orc, b"!".join(p[0] for p in (p1, p2, p3)), b"!".join(p[1] for p in (p1, p2, p3)))
+    assert abs(d - 0.1) < 0.03, d
+    # test/test_join.sh:46-67: unbalanced -- one contig against two, the extra contig (1000 nt) has no partner
+    p2, p3 = _tf(1000, seed + 5), _tf(10000, seed + 6)
+    d, _ = _raw(orc, p3[0], b"!".join((p2[1], p3[1])))
+    assert abs(d - 0.1) < 0.03, d
+    # test/test_join.sh:69-96: unbalanced 2 -- two contigs against three
+    p1, p2, p3 = _tf(1000, seed + 11), _tf(1000, seed + 12), _tf(10000, seed + 13)
+    d, _ = _raw(orc, b"!".join((p1[0], p3[0])), b"!".join((p1[1], p2[1], p3[1])))
+    assert abs(d - 0.1) < 0.03, d
+
+
+@pytest.mark.parametrize("seed", [1, 23, 777])
+def test_unrelated_sequences_give_nan(orc, seed):
+    # test/nan.sh:11-25: two files of unrelated 10 kbp sequences, joined per file: "reported as nan" (src/io.c:282-289)
+    a, b = _tf(10000, seed), _tf(10000, seed + 1)
+    M = orc.dist_matrix([b"!".join(a), b"!".join(b)], model=orc.M_JC, threads=2)
+    assert np.isnan(orc.estimate(M[0, 1].astype(np.uint64) + M[1, 0], orc.M_JC))
+
+
+@pytest.mark.parametrize("seed", [1, 23, 777])
+def test_low_homology_is_below_the_warning_line(orc, seed):
+    # test/low_homo.sh:12-29: 100 homologous nt in front of 100 kbp of unrelated sequence per genome: the distance is a
+    # number or nan, and where it is a number a coverage is below 0.2 (the warning's condition, src/io.c:291-303)
+    a, b, both = _tf(100000, seed), _tf(100000, seed + 1), _tf(100, seed + 2)
+    s0, s1 = both[0] + b"!" + a[0], both[1] + b"!" + b[1]
+    M = orc.dist_matrix([s0, s1], model=orc.M_JC, threads=2)
+    d = orc.estimate(M[0, 1].astype(np.uint64) + M[1, 0], orc.M_JC)
+    assert np.isnan(d) or orc.coverage(M[0, 1]) < 0.2 or orc.coverage(M[1, 0]) < 0.2
+    assert orc.coverage(M[0, 1]) < 0.2 and orc.coverage(M[1, 0]) < 0.2
