@@ -251,6 +251,13 @@ struct Timed {
 		ok = false;
 		if (ctx->pending.size() > 256) resolve_events(ctx);
 	}
+	~Timed() { // an error exit before stop(): the events go with the timer
+		if (!ok) return;
+		(void)hipEventDestroy(ev.a);
+		(void)hipEventDestroy(ev.b);
+	}
+	Timed(const Timed &) = delete;
+	Timed &operator=(const Timed &) = delete;
 };
 
 EsaDev esa_view(const andi_hip_esa *e, int mode) {
@@ -298,6 +305,7 @@ int andi_hip_abi_version(void) {
 }
 
 size_t andi_hip_trim(void) {
+	if (!andi_arena::any_chunks()) return 0; // (a process that never used the library's device memory: no HIP call at all)
 	int ndev = 0, cur = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess) {
 		(void)hipGetLastError();
@@ -308,7 +316,6 @@ size_t andi_hip_trim(void) {
 	for (int d = 0; d < ndev && d < 64; ++d) {
 		if (!andi_arena::has_chunks(d)) continue; // (a device the library never used is not touched)
 		if (hipSetDevice(d) != hipSuccess) continue;
-		(void)hipDeviceSynchronize(); // (as hipFree: nothing in flight lies in a chunk that goes)
 		freed += andi_arena::trim(d);
 	}
 	(void)hipSetDevice(cur);
@@ -541,7 +548,7 @@ static int esa_sort_suffixes(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!e->rec && !andi_knob(KNOB_NO_SORTED_RECORDS)) { // (experiments: the index build then gathers from the text, as with a host-made suffix array)
 		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec, (e->cap + 8) * sizeof(uint32_t)));
 		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec2, (e->cap + 8) * sizeof(uint16_t)));
-		e->bytes += (e->cap + 8) * sizeof(uint32_t);
+		e->bytes += (e->cap + 8) * (sizeof(uint32_t) + sizeof(uint16_t));
 	}
 	const auto t0 = std::chrono::steady_clock::now();
 	int rounds = 0;
@@ -1176,7 +1183,9 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		for (size_t i = 0; i < q->nq; ++i) used += (q->len[i] + (uint64_t)seg0 - 1) / seg0;
 		used *= nsub;
 		size_t free_b = 0, total_b = 0;
-		const size_t want_b = (size_t)64 * max_waves * ANDI_SLOT_BYTES;
+		// (a routed call may need a second lane layout as large as the first for the pairs handed back: counted here, so that
+		// a call that fits keeps fitting when that happens)
+		const size_t want_b = (size_t)64 * max_waves * ANDI_SLOT_BYTES * (routed ? 2 : 1);
 		const bool fits = max_waves < (1u << 26) && // (the device is asked only when the scratch would have to grow)
 						  (want_b <= ctx->scratch_bytes || hipMemGetInfo(&free_b, &total_b) != hipSuccess || want_b < free_b / 2 + ctx->scratch_bytes);
 		if (!fits || (10 * used < 7 * 64 * max_waves && !andi_knob(KNOB_FORCE_ADAPTIVE))) adaptive = false, max_waves = 0;
@@ -1285,12 +1294,20 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
 		carve(b, slots2);
 		hipError_t e;
+		// every error exit below first waits for the streams this branch forks work onto: their kernels read the scratch
+		// the next call may regrow, and the context's teardown waits for ctx->stream only
+		auto bail = [&](const char *what, hipError_t err) {
+			(void)hipStreamSynchronize(ctx->coop_stream);
+			(void)hipStreamSynchronize(ctx->side_stream);
+			(void)hipStreamSynchronize(ctx->stream);
+			return fail(ctx, what, err);
+		};
 		{
 			Timed t(ctx, 2);
 			e = hipMemsetAsync(b.restitch_count, 0, 16 * sizeof(uint32_t), ctx->stream);
 			if (e == hipSuccess) e = andi_launch_pair_layout(a, ctx->stream);
 			t.stop();
-			if (e != hipSuccess) return fail(ctx, "scan layout", e);
+			if (e != hipSuccess) return bail("scan layout", e);
 		}
 		if (andi_knob(KNOB_DEBUG_STITCH)) { // diagnostics: how the pairs were routed
 			std::vector<uint8_t> cls(pairs_all);
@@ -1325,7 +1342,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->coop_join, 0);
 			if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_any_left, b.restitch_count + ANDI_ROUTE_ANY_LEFT, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
 			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-			if (e != hipSuccess) return fail(ctx, "scan pass A", e);
+			if (e != hipSuccess) return bail("scan pass A", e);
 			any_left = ctx->h_any_left[0] != 0;
 			const bool any_lanes = ctx->h_any_left[1] != 0; // (no pair in the lane layout: its passes B and C have nothing to do)
 			ScanArgs a2 = a;
@@ -1334,7 +1351,8 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 				if (ctx->scratch2_bytes < need2) {
 					if (ctx->scratch2) (void)andi_arena::dev_free(ctx->scratch2);
 					ctx->scratch2 = nullptr, ctx->scratch2_bytes = 0;
-					HIP_TRY(ctx, andi_arena::dev_malloc(&ctx->scratch2, need2));
+					e = andi_arena::dev_malloc(&ctx->scratch2, need2);
+					if (e != hipSuccess) return bail("scratch of the second lane layout", e);
 					ctx->scratch2_bytes = need2;
 				}
 				p = (char *)ctx->scratch2;
@@ -1368,7 +1386,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			if (e == hipSuccess && any_left) e = hipStreamWaitEvent(ctx->stream, ctx->l2_join, 0);
 			if (e == hipSuccess) e = andi_launch_route_count(a, ctx->stream);
 			t2.stop();
-			if (e != hipSuccess) return fail(ctx, "scan passes B/C", e);
+			if (e != hipSuccess) return bail("scan passes B/C", e);
 		}
 		ctx->acc.coop_calls++;
 		ctx->acc.routed_calls++;

@@ -10,8 +10,8 @@
 // One arena per device, shared by the contexts on it.  The chunks outlive the contexts (round 4): a process that calls
 // the seam again finds them -- on some boxes of the pool a fresh hipMalloc of the 6.5 GB a 29-genome job takes costs
 // 0.3 s (the driver clears what it hands out), every call, which was three quarters of the seam's wall time there;
-// andi_hip_trim() gives the unused chunks back, ANDI_ARENA_KEEP=0 releases them with a device's last context as
-// before.  Freeing waits for the device like hipFree does, so a block is never handed out again while a kernel may
+// andi_hip_trim() gives the unused chunks back (the Python binding calls it at exit); at most ANDI_ARENA_KEEP MiB
+// (default 8192) stay behind a device's last context, 0 releases everything as before.  Freeing waits for the device like hipFree does, so a block is never handed out again while a kernel may
 // still use it.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -140,9 +140,10 @@ inline void retain(int dev) {
 	++A.contexts;
 }
 
-inline bool keep_chunks() {
+inline size_t keep_bytes() { // ANDI_ARENA_KEEP: MiB of unused chunks that outlive a device's last context (1: the default, 8192)
 	const char *e = andi_knob(KNOB_ARENA_KEEP);
-	return !e || atoi(e) != 0;
+	const long mb = e ? atol(e) : 8192;
+	return mb == 1 ? (size_t)8192 << 20 : mb > 0 ? (size_t)mb << 20 : (size_t)0;
 }
 
 inline bool has_chunks(int dev) {
@@ -151,19 +152,35 @@ inline bool has_chunks(int dev) {
 	return !A.chunks.empty();
 }
 
+inline bool any_chunks() {
+	for (int d = 0; d < 64; ++d)
+		if (has_chunks(d)) return true;
+	return false;
+}
+
 // the chunks of a device nobody holds a block of go back to the driver; returns the bytes given back
+// (the device must be current.  The chunks leave the arena under its lock; the wait for the device and the hipFrees --
+// slow calls -- happen outside it, so that other contexts' allocations are not held up)
 inline size_t trim(int dev) {
 	Arena &A = of_device(dev);
-	std::lock_guard<std::mutex> lock(A.mu);
-	size_t freed = 0;
-	for (size_t i = 0; i < A.chunks.size();) {
-		if (A.chunks[i].used == 0) {
-			freed += A.chunks[i].size;
-			(void)hipFree(A.chunks[i].base);
-			A.chunks.erase(A.chunks.begin() + (long)i);
-		} else {
-			++i;
+	std::vector<Chunk> gone;
+	{
+		std::lock_guard<std::mutex> lock(A.mu);
+		for (size_t i = 0; i < A.chunks.size();) {
+			if (A.chunks[i].used == 0) {
+				gone.push_back(std::move(A.chunks[i]));
+				A.chunks.erase(A.chunks.begin() + (long)i);
+			} else {
+				++i;
+			}
 		}
+	}
+	if (gone.empty()) return 0;
+	(void)hipDeviceSynchronize(); // (as hipFree: nothing in flight lies in a chunk that goes)
+	size_t freed = 0;
+	for (Chunk &c : gone) {
+		freed += c.size;
+		(void)hipFree(c.base);
 	}
 	return freed;
 }
@@ -173,12 +190,16 @@ inline void release(int dev) {
 	std::lock_guard<std::mutex> lock(A.mu);
 	if (--A.contexts > 0) return;
 	A.contexts = 0;
-	if (keep_chunks()) return; // (andi_hip_trim, or the process's end)
+	// What stays with the arena after a device's last context (andi_hip_trim or the process's end releases it): at most
+	// ANDI_ARENA_KEEP MiB (default 8192 -- the 6.5 GB of a 29-genome job, whose hipMalloc costs 0.3 s per call on some
+	// boxes; 0: nothing); a large job's memory goes back to the driver with its last context
+	size_t keep = keep_bytes(), kept = 0;
 	for (size_t i = 0; i < A.chunks.size();) {
-		if (A.chunks[i].used == 0) {
+		if (A.chunks[i].used == 0 && kept + A.chunks[i].size > keep) {
 			(void)hipFree(A.chunks[i].base);
 			A.chunks.erase(A.chunks.begin() + (long)i);
 		} else {
+			if (A.chunks[i].used == 0) kept += A.chunks[i].size;
 			++i;
 		}
 	}

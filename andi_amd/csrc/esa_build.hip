@@ -610,7 +610,10 @@ size_t andi_min_tree_entries(int32_t n) {
 int andi_index_single_ext(size_t queries, bool sorted_on_device) { // queries: how many the subject is going to meet (0: unknown)
 	const int coop = andi_coop_enabled();
 	if (coop == 0) return 0;
-	if (const char *f = andi_knob(KNOB_SINGLE_EXT)) return atoi(f); // (experiments: 0, 1, 2)
+	if (const char *f = andi_knob(KNOB_SINGLE_EXT)) { // (experiments: 0, 1, 2; anything else is ignored -- the scan decodes an entry by the form its handle records)
+		const int v = atoi(f);
+		if (v >= 0 && v <= 2 && (v != 2 || sorted_on_device)) return v;
+	}
 	// Pass A by wavefronts reads them: a chance occurrence of a K-mer off the window's diagonal is then settled by the
 	// entry instead of a look at the text with the parked lanes (bench set: pass A 4.95 -> 4.71 ms).  Four symbols settle
 	// all but one chance occurrence in 256 -- pass A is as fast as with thirteen (bench set 4.71 / 4.67 ms, C4 shape

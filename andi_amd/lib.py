@@ -147,6 +147,8 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        import atexit
+        atexit.register(L.andi_hip_trim)  # the arena's retained chunks go back before the interpreter is torn down
     return _lib
 
 
