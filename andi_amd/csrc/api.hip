@@ -126,6 +126,8 @@ struct andi_hip_ctx {
 	hipStream_t coop_stream = nullptr; // routed scan calls: pass A by wavefronts runs beside the lane scan's kernels
 	hipEvent_t coop_fork = nullptr, coop_join = nullptr, l2_fork = nullptr, l2_join = nullptr;
 	uint32_t *h_any_left = nullptr;    // pinned: [0] the wavefront kernel handed some pair back, [1 ... 6] the layout's counters (restitch_count[ANDI_LANE_WAVES ...]: [1] wavefronts of the lane layout)
+	void *pool_scratch = nullptr;      // pass A by wavefronts with pooled walks (coop_pool.h): a scratch per resident wavefront
+	uint32_t pool_waves = 0;
 	void *scratch2 = nullptr;          // the second lane layout (those pairs), grown on demand
 	size_t scratch2_bytes = 0;
 	unsigned long long *d_route = nullptr; // routed scan calls: query nucleotides whose pass A ran by wavefronts / by lanes, pairs handed back (read with the timings)
@@ -422,6 +424,7 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->h_quad_waves) (void)hipHostFree(ctx->h_quad_waves);
 	if (ctx->d_route) (void)andi_arena::dev_free(ctx->d_route);
 	if (ctx->scratch2) (void)andi_arena::dev_free(ctx->scratch2);
+	if (ctx->pool_scratch) (void)andi_arena::dev_free(ctx->pool_scratch);
 	if (ctx->h_any_left) (void)hipHostFree(ctx->h_any_left);
 	if (ctx->coop_stream) {
 		(void)hipStreamSynchronize(ctx->coop_stream);
@@ -1265,6 +1268,16 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		a.knock = kn ? (uint32_t)atoi(kn) : 0u;
 	}
 	a.coop = coop && !a.adaptive;
+	a.pool_scratch = nullptr, a.pool_ticket = nullptr, a.pool_waves = 0;
+	if ((a.coop || routed) && model != ANDI_M_LOGDET && model != ANDI_M_ANI) { // pooled walks: the scratch of the resident wavefronts, once per context
+		if (!ctx->pool_scratch) {
+			uint32_t waves = 0;
+			const size_t bytes = andi_pool_scratch_bytes(ctx->device, &waves);
+			if (bytes && andi_arena::dev_malloc(&ctx->pool_scratch, bytes) == hipSuccess) ctx->pool_waves = waves;
+			else (void)hipGetLastError(), ctx->pool_scratch = nullptr; // (no room, or switched off: the windows stay in LDS)
+		}
+		if (ctx->pool_scratch) a.pool_ticket = (uint32_t *)ctx->pool_scratch, a.pool_scratch = (char *)ctx->pool_scratch + 256, a.pool_waves = ctx->pool_waves;
+	}
 	a.route = routed ? ANDI_LAYOUT_LANES : 0, a.route_seg = coop_seg, a.route_nt = ctx->d_route;
 	uint32_t longest_q = 0;
 	for (size_t i = 0; i < q->nq; ++i) longest_q = std::max(longest_q, (uint32_t)q->len[i]);

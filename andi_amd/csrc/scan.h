@@ -110,6 +110,12 @@ struct ScanArgs {
 	uint32_t route_giveup;        // generic steps in one of its segments beyond which a wavefront hands its pair back (scan_coop.hip: COOP_TRIAL_G; ANDI_COOP_GIVEUP: tests)
 	unsigned long long *route_nt; // [3]: query nucleotides of the pairs whose pass A ran by wavefronts / by lanes, pairs handed back
 	int coop;            // pass A with one wavefront per chain (scan_coop.hip): one segment length, RAW/JC/Kimura, probe-table subjects
+	// ... with the windows' walks pooled through global memory (coop_pool.h: k_pool_cold; the models that split an anchor's length
+	// evenly): a scratch per resident wavefront, pool_waves of them; pool_ticket: the next segment to take (zeroed per launch)
+	void *pool_scratch;
+	uint32_t *pool_ticket;
+	uint32_t pool_waves;
+	uint32_t pool_first; // rounds of 2048 positions of a chain's first window (doubled after every window the chain got through)
 	uint32_t knock;      // diagnostic builds (-DANDI_LANE_STATS): parts of pass A switched off to time them (results are then wrong)
 };
 
@@ -128,6 +134,7 @@ hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 // pass A with one wavefront per chain (scan_coop.hip)
 int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: the engine chooses -- tiny calls every pair, others routed per pair (the default); n = 2, 4, 8: every pair, windows of 2048 n symbols
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st);
+size_t andi_pool_scratch_bytes(int device, uint32_t *waves); // the pooled kernel's scratch (256 bytes for the ticket in front); 0: that kernel is off (ANDI_POOL=0)
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStream_t st); // k_lane_quad, one wavefront per block (scan_lane.hip compiled a second time)
 // Pass B again for the segments that were entered in a state their predecessor's true chain did not leave in (a true

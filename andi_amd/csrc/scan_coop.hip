@@ -283,24 +283,16 @@ __device__ __forceinline__ uint32_t squeeze_codes(uint32_t x) {
 // together (a path one lane in ten takes is otherwise executed on nine trips in ten).
 // (on_diag: the K-mer occurs once, at p + dg -- on the window's diagonal: the match is the run of equal symbols the bits show)
 // (multi_x, multi_n, multi_q: the K-mer occurs multi_n <= 4 times, at SA[multi_x ...]; multi_q = the 16 symbols behind it)
-template <int NCH>
-__device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<NCH> &L, uint32_t wbase, bool clean, uint32_t p, uint32_t sd, Probe &r, bool &on_diag,
-												uint32_t &multi_x, uint32_t &multi_n, uint32_t &multi_q) {
-	on_diag = false, multi_n = 0;
+// (the part behind the query symbols: lo = the 16 symbols from p on as 2-bit codes, first in the low bits; hi = the next 16)
+__device__ __forceinline__ bool coop_probe_codes(const PairCtx &c, uint32_t p, uint32_t sd, uint32_t lo, uint32_t hi, Probe &r, bool &on_diag,
+												 uint32_t &multi_x, uint32_t &multi_n, uint32_t &multi_q) {
 	const EsaG &E = c.E;
-	const uint32_t K = (uint32_t)E.deepK, qrem = c.qlen - p, o = p - wbase;
+	const uint32_t K = (uint32_t)E.deepK, qrem = c.qlen - p;
 #ifdef ANDI_COOP_STATS
 #define WHY(k) atomicAdd(&g_coop_stats[k], 1ull)
 #else
 #define WHY(k) ((void)0)
 #endif
-	if (!(clean && o + 32 <= 2048 * NCH && p + 32 <= c.qlen)) {
-		WHY(CS_WHY_PRE);
-		return false;
-	}
-	const uint32_t j = o >> 4, sh = 2 * (o & 15u);
-	const uint32_t w0 = L.q2[j], w1 = L.q2[j + 1], w2 = L.q2[j + 2];
-	const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
 	uint32_t y = __brev(lo); // first symbol on top, the bits of a pair swapped
 	y = ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
 	const uint32_t code = y >> (32 - 2 * K);
@@ -343,6 +335,20 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 		return false; // all that could be compared matches: the occurrence has to be followed
 	}
 	return true;
+}
+
+template <int NCH>
+__device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<NCH> &L, uint32_t wbase, bool clean, uint32_t p, uint32_t sd, Probe &r, bool &on_diag,
+												uint32_t &multi_x, uint32_t &multi_n, uint32_t &multi_q) {
+	on_diag = false, multi_n = 0;
+	const uint32_t o = p - wbase;
+	if (!(clean && o + 32 <= 2048 * NCH && p + 32 <= c.qlen)) {
+		WHY(CS_WHY_PRE);
+		return false;
+	}
+	const uint32_t j = o >> 4, sh = 2 * (o & 15u);
+	const uint32_t w0 = L.q2[j], w1 = L.q2[j + 1], w2 = L.q2[j + 2];
+	return coop_probe_codes(c, p, sd, __builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh), r, on_diag, multi_x, multi_n, multi_q);
 }
 
 // The probe of a parked lane whose K-mer occurs n <= 4 times (at SA[x ...]): the longest match is the best of the
@@ -392,8 +398,8 @@ __device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, u
 }
 
 // the record of an anchor (scan.h: the cold chain's first anchor, the state and counts right after its second)
-template <int NCH>
-__device__ __forceinline__ void coop_note_anchor(const ScanArgs &a, size_t slot, Chain &ch, const CoopLds<NCH> &L) {
+template <class LDS>
+__device__ __forceinline__ void coop_note_anchor(const ScanArgs &a, size_t slot, Chain &ch, const LDS &L) {
 	const uint32_t lane = __lane_id();
 	ColdMark *m = a.marks + slot * ANDI_COLD_MARKS;
 	++ch.anchors;
@@ -415,8 +421,8 @@ __device__ __forceinline__ void coop_note_anchor(const ScanArgs &a, size_t slot,
 }
 
 // What an anchor at subject offset curS found at query offset st.p does to the counts (src/process.c:157-190)
-template <int NCH, bool EXACT>
-__device__ __forceinline__ void coop_account(const PairCtx &c, Chain &ch, CoopLds<NCH> &L, uint32_t curS) {
+template <bool EXACT, class LDS>
+__device__ __forceinline__ void coop_account(const PairCtx &c, Chain &ch, LDS &L, uint32_t curS) {
 	ChainState &st = ch.st;
 	const uint32_t endS = st.lastS + st.lastLen, endQ = st.lastQ + st.lastLen;
 	auto count_last = [&]() { // model_count_equal of the last anchor
@@ -930,6 +936,8 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	return true;
 }
 
+#include "coop_pool.h"
+
 // ------------------------------------------------------------------ the kernel
 template <int NCH, bool EXACT>
 #ifndef COOP_OCC
@@ -1007,7 +1015,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 			found = (v >> 31) && curLen >= thr;
 		}
 		if (found) {
-			coop_account<NCH, EXACT>(c, ch, L, curS);
+			coop_account<EXACT>(c, ch, L, curS);
 			st.lastS = curS, st.lastQ = st.p, st.lastLen = curLen;
 		}
 		st.p += curLen + 1;
@@ -1059,9 +1067,34 @@ int andi_coop_enabled(void) {
 	return 4;
 }
 
+static bool pool_enabled() { // ANDI_POOL=0: the windows stay in LDS (coop_window), as up to round 4
+	const char *e = andi_knob(KNOB_POOL);
+	return !e || atoi(e) != 0;
+}
+
+size_t andi_pool_scratch_bytes(int device, uint32_t *waves) {
+	*waves = 0;
+	if (!pool_enabled()) return 0;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+	*waves = (uint32_t)prop.multiProcessorCount * 4u * POOL_OCC;
+	return 256 + (size_t)*waves * sizeof(PoolScratch);
+}
+
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one segment length for the call, RAW/JC/Kimura
 	const dim3 grid((a.total_segs + COOP_WAVES - 1) / COOP_WAVES, a.nsub);
 	const int nch = andi_coop_enabled();
+	const bool pooled = !a.exact_equal && a.pool_scratch && a.pool_waves && pool_enabled() && (nch < 0 || nch == 4);
+	if (pooled) { // the windows' walks pooled through global memory: persistent wavefronts take the segments in order
+		hipError_t e = hipMemsetAsync(a.pool_ticket, 0, sizeof(uint32_t), st);
+		if (e != hipSuccess) return e;
+		const uint64_t items = (uint64_t)a.total_segs * a.nsub;
+		ScanArgs b = a;
+		b.pool_first = 16;
+		if (const char *pf = andi_knob(KNOB_POOL_FIRST)) // (experiments)
+			if (atoi(pf) >= 1 && atoi(pf) <= (int)(POOL_MW / 2048u)) b.pool_first = (uint32_t)atoi(pf);
+		k_pool_cold<<<(uint32_t)(items < a.pool_waves ? items : a.pool_waves), 64, 0, st>>>(b);
+	} else
 	switch (nch < 0 ? -nch : nch) {
 		case 2: a.exact_equal ? k_coop_cold<2, true><<<grid, 64 * COOP_WAVES, 0, st>>>(a) : k_coop_cold<2, false><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 		case 8: a.exact_equal ? k_coop_cold<8, true><<<grid, 64 * COOP_WAVES, 0, st>>>(a) : k_coop_cold<8, false><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;

@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
             calls[k][row["Counter_Name"]] += 1
 for k in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", 0)):
-    if not any(s in k for s in ("k_scan", "k_coop", "k_lane", "k_rounds", "k_pair", "k_pack", "k_suffix", "k_probe", "k_child", "k_plcp", "k_lcp", "k_phi", "k_kmer", "k_min")):
+    if not any(s in k for s in ("k_scan", "k_coop", "k_pool", "k_lane", "k_rounds", "k_pair", "k_pack", "k_suffix", "k_probe", "k_child", "k_plcp", "k_lcp", "k_phi", "k_kmer", "k_min")):
         continue
     print("==", k)
     for c in sorted(acc[k]):
