@@ -45,6 +45,7 @@ struct EsaDev {
 	const uint2 *deep;
 	const int32_t *flags;
 	const uint8_t *N0, *N1; // nibble-packed text, two alignments (scan_lane.hip)
+	const uint32_t *P;      // the text bit-sliced (coop_pool.h): block b = words 3b, 3b+1, 3b+2 = bit 0, 1, 2 of the symbols 32b ... 32b+31; a block of padding in front
 	int32_t n;
 	int32_t thr;
 	int32_t deepK;
@@ -68,6 +69,7 @@ typedef ANDI_GLOBAL const uint8_t *g_u8p;
 typedef ANDI_GLOBAL const int32_t *g_i32p;
 typedef ANDI_GLOBAL const int4 *g_i4p;
 typedef ANDI_GLOBAL const uint2 *g_u2p;
+typedef ANDI_GLOBAL const uint32_t *g_u32p;
 
 struct EsaG {
 	g_u8p S;
@@ -76,6 +78,7 @@ struct EsaG {
 	g_i4p tab;
 	g_u2p deep;
 	g_u8p N0, N1;
+	g_u32p P;
 	int32_t n, thr, deepK, mode, deep_ext;
 };
 
@@ -85,6 +88,7 @@ __device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
 	g.FVC = (g_u8p)e.FVC, g.tab = (g_i4p)e.tab;
 	g.deep = (g_u2p)e.deep;
 	g.N0 = (g_u8p)e.N0, g.N1 = (g_u8p)e.N1;
+	g.P = (g_u32p)e.P;
 	g.n = e.n, g.thr = e.thr, g.deepK = e.deepK, g.mode = e.mode, g.deep_ext = e.deep_ext;
 	return g;
 }

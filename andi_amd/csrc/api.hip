@@ -127,6 +127,7 @@ struct andi_hip_ctx {
 	hipEvent_t coop_fork = nullptr, coop_join = nullptr, l2_fork = nullptr, l2_join = nullptr;
 	uint32_t *h_any_left = nullptr;    // pinned: [0] the wavefront kernel handed some pair back, [1 ... 6] the layout's counters (restitch_count[ANDI_LANE_WAVES ...]: [1] wavefronts of the lane layout)
 	void *pool_scratch = nullptr;      // pass A by wavefronts with pooled walks (coop_pool.h): a scratch per resident wavefront
+	size_t pool_bytes = 0;
 	uint32_t pool_waves = 0;
 	void *scratch2 = nullptr;          // the second lane layout (those pairs), grown on demand
 	size_t scratch2_bytes = 0;
@@ -144,6 +145,7 @@ struct andi_hip_esa {
 	uint2 *deep = nullptr;
 	uint8_t *Nraw = nullptr;              // 4-bit symbols for the lane scan: N0 and N1 with their padding
 	uint8_t *N0 = nullptr, *N1 = nullptr;
+	uint32_t *Praw = nullptr, *P = nullptr; // the text bit-sliced (EsaDev.P; packed from N0 when a scan call wants it), a block of padding in front
 	uint32_t *rec = nullptr;    // the suffixes' records in suffix-array order, left by the device sorter (sa_device.hip) for the index build
 	bool rec_valid = false;
 	uint16_t *rec2 = nullptr;   // ... and the symbols behind their first deepK (same validity)
@@ -164,6 +166,7 @@ struct andi_hip_esa {
 struct andi_hip_queries {
 	uint8_t *pool = nullptr;
 	uint8_t *nib = nullptr;       // the pool as 4-bit symbols
+	uint32_t *planes = nullptr;   // ... bit-sliced (EsaDev.P)
 	int32_t *h_foreign = nullptr; // pinned: set if the pool holds bytes outside the alphabet
 	uint64_t *d_off = nullptr;
 	uint32_t *d_len = nullptr;
@@ -266,7 +269,7 @@ EsaDev esa_view(const andi_hip_esa *e, int mode) {
 	EsaDev v;
 	v.S = e->S, v.SA = e->SA, v.LCP = e->LCP, v.CLD = e->CLD, v.FVC = e->FVC, v.tab = e->tab;
 	v.deep = e->deep, v.flags = e->flags;
-	v.N0 = e->N0, v.N1 = e->N1;
+	v.N0 = e->N0, v.N1 = e->N1, v.P = e->P;
 	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.mode = mode, v.deep_ext = e->deep_ext;
 	return v;
 }
@@ -497,6 +500,14 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	if (err == hipSuccess) {
 		e->N0 = e->Nraw + ANDI_NIB_FRONT, e->N1 = e->Nraw + ANDI_NIB_FRONT + nib_part + ANDI_NIB_FRONT;
 		chk(hipMemsetAsync(e->Nraw, 0x77, 2 * (ANDI_NIB_FRONT + nib_part), ctx->stream));
+	}
+	{ // the text bit-sliced: 12 bytes per 32 symbols, a block in front, the padding all ones (NUL symbols)
+		const size_t blocks = (cap + 1 + 4096) / 32 + 4;
+		chk(dmalloc(&e->Praw, 3 * blocks));
+		if (err == hipSuccess) {
+			e->P = e->Praw + 3;
+			chk(hipMemsetAsync(e->Praw, 0xff, 3 * blocks * sizeof(uint32_t), ctx->stream));
+		}
 	}
 	// flags: pinned host memory the kernels write directly (rare, idempotent plain stores) --
 	// no per-build memset or copy; the host reads them after a stream synchronisation
@@ -751,7 +762,7 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	if (!e) return;
 	if (ctx) (void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize(); // once for the handle's ten buffers: nothing in flight uses them when they are handed out again
-	void *bufs[] = {e->S, e->SA, e->LCP, e->CLD, e->FVC, e->tab, e->deep, e->Nraw, e->rec, e->rec2, e->min_scratch};
+	void *bufs[] = {e->S, e->SA, e->LCP, e->CLD, e->FVC, e->tab, e->deep, e->Nraw, e->Praw, e->rec, e->rec2, e->min_scratch};
 	for (void *b : bufs) (void)andi_arena::dev_free(b, false);
 	if (e->h_flags) (void)hipHostFree(e->h_flags);
 	delete e;
@@ -792,6 +803,7 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 	};
 	chk(dmalloc(&q->pool, pool_bytes));
 	chk(dmalloc(&q->nib, pool_bytes / 2 + 64));
+	chk(dmalloc(&q->planes, 3 * (pool_bytes / 32) + 16));
 	chk(hipHostMalloc((void **)&q->h_foreign, sizeof(int32_t), hipHostMallocDefault));
 	int32_t *d_foreign = nullptr;
 	chk(dmalloc(&d_foreign, 1));
@@ -809,6 +821,7 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 	if (err == hipSuccess) err = hipMemsetAsync(d_foreign, 0, sizeof(int32_t), ctx->stream);
 	if (err == hipSuccess)
 		err = andi_launch_pack_symbols(q->pool, pool_bytes, q->nib, nullptr, d_foreign, ctx->stream);
+	if (err == hipSuccess) err = andi_launch_pack_planes(q->nib, pool_bytes, q->planes, ctx->stream);
 	if (err == hipSuccess)
 		err = hipMemcpyAsync(q->h_foreign, d_foreign, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
 	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
@@ -826,7 +839,7 @@ void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q) {
 	if (!q) return;
 	if (ctx) (void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize();
-	void *bufs[] = {q->pool, q->nib, q->d_off, q->d_len, q->d_qseg_start, q->d_seg2query, q->c_qseg_start, q->c_seg2query};
+	void *bufs[] = {q->pool, q->nib, q->planes, q->d_off, q->d_len, q->d_qseg_start, q->d_seg2query, q->c_qseg_start, q->c_seg2query};
 	for (void *b : bufs) (void)andi_arena::dev_free(b, false);
 	if (q->h_foreign) (void)hipHostFree(q->h_foreign);
 	delete q;
@@ -964,12 +977,14 @@ static int queries_stage_packed(andi_hip_ctx *ctx, const PackedQueries &P, andi_
 	};
 	chk(dmalloc(&q->pool, P.pool_bytes));
 	chk(dmalloc(&q->nib, P.pool_bytes / 2 + 64));
+	chk(dmalloc(&q->planes, 3 * (P.pool_bytes / 32) + 16));
 	chk(hipHostMalloc((void **)&q->h_foreign, sizeof(int32_t), hipHostMallocDefault));
 	chk(dmalloc(&q->d_off, n));
 	chk(dmalloc(&q->d_len, n));
 	if (err == hipSuccess) *q->h_foreign = P.foreign;
 	if (err == hipSuccess) err = hipMemcpyAsync(q->nib, P.nib, P.pool_bytes / 2, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess) err = andi_launch_unpack_symbols(q->nib, P.pool_bytes, q->pool, ctx->stream);
+	if (err == hipSuccess) err = andi_launch_pack_planes(q->nib, P.pool_bytes, q->planes, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(q->d_off, q->off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(q->d_len, q->len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
@@ -1212,7 +1227,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.subjects = (const EsaDev *)ctx->desc_dev;
 	a.self = (const int64_t *)((const EsaDev *)ctx->desc_dev + nsub);
 	a.nsub = (uint32_t)nsub;
-	a.qpool = q->pool, a.qnib = q->nib, a.qoff = q->d_off, a.qlen = q->d_len, a.nq = (uint32_t)q->nq;
+	a.qpool = q->pool, a.qnib = q->nib, a.qplanes = q->planes, a.qoff = q->d_off, a.qlen = q->d_len, a.nq = (uint32_t)q->nq;
 	a.qseg_start = q->d_qseg_start, a.seg2query = q->d_seg2query;
 	a.total_segs = q->total_segs, a.seg = segment;
 	char *p = (char *)ctx->scratch;
@@ -1268,15 +1283,25 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		a.knock = kn ? (uint32_t)atoi(kn) : 0u;
 	}
 	a.coop = coop && !a.adaptive;
-	a.pool_scratch = nullptr, a.pool_ticket = nullptr, a.pool_waves = 0;
+	a.pool_scratch = nullptr, a.pool_ticket = nullptr, a.pool_waves = 0, a.pool_bytes = 0;
+	a.pool_maxchunks = a.pool_hc = 0, a.pool_first = 0;
 	if ((a.coop || routed) && model != ANDI_M_LOGDET && model != ANDI_M_ANI) { // pooled walks: the scratch of the resident wavefronts, once per context
 		if (!ctx->pool_scratch) {
 			uint32_t waves = 0;
 			const size_t bytes = andi_pool_scratch_bytes(ctx->device, &waves);
-			if (bytes && andi_arena::dev_malloc(&ctx->pool_scratch, bytes) == hipSuccess) ctx->pool_waves = waves;
-			else (void)hipGetLastError(), ctx->pool_scratch = nullptr; // (no room, or switched off: the windows stay in LDS)
+			if (bytes && hipMalloc(&ctx->pool_scratch, bytes) == hipSuccess) // (its own mapping: larger than half an arena chunk)
+				ctx->pool_waves = waves, ctx->pool_bytes = bytes - 4096;
+			else
+				(void)hipGetLastError(), ctx->pool_scratch = nullptr; // (no room, or switched off: the windows stay in LDS)
 		}
-		if (ctx->pool_scratch) a.pool_ticket = (uint32_t *)ctx->pool_scratch, a.pool_scratch = (char *)ctx->pool_scratch + 256, a.pool_waves = ctx->pool_waves;
+		if (ctx->pool_scratch) {
+			a.pool_ticket = (uint32_t *)ctx->pool_scratch, a.pool_scratch = (char *)ctx->pool_scratch + 4096, a.pool_waves = ctx->pool_waves, a.pool_bytes = ctx->pool_bytes;
+			// that kernel streams the texts bit-sliced: the subjects' planes from their 4-bit symbols (one launch; 0.03 ms for 29 subjects)
+			size_t max_n = 0;
+			for (size_t k = 0; k < nsub; ++k) max_n = std::max(max_n, (size_t)subjects[k]->n);
+			hipError_t pe = andi_launch_pack_planes_subjects(a.subjects, (uint32_t)nsub, max_n, ctx->stream);
+			if (pe != hipSuccess) return fail(ctx, "bit-sliced subjects", pe);
+		}
 	}
 	a.route = routed ? ANDI_LAYOUT_LANES : 0, a.route_seg = coop_seg, a.route_nt = ctx->d_route;
 	uint32_t longest_q = 0;

@@ -21,24 +21,37 @@
 // runs both against the oracle and against each other.  LogDet / ANI (EXACT) stay with coop_window.
 
 constexpr uint32_t POOL_MW = 131072;            // positions of a window at most (a multiple of 2048)
-constexpr uint32_t POOL_WORDS = POOL_MW / 32;
-constexpr uint32_t POOL_HC = POOL_MW / 32;      // heads of a window that are walked (more: nothing is decided from the first one dropped on)
 constexpr uint32_t POOL_CHUNK_HEADS = 128;      // heads of one round of 2048 positions (more: as above)
 
 struct __attribute__((aligned(16))) PoolRec { // what a head's walk reads
-	uint32_t q2[4];   // the query's symbols at positions pos + 1 ... pos + 64 as 2-bit codes, 16 per word, first in the low bits
+	uint32_t q2[4];   // the query's symbols at positions pos + 1 ... pos + 64, bit-sliced: [0], [1] = bit 0 of the 64 symbols, [2], [3] = bit 1
 	uint32_t bits[2]; // the mismatch bits of those positions
 	uint32_t pos, pad;
 };
 struct __attribute__((aligned(16))) PoolRes { // what it found
 	uint32_t pos, ha, hend, flag; // the head; landing position; length of the anchor landed on (W_LUCKY: not known); W_* flags
 };
-struct PoolScratch { // per wavefront, in global memory
-	uint32_t bits[POOL_WORDS + 64]; // bit (x - wbase): query symbol x != subject symbol x + dg
-	uint32_t ebits[POOL_WORDS + 64]; // sweep R: the stretches behind the heads the chain came by, [head, landing): gap positions too
-	PoolRec rec[POOL_HC];
-	PoolRes res[POOL_HC];
+struct PoolScratch { // a window's scratch in global memory, one per resident wavefront
+	uint32_t *bits;  // [64 maxchunks + 64] bit (x - wbase): query symbol x != subject symbol x + dg
+	uint32_t *ebits; // [64 maxchunks + 64] sweep R: the stretches behind the heads the chain came by, [head, landing): gap positions too
+	PoolRec *rec;    // [hc]
+	PoolRes *res;    // [hc]
+	uint32_t hc;        // heads of a window that are walked (more: nothing is decided from the first one dropped on)
+	uint32_t maxchunks; // rounds of 2048 positions of a window at most
 };
+__host__ __device__ inline size_t pool_scratch_bytes(uint32_t maxchunks, uint32_t hc) {
+	return 2 * (size_t)(64 * maxchunks + 64) * sizeof(uint32_t) + (size_t)hc * (sizeof(PoolRec) + sizeof(PoolRes));
+}
+__device__ __forceinline__ PoolScratch pool_scratch_at(void *base, size_t idx, uint32_t maxchunks, uint32_t hc) {
+	char *p = (char *)base + idx * pool_scratch_bytes(maxchunks, hc);
+	PoolScratch g;
+	g.bits = (uint32_t *)p, p += (size_t)(64 * maxchunks + 64) * sizeof(uint32_t);
+	g.ebits = (uint32_t *)p, p += (size_t)(64 * maxchunks + 64) * sizeof(uint32_t);
+	g.rec = (PoolRec *)p, p += (size_t)hc * sizeof(PoolRec);
+	g.res = (PoolRes *)p;
+	g.hc = hc, g.maxchunks = maxchunks;
+	return g;
+}
 struct PoolLds {
 	uint32_t mring[256];          // sweep S: the bits of the last four rounds (word w at w & 255)
 	uint32_t qring[512];          // and the query's 2-bit codes (two words per word of bits)
@@ -148,6 +161,52 @@ __device__ __forceinline__ void pool_count_equal_coop(const PairCtx &c, uint32_t
 	}
 }
 
+// The texts bit-sliced (andi_dev.h: EsaDev.P): 32 symbols of the query from x0 (a multiple of 32) / of the subject from any offset s
+// (>= -32; at and beyond the text's end: NUL, all ones) as bit 0, 1, 2 of the symbols
+struct Planes {
+	uint32_t b0, b1, b2;
+};
+__device__ __forceinline__ Planes ld_query_planes(const PairCtx &c, uint32_t x0) {
+	const g_u32p p = c.Qp + 3 * (x0 >> 5);
+	Planes r;
+	r.b0 = p[0], r.b1 = p[1], r.b2 = p[2];
+	return r;
+}
+__device__ __forceinline__ Planes ld_subject_planes(const PairCtx &c, int64_t s) {
+	Planes r;
+	r.b0 = r.b1 = r.b2 = ~0u;
+	if (s >= (int64_t)c.E.n) return r;
+	const int32_t blk = (int32_t)(s >> 5);
+	const uint32_t sh = (uint32_t)s & 31u;
+	const g_u32p p = c.E.P + 3 * blk; // (blk >= -1: a block of padding lies in front)
+	const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], n0 = p[3], n1 = p[4], n2 = p[5];
+	r.b0 = __builtin_amdgcn_alignbit(n0, a0, sh), r.b1 = __builtin_amdgcn_alignbit(n1, a1, sh), r.b2 = __builtin_amdgcn_alignbit(n2, a2, sh);
+	return r;
+}
+// the substitutions among the positions `mm` (query symbol != subject symbol, both nucleotides) by kind, into twelve counters:
+// kind k = 3 * (query nucleotide) + (rank of the subject's among the three others) -- no loop over the mismatches, no LDS
+struct SubstAcc {
+	uint32_t n[12];
+};
+__device__ __forceinline__ void subst_count(SubstAcc &acc, uint32_t mm, const Planes &q, const Planes &s) {
+	const uint32_t qA = mm & ~q.b1 & ~q.b0, qC = mm & ~q.b1 & q.b0, qG = mm & q.b1 & ~q.b0, qT = mm & q.b1 & q.b0;
+	const uint32_t sA = ~s.b1 & ~s.b0, sC = ~s.b1 & s.b0, sG = s.b1 & ~s.b0, sT = s.b1 & s.b0;
+	acc.n[0] += (uint32_t)__builtin_popcount(qA & sC), acc.n[1] += (uint32_t)__builtin_popcount(qA & sG), acc.n[2] += (uint32_t)__builtin_popcount(qA & sT);
+	acc.n[3] += (uint32_t)__builtin_popcount(qC & sA), acc.n[4] += (uint32_t)__builtin_popcount(qC & sG), acc.n[5] += (uint32_t)__builtin_popcount(qC & sT);
+	acc.n[6] += (uint32_t)__builtin_popcount(qG & sA), acc.n[7] += (uint32_t)__builtin_popcount(qG & sC), acc.n[8] += (uint32_t)__builtin_popcount(qG & sT);
+	acc.n[9] += (uint32_t)__builtin_popcount(qT & sA), acc.n[10] += (uint32_t)__builtin_popcount(qT & sC), acc.n[11] += (uint32_t)__builtin_popcount(qT & sG);
+}
+// the counters of all lanes into the 4 x 4 counts (cell = subject nucleotide << 2 | query nucleotide, src/model.c:309-337), added or taken back
+__device__ __forceinline__ void subst_flush(const SubstAcc &acc, lds_u32 *hist, bool add) {
+	const uint32_t lane = __lane_id();
+#pragma unroll
+	for (int k = 0; k < 12; ++k) {
+		const uint32_t qn = (uint32_t)k / 3, r = (uint32_t)k % 3, sn = r + (r >= qn ? 1u : 0u);
+		const uint32_t v = wave_sum(acc.n[k]);
+		if (lane == 0 && v) lds_add(&hist[(sn << 2) | qn], add ? v : 0u - v);
+	}
+}
+
 // 16 bits -> the even bits of a word (bit k to bit 2k)
 __device__ __forceinline__ uint32_t spread16(uint32_t x) {
 	x &= 0xffffu;
@@ -164,73 +223,68 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
 #endif
 
 // ------------------------------------------------------------------ mode P
-// The chain stands at a canonical state of diagonal dg, as for coop_window.  Returns true if the chain moved; st is a
-// genuine loop-top state either way.  `chunks`: rounds of 2048 positions this window may take.
-__device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c, Chain &ch, PoolLds &L, PoolScratch *G, uint32_t end, uint32_t chunks, bool &through, uint32_t (&same)[4]) {
-	const uint32_t lane = __lane_id(), thr = c.thr, n = (uint32_t)c.E.n;
-	ChainState &st = ch.st;
+// A window: what sweep S leaves for the sweeps W and R (wave-uniform)
+struct PoolWin {
+	uint32_t e0, nchunks, nheads, last_mm, f_cap, clean;
+};
+
+// Sweep S.  The chain stands at a canonical state of diagonal dg, as for coop_window; `chunks`: rounds of 2048 positions this
+// window may take.
+__device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c, Chain &ch, PoolLds &L, const PoolScratch *G, uint32_t end, uint32_t chunks, PoolWin &pw) {
+	const uint32_t lane = __lane_id(), thr = c.thr;
+	const ChainState &st = ch.st;
 	const int64_t dg = (int64_t)st.lastS - (int64_t)st.lastQ;
-	const uint32_t sd = st.lastS - st.lastQ;
 	const uint32_t e0 = st.lastQ + st.lastLen;
 	const uint32_t wbase = e0 & ~31u;
 	lds_u32 *hist = (lds_u32 *)L.hist;
-	through = false;
 	// the window: up to the round behind the segment's end (an anchor that begins inside the segment may end there) and the query's
 	uint32_t nchunks = (end + 2048u - wbase + 2047u) / 2048u;
 	{
 		const uint32_t qch = (c.qlen + 64u - wbase + 2047u) / 2048u;
 		if (qch < nchunks) nchunks = qch;
 		if (chunks < nchunks) nchunks = chunks;
-		if (POOL_MW / 2048u < nchunks) nchunks = POOL_MW / 2048u;
+		if (G->maxchunks < nchunks) nchunks = G->maxchunks;
 	}
 	const uint32_t nwords = 64 * nchunks, Wp = 2048 * nchunks, wend = wbase + Wp;
+	(void)Wp;
 
 	TICK(tph);
-#ifdef POOL_DEBUG_HEAD
-	for (uint32_t w = lane; w < nwords; w += 64) G->bits[w] = ~0u;
-	pool_sync();
-#endif
-#ifdef POOL_DEBUG_CLEAR
-	for (uint32_t w = lane; w < POOL_WORDS + 64; w += 64) G->bits[w] = POOL_DEBUG_CLEAR;
-	for (uint32_t k = lane; k < POOL_HC; k += 64) G->res[k].pos = NOPOS, G->res[k].flag = 0, G->rec[k].pos = NOPOS;
-	pool_sync();
-#endif
 	// ---- sweep S
 	uint32_t nheads = 0, f_cap = NOPOS, last_mm = e0, dirty = 0;
 	bool heads_on = true;
 	{
-		uint4 qv = make_uint4(0, 0, 0, 0), sv = qv;
-		auto fetch = [&](uint32_t t, uint4 &q_, uint4 &s_) {
+		Planes qv, sv;
+		qv.b0 = qv.b1 = qv.b2 = sv.b0 = sv.b1 = sv.b2 = 0;
+		SubstAcc acc; // every mismatch a single-position gap (model_count of one position, src/model.c:309-337): sweep R takes back what is not
+#pragma unroll
+		for (int k = 0; k < 12; ++k) acc.n[k] = 0;
+		auto fetch = [&](uint32_t t, Planes &q_, Planes &s_) {
 			const uint32_t x0 = wbase + 2048 * t + WNT * lane;
-			if (t < nchunks && x0 < c.qlen) q_ = ld_query(c, x0), s_ = ld_subject_guarded(c, (int64_t)x0 + dg);
+			if (t < nchunks && x0 < c.qlen) q_ = ld_query_planes(c, x0), s_ = ld_subject_planes(c, (int64_t)x0 + dg);
 		};
 		fetch(0, qv, sv);
 		for (uint32_t t = 0; t <= nchunks; ++t) {
 			if (t < nchunks) {
-				uint4 qn = make_uint4(0, 0, 0, 0), sn = qn;
+				Planes qn, sn;
+				qn.b0 = qn.b1 = qn.b2 = sn.b0 = sn.b1 = sn.b2 = 0;
 				fetch(t + 1, qn, sn); // (in flight while this round is worked on)
 				const uint32_t x0 = wbase + 2048 * t + WNT * lane;
 				uint32_t m = ~0u, mc = 0; // positions at and beyond the query's end: lcp() stops there; mc: the mismatches that are counted
-				uint2 codes = make_uint2(0, 0);
+				uint2 codes = make_uint2(0, 0); // (the query's planes b0, b1: what the heads' records are cut from)
 				if (x0 < c.qlen) {
-					m = squeeze32(neq32(qv, sv));
-					if (!PKNOCK(5)) codes = make_uint2(squeeze_codes(qv.x) | (squeeze_codes(qv.y) << 16), squeeze_codes(qv.z) | (squeeze_codes(qv.w) << 16));
-					mc = m;
-					if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0), mc &= ~(~0u << (c.qlen - x0));
-					dirty |= (qv.x | qv.y | qv.z | qv.w) & 0x44444444u;
+					m = (qv.b0 ^ sv.b0) | (qv.b1 ^ sv.b1) | (qv.b2 ^ sv.b2);
+					codes = make_uint2(qv.b0, qv.b1);
+					mc = m & ~(qv.b2 | sv.b2); // both nucleotides (src/model.c:318-320)
+					uint32_t inq = ~0u;
+					if (c.qlen - x0 < WNT) inq = ~(~0u << (c.qlen - x0)), m |= ~inq, mc &= inq;
+					dirty |= qv.b2 & inq;
 				}
 				if (x0 <= e0 && e0 - x0 < WNT) m &= ~0u << (e0 - x0), mc &= ~0u << (e0 - x0); // (what lies before the anchor is none of the window's business)
 				if (x0 + WNT <= e0) m = 0, mc = 0;
 				G->bits[64 * t + lane] = m;
 				L.mring[(64 * t + lane) & 255u] = m;
 				*(uint2 *)&L.qring[(2 * (64 * t + lane)) & 511u] = codes;
-				// every mismatch a single-position gap (model_count of one position, src/model.c:309-337): sweep R takes back what is not
-				if (PKNOCK(0)) mc = 0;
-				for (; mc; mc &= mc - 1) {
-					const uint32_t b = (uint32_t)__builtin_ctz(mc), sh = 4 * (b & 7u);
-					const uint32_t qn4 = (pick(qv, b >> 3) >> sh) & 15u, sn4 = (pick(sv, b >> 3) >> sh) & 15u;
-					if (!((qn4 | sn4) & 4u)) lds_add(&hist[((sn4 & 3u) << 2) | (qn4 & 3u)], 1u);
-				}
+				if (!PKNOCK(0)) subst_count(acc, mc, qv, sv);
 				{
 					const uint64_t any = __ballot(m != 0);
 					if (any) {
@@ -274,7 +328,7 @@ __device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c,
 				const uint32_t total = uni((uint32_t)__shfl((int)hb, 63));
 				hb -= nh;
 				if (total) {
-					if (total > POOL_CHUNK_HEADS || nheads + total > POOL_HC) { // dropped: nothing is decided from this round's first head on
+					if (total > POOL_CHUNK_HEADS || nheads + total > G->hc) { // dropped: nothing is decided from this round's first head on
 						const uint32_t first = uni(wave_min(hmask ? x0 + (uint32_t)__builtin_ctz(hmask) : NOPOS));
 						if (first < f_cap) f_cap = first;
 						heads_on = false;
@@ -288,13 +342,13 @@ __device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c,
 							const uint32_t e = valid ? wbase + 2048 * T + L.hl[i] : 0u;
 							const bool ok = valid && e + 65u <= wend; // (its record lies inside the window)
 							if (ok) {
-								const uint32_t b0 = e + 1 - wbase, wq = b0 >> 5, sh = b0 & 31u, cw = b0 >> 4, csh = 2 * (b0 & 15u);
+								const uint32_t b0 = e + 1 - wbase, wq = b0 >> 5, sh = b0 & 31u, cw = 2 * wq;
 								const uint32_t r0 = L.mring[wq & 255u], r1 = L.mring[(wq + 1) & 255u], r2 = L.mring[(wq + 2) & 255u];
 								const uint32_t c0 = L.qring[cw & 511u], c1 = L.qring[(cw + 1) & 511u], c2 = L.qring[(cw + 2) & 511u],
-											   c3 = L.qring[(cw + 3) & 511u], c4 = L.qring[(cw + 4) & 511u];
-								PoolRec rc;
-								rc.q2[0] = __builtin_amdgcn_alignbit(c1, c0, csh), rc.q2[1] = __builtin_amdgcn_alignbit(c2, c1, csh);
-								rc.q2[2] = __builtin_amdgcn_alignbit(c3, c2, csh), rc.q2[3] = __builtin_amdgcn_alignbit(c4, c3, csh);
+											   c3 = L.qring[(cw + 3) & 511u], c4 = L.qring[(cw + 4) & 511u], c5 = L.qring[(cw + 5) & 511u];
+								PoolRec rc; // (the ring holds the query's planes: words 2w, 2w + 1 = bit 0, bit 1 of the symbols of bits-word w)
+								rc.q2[0] = __builtin_amdgcn_alignbit(c2, c0, sh), rc.q2[1] = __builtin_amdgcn_alignbit(c4, c2, sh);
+								rc.q2[2] = __builtin_amdgcn_alignbit(c3, c1, sh), rc.q2[3] = __builtin_amdgcn_alignbit(c5, c3, sh);
 								rc.bits[0] = __builtin_amdgcn_alignbit(r1, r0, sh), rc.bits[1] = __builtin_amdgcn_alignbit(r2, r1, sh);
 								rc.pos = e, rc.pad = 0;
 								G->rec[rbase + i] = rc;
@@ -313,18 +367,29 @@ __device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c,
 			wave_sync();
 		}
 		if (lane < 4) G->bits[nwords + lane] = 0; // (behind the window nothing is known)
-#ifdef POOL_DEBUG_TAIL
-		for (uint32_t w = nwords + 4 + lane; w < POOL_WORDS + 64; w += 64) G->bits[w] = ~0u;
-#endif
+		subst_flush(acc, hist, true);
 	}
-	const bool clean = !__any(dirty != 0);
 	if (PKNOCK(2)) nheads = 0;
 	ch.blk_base = NOPOS;
 	CSTAT(CS_WINDOWS, 1);
 	CSTAT(CS_HEADS, nheads);
+	pw.e0 = e0, pw.nchunks = nchunks, pw.nheads = nheads, pw.last_mm = last_mm, pw.f_cap = f_cap, pw.clean = __any(dirty != 0) ? 0u : 1u;
 	pool_sync();
-
 	TOCK(tph, PH_STREAM);
+}
+
+// Sweeps W and R of the window pw.  Returns true if the chain moved; st is a genuine loop-top state either way.
+__device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c, Chain &ch, PoolLds &L, const PoolScratch *G, uint32_t end, const PoolWin &pw, bool &through, uint32_t (&same)[4]) {
+	const uint32_t lane = __lane_id(), thr = c.thr, n = (uint32_t)c.E.n;
+	ChainState &st = ch.st;
+	const int64_t dg = (int64_t)st.lastS - (int64_t)st.lastQ;
+	const uint32_t sd = st.lastS - st.lastQ;
+	const uint32_t e0 = pw.e0, wbase = e0 & ~31u, nchunks = pw.nchunks, nheads = pw.nheads, last_mm = pw.last_mm, f_cap = pw.f_cap;
+	const uint32_t nwords = 64 * nchunks, Wp = 2048 * nchunks, wend = wbase + Wp;
+	const bool clean = pw.clean != 0;
+	lds_u32 *hist = (lds_u32 *)L.hist;
+	through = false;
+	TICK(tph);
 	// ---- sweep W: the walks, one lane each; a lane that is done takes the next head (as coop_window's, the window's
 	// bits and codes from the head's record)
 	{
@@ -432,9 +497,9 @@ __device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c,
 						const uint32_t oc = p - (e + 1);
 						uint32_t lo, hi;
 						if (oc <= 36) {
-							const uint32_t j = oc >> 4, sh = 2 * (oc & 15u);
-							const uint32_t w0 = j == 0 ? cq0 : j == 1 ? cq1 : cq2, w1 = j == 0 ? cq1 : j == 1 ? cq2 : cq3, w2 = j == 0 ? cq2 : j == 1 ? cq3 : 0u;
-							lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+							// the record holds the symbols bit-sliced: bit 0 and bit 1 of the 32 from p on, interleaved to 2-bit codes
+							const uint32_t pa = (uint32_t)((((uint64_t)cq1 << 32) | cq0) >> oc), pb = (uint32_t)((((uint64_t)cq3 << 32) | cq2) >> oc);
+							lo = spread16(pa) | (spread16(pb) << 1), hi = spread16(pa >> 16) | (spread16(pb >> 16) << 1);
 						} else {
 							const uint4 qv = ld_query(c, p & ~1u); // 32 symbols from an even position on
 							const uint32_t s0 = squeeze_codes(qv.x) | (squeeze_codes(qv.y) << 16), s1 = squeeze_codes(qv.z) | (squeeze_codes(qv.w) << 16);
@@ -500,19 +565,20 @@ __device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c,
 	}
 	// what sweep S counted of positions the chain does not reach is taken back: the mismatches of [from, wend)
 	auto take_back = [&](uint32_t from) {
-		for (uint32_t t = (from - wbase) / 2048u; t < nchunks && !PKNOCK(4); ++t) {
+		if (PKNOCK(4) || (from - wbase) / 2048u >= nchunks) return;
+		SubstAcc acc;
+#pragma unroll
+		for (int k = 0; k < 12; ++k) acc.n[k] = 0;
+		for (uint32_t t = (from - wbase) / 2048u; t < nchunks; ++t) {
 			const uint32_t x0 = wbase + 2048 * t + WNT * lane;
 			if (x0 >= c.qlen || x0 + WNT <= from) continue;
-			const uint4 qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
-			uint32_t mc = squeeze32(neq32(qv, sv));
+			const Planes qv = ld_query_planes(c, x0), sv = ld_subject_planes(c, (int64_t)x0 + dg);
+			uint32_t mc = ((qv.b0 ^ sv.b0) | (qv.b1 ^ sv.b1) | (qv.b2 ^ sv.b2)) & ~(qv.b2 | sv.b2);
 			if (c.qlen - x0 < WNT) mc &= ~(~0u << (c.qlen - x0));
 			if (from > x0) mc &= ~0u << (from - x0);
-			for (; mc; mc &= mc - 1) {
-				const uint32_t b = (uint32_t)__builtin_ctz(mc), sh = 4 * (b & 7u);
-				const uint32_t qn4 = (pick(qv, b >> 3) >> sh) & 15u, sn4 = (pick(sv, b >> 3) >> sh) & 15u;
-				if (!((qn4 | sn4) & 4u)) lds_add(&hist[((sn4 & 3u) << 2) | (qn4 & 3u)], 0u - 1u);
-			}
+			subst_count(acc, mc, qv, sv);
 		}
+		subst_flush(acc, hist, false);
 	};
 	if (e0 >= F) {
 		take_back(e0);
@@ -536,8 +602,10 @@ __device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c,
 		const uint32_t k = base + lane;
 		const bool valid = k < nheads;
 		PoolRes rs;
+		PoolRec rc; // (the head's record, for the equal symbols of its stretch: fetched with the result, one round trip per round of heads)
 		rs.pos = NOPOS, rs.ha = 0, rs.hend = 0, rs.flag = 0;
-		if (valid) rs = G->res[k];
+		rc.q2[0] = rc.q2[1] = rc.q2[2] = rc.q2[3] = rc.bits[0] = rc.bits[1] = 0;
+		if (valid) rs = G->res[k], rc = G->rec[k];
 		const uint32_t pos = rs.pos, fl = rs.flag, la = rs.ha;
 		// Where the anchor the walk landed on ends is the chain's next stand.  A probe's anchor: the result says; a lucky anchor's end
 		// is the next mismatch behind the landing -- looked up only where it matters: the next head, a mismatch itself, bounds it
@@ -625,17 +693,13 @@ __device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c,
 				const uint32_t len = la - pos - 1;
 				const bool ord = onpath && !(fl & W_HADX) && len != 0, fast = ord && clean && len <= 64;
 				if (fast && !PKNOCK(8)) {
-					const PoolRec rc = G->rec[k];
-					uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-#pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						uint32_t eq16 = ~(rc.bits[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-						if (16u * j >= len) eq16 = 0;
-						else if (len - 16u * j < 16) eq16 &= (1u << (len - 16u * j)) - 1u;
-						const uint32_t E = spread16(eq16), w = rc.q2[j], b0 = w, b1 = w >> 1;
-						n0 += (uint32_t)__builtin_popcount(E & ~(b0 | b1)), n1 += (uint32_t)__builtin_popcount(E & b0 & ~b1);
-						n2 += (uint32_t)__builtin_popcount(E & b1 & ~b0), n3 += (uint32_t)__builtin_popcount(E & b0 & b1);
-					}
+					uint32_t eqlo = ~rc.bits[0], eqhi = ~rc.bits[1]; // the equal positions among the len <= 64 behind the head
+					if (len < 32) eqlo &= (1u << len) - 1u, eqhi = 0;
+					else if (len < 64) eqhi &= (1u << (len - 32)) - 1u;
+					const uint32_t n0 = (uint32_t)__builtin_popcount(eqlo & ~rc.q2[2] & ~rc.q2[0]) + (uint32_t)__builtin_popcount(eqhi & ~rc.q2[3] & ~rc.q2[1]);
+					const uint32_t n1 = (uint32_t)__builtin_popcount(eqlo & ~rc.q2[2] & rc.q2[0]) + (uint32_t)__builtin_popcount(eqhi & ~rc.q2[3] & rc.q2[1]);
+					const uint32_t n2 = (uint32_t)__builtin_popcount(eqlo & rc.q2[2] & ~rc.q2[0]) + (uint32_t)__builtin_popcount(eqhi & rc.q2[3] & ~rc.q2[1]);
+					const uint32_t n3 = (uint32_t)__builtin_popcount(eqlo & rc.q2[2] & rc.q2[0]) + (uint32_t)__builtin_popcount(eqhi & rc.q2[3] & rc.q2[1]);
 					eq0 += n0, eq1 += n1, eq2 += n2, eq3 += n3;
 				}
 				for (uint64_t sl = PKNOCK(9) ? 0ull : __ballot(ord && !fast); sl; sl &= sl - 1) {
@@ -757,11 +821,18 @@ __device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c,
 	return true;
 }
 
+__device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c, Chain &ch, PoolLds &L, const PoolScratch *G, uint32_t end, uint32_t chunks, bool &through, uint32_t (&same)[4]) {
+	PoolWin pw;
+	pool_stream(a, c, ch, L, G, end, chunks, pw);
+	return pool_resolve(a, c, ch, L, G, end, pw, through, same);
+}
+
 // ------------------------------------------------------------------ the kernel: persistent wavefronts take the segments in order
 #ifndef POOL_OCC
 #define POOL_OCC 6 /* wavefronts per SIMD: 80 registers, 75 spilled on rare paths -- bench set 5.66 / 5.09 / 4.92 ms at 4 / 5 / 6 */
 #endif
-__device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, PoolScratch *G, uint32_t sub, uint32_t wseg) {
+// One segment: mode G until the chain has a diagonal, windows while it stays on it.
+__device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, const PoolScratch *G, uint32_t sub, uint32_t wseg) {
 	const uint32_t lane = __lane_id();
 	if (a.subjects[sub].mode != ANDI_MODE_PROBE) return;
 	const uint32_t qidx = uni(a.seg2query[wseg]);
@@ -779,8 +850,10 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, Pool
 	auto given_up = [&]() { return route && (uni(__hip_atomic_load(route, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & (ANDI_ROUTE_COOP | ANDI_ROUTE_LEFT)) != ANDI_ROUTE_COOP; };
 	if (given_up()) return;
 	wave_sync();
-	if (lane < 16) L.hist[lane] = 0;
 	Chain ch;
+	uint32_t my_g = 0;
+	PoolWin pw;
+	if (lane < 16) L.hist[lane] = 0;
 	ch.st = seg_in_q == 0 ? initial_state() : cold_state(start, n);
 	ch.quarter = ch.rest = ch.anchors = ch.marked = 0, ch.blk_base = NOPOS;
 	ChainState &st = ch.st;
@@ -788,8 +861,20 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, Pool
 
 	CSTAT(CS_SEGMENTS, 1);
 	TICK(tall);
-	uint32_t my_g = 0;
 	uint32_t same[4] = {0, 0, 0, 0}; // equal pairs the windows found in gaps, by nucleotide
+	// windows one after the other while the chain stays canonical on the diagonal and moves; false: the pair was handed back
+	auto windows = [&]() {
+		uint32_t chunks = a.pool_first;
+		bool through = false;
+		for (;;) {
+			if (!(st.p < end && st.lastQ + st.lastLen < c.qlen)) break;
+			pool_stream(a, c, ch, L, G, end, chunks, pw);
+			if (!pool_resolve(a, c, ch, L, G, end, pw, through, same)) break;
+			if (given_up()) return false;
+			chunks = !through ? a.pool_first : 2 * chunks < G->maxchunks ? 2 * chunks : G->maxchunks;
+		}
+		return true;
+	};
 	while (st.p < end) {
 		CSTAT(CS_G_STEPS, 1);
 		++my_g;
@@ -835,23 +920,15 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, Pool
 			wave_sync();
 			coop_note_anchor(a, slot, ch, L);
 		}
-		// ---- windows one after the other while the chain stays canonical on the diagonal and moves
-		if (found && lucky) {
-			uint32_t chunks = a.pool_first;
-			bool through = false;
-			while (st.p < end && st.lastQ + st.lastLen < c.qlen && pool_window(a, c, ch, L, G, end, chunks, through, same)) {
-				if (given_up()) return;
-				chunks = !through ? a.pool_first : 2 * chunks < POOL_MW / 2048u ? 2 * chunks : POOL_MW / 2048u;
-			}
-		}
+		if (found && lucky && !windows()) return;
 	}
 	TOCK(tall, 7);
+	wave_sync();
 #ifdef ANDI_COOP_STATS
 	if (lane == 0) atomicMax(&g_coop_max[0], my_g);
 #endif
 	(void)my_g;
 	// ---- what pass B reads (scan.h)
-	wave_sync();
 	if (lane == 0) {
 		ColdMark *m = a.marks + slot * ANDI_COLD_MARKS;
 		if (!ch.marked) m->st.pad[0] = 0; // unused mark
@@ -869,16 +946,18 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, Pool
 	}
 }
 
+// the kernel: persistent wavefronts, a scratch each, take the segments in order
 __global__ __launch_bounds__(64, POOL_OCC) void k_pool_cold(ScanArgs a) {
 	__shared__ PoolLds L;
-	PoolScratch *G = (PoolScratch *)a.pool_scratch + blockIdx.x;
+	const PoolScratch Gs = pool_scratch_at(a.pool_scratch, blockIdx.x, a.pool_maxchunks, a.pool_hc);
 	const uint32_t items = a.total_segs * a.nsub;
 	uint32_t item = blockIdx.x; // the first one; then whatever comes next
 	while (item < items) {
-		pool_segment(a, L, G, item / a.total_segs, item % a.total_segs);
+		pool_segment(a, L, &Gs, item / a.total_segs, item % a.total_segs);
 		wave_sync();
 		uint32_t nx = 0;
 		if (__lane_id() == 0) nx = atomicAdd(a.pool_ticket, 1u);
 		item = gridDim.x + uni((uint32_t)__shfl((int)nx, 0));
 	}
 }
+

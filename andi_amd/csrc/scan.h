@@ -37,6 +37,7 @@ struct ScanArgs {
 	// query pool
 	const uint8_t *qpool;
 	const uint8_t *qnib;  // the pool as 4-bit symbols: sequence q starts at qnib + qoff[q] / 2
+	const uint32_t *qplanes; // the pool bit-sliced (andi_dev.h: EsaDev.P): sequence q starts at block qoff[q] / 32
 	const uint64_t *qoff; // [nq]
 	const uint32_t *qlen; // [nq]
 	uint32_t nq;
@@ -112,9 +113,11 @@ struct ScanArgs {
 	int coop;            // pass A with one wavefront per chain (scan_coop.hip): one segment length, RAW/JC/Kimura, probe-table subjects
 	// ... with the windows' walks pooled through global memory (coop_pool.h: k_pool_cold; the models that split an anchor's length
 	// evenly): a scratch per resident wavefront, pool_waves of them; pool_ticket: the next segment to take (zeroed per launch)
-	void *pool_scratch;
+	void *pool_scratch;   // the wavefronts' scratches
 	uint32_t *pool_ticket;
 	uint32_t pool_waves;
+	size_t pool_bytes;    // host side: what the context holds behind pool_ticket's 4096 bytes
+	uint32_t pool_maxchunks, pool_hc; // a scratch's size: rounds of 2048 positions of a window, heads of a window
 	uint32_t pool_first; // rounds of 2048 positions of a chain's first window (doubled after every window the chain got through)
 	uint32_t knock;      // diagnostic builds (-DANDI_LANE_STATS): parts of pass A switched off to time them (results are then wrong)
 };
@@ -125,6 +128,10 @@ struct ScanArgs {
 hipError_t andi_launch_unpack_symbols(const uint8_t *N0, size_t bytes, uint8_t *dst, hipStream_t st); // a byte pool from its 4-bit symbols
 hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N0, uint8_t *N1,
 									int32_t *foreign, hipStream_t st);
+// the bit-sliced form of 4-bit symbols (EsaDev.P): `symbols` of them from N0 (rounded up to blocks of 32) into planes
+hipError_t andi_launch_pack_planes(const uint8_t *N0, size_t symbols, uint32_t *planes, hipStream_t st);
+// ... of the subjects of a scan call (their descriptors on the device): symbols 0 ... n + 64 of each
+hipError_t andi_launch_pack_planes_subjects(const EsaDev *subjects, uint32_t nsub, size_t max_n, hipStream_t st);
 // adaptive mode: sample every pair's match lengths, choose its segment length (and, in a routed call, its pass A), lay out the slots
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 // routed calls: the second lane layout (a2: the pairs pass A by wavefronts handed back); who took what, for the timings
@@ -134,7 +141,7 @@ hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 // pass A with one wavefront per chain (scan_coop.hip)
 int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: the engine chooses -- tiny calls every pair, others routed per pair (the default); n = 2, 4, 8: every pair, windows of 2048 n symbols
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st);
-size_t andi_pool_scratch_bytes(int device, uint32_t *waves); // the pooled kernel's scratch (256 bytes for the ticket in front); 0: that kernel is off (ANDI_POOL=0)
+size_t andi_pool_scratch_bytes(int device, uint32_t *waves); // the pooled kernels' scratch (4096 bytes for the ticket in front); 0: those kernels are off (ANDI_POOL=0)
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStream_t st); // k_lane_quad, one wavefront per block (scan_lane.hip compiled a second time)
 // Pass B again for the segments that were entered in a state their predecessor's true chain did not leave in (a true

@@ -1072,13 +1072,15 @@ static bool pool_enabled() { // ANDI_POOL=0: the windows stay in LDS (coop_windo
 	return !e || atoi(e) != 0;
 }
 
+// The pooled kernel's scratch: a window of POOL_MW positions per resident wavefront
+constexpr uint32_t POOL_FUSED_CHUNKS = POOL_MW / 2048u, POOL_FUSED_HC = POOL_MW / 64u;
 size_t andi_pool_scratch_bytes(int device, uint32_t *waves) {
 	*waves = 0;
 	if (!pool_enabled()) return 0;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	*waves = (uint32_t)prop.multiProcessorCount * 4u * POOL_OCC;
-	return 256 + (size_t)*waves * sizeof(PoolScratch);
+	return 4096 + (size_t)*waves * pool_scratch_bytes(POOL_FUSED_CHUNKS, POOL_FUSED_HC);
 }
 
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one segment length for the call, RAW/JC/Kimura
@@ -1086,13 +1088,14 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 	const int nch = andi_coop_enabled();
 	const bool pooled = !a.exact_equal && a.pool_scratch && a.pool_waves && pool_enabled() && (nch < 0 || nch == 4);
 	if (pooled) { // the windows' walks pooled through global memory: persistent wavefronts take the segments in order
-		hipError_t e = hipMemsetAsync(a.pool_ticket, 0, sizeof(uint32_t), st);
-		if (e != hipSuccess) return e;
 		const uint64_t items = (uint64_t)a.total_segs * a.nsub;
 		ScanArgs b = a;
-		b.pool_first = 16;
+		b.pool_first = 64;
 		if (const char *pf = andi_knob(KNOB_POOL_FIRST)) // (experiments)
-			if (atoi(pf) >= 1 && atoi(pf) <= (int)(POOL_MW / 2048u)) b.pool_first = (uint32_t)atoi(pf);
+			if (atoi(pf) >= 1 && atoi(pf) <= (int)POOL_FUSED_CHUNKS) b.pool_first = (uint32_t)atoi(pf);
+		hipError_t e = hipMemsetAsync(a.pool_ticket, 0, sizeof(uint32_t), st);
+		if (e != hipSuccess) return e;
+		b.pool_maxchunks = POOL_FUSED_CHUNKS, b.pool_hc = POOL_FUSED_HC;
 		k_pool_cold<<<(uint32_t)(items < a.pool_waves ? items : a.pool_waves), 64, 0, st>>>(b);
 	} else
 	switch (nch < 0 ? -nch : nch) {

@@ -20,6 +20,7 @@ struct PairCtx {
 	EsaG E;
 	g_u8p Q;
 	g_u8p Qn; // packed symbols of the query
+	g_u32p Qp; // ... bit-sliced (block 0 = its symbols 0 ... 31)
 	uint32_t qlen;
 	uint32_t thr;
 	uint32_t border; // n / 2, src/process.c:149
@@ -114,6 +115,7 @@ __device__ __forceinline__ PairCtx make_ctx(const ScanArgs &a, uint32_t sub, uin
 	c.E = esa_global(a.subjects[sub]);
 	c.Q = (g_u8p)(a.qpool + a.qoff[qidx]);
 	c.Qn = (g_u8p)(a.qnib + a.qoff[qidx] / 2);
+	c.Qp = (g_u32p)(a.qplanes + 3 * (a.qoff[qidx] / 32));
 	c.qlen = a.qlen[qidx];
 	c.thr = (uint32_t)c.E.thr;
 	c.border = (uint32_t)c.E.n / 2;

@@ -1081,6 +1081,40 @@ __global__ __launch_bounds__(256) void k_unpack_symbols(const uint2 *__restrict_
 	dst[j] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+// 32 symbols (16 bytes of 4-bit symbols) -> bit 0, 1, 2 of each as three words (EsaDev.P)
+__device__ __forceinline__ void planes_of(const uint4 v, uint32_t *out) {
+	auto squeeze = [](uint32_t x) { // bit 4k + 3 of a word -> bit k
+		x = (x >> 3) & 0x11111111u;
+		x = (x | (x >> 3)) & 0x03030303u;
+		x = (x | (x >> 6)) & 0x000f000fu;
+		return (x | (x >> 12)) & 0xffu;
+	};
+#pragma unroll
+	for (int b = 0; b < 3; ++b) {
+		const int sh = 3 - b;
+		out[b] = squeeze(v.x << sh) | (squeeze(v.y << sh) << 8) | (squeeze(v.z << sh) << 16) | (squeeze(v.w << sh) << 24);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_pack_planes(const uint4 *__restrict__ N0, int64_t blocks, uint32_t *__restrict__ planes) {
+	const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= blocks) return;
+	uint32_t o[3];
+	planes_of(N0[j], o);
+	planes[3 * j] = o[0], planes[3 * j + 1] = o[1], planes[3 * j + 2] = o[2];
+}
+
+__global__ __launch_bounds__(256) void k_pack_planes_subjects(const EsaDev *__restrict__ subjects) {
+	const EsaDev E = subjects[blockIdx.y];
+	if (!E.P || !E.N0) return;
+	const int64_t blocks = ((int64_t)E.n + 1 + 64 + 31) / 32, j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= blocks) return;
+	uint32_t o[3];
+	planes_of(((const uint4 *)E.N0)[j], o);
+	uint32_t *planes = const_cast<uint32_t *>(E.P);
+	planes[3 * j] = o[0], planes[3 * j + 1] = o[1], planes[3 * j + 2] = o[2];
+}
+
 __global__ __launch_bounds__(256) void k_pack_symbols_batch(const AndiIndexBatchItem *__restrict__ items) {
 	const AndiIndexBatchItem it = items[blockIdx.y];
 	pack_symbols_block(it.S, ((int64_t)it.n + 1 + 64 + 15) / 16, (uint2 *)it.N0, (uint2 *)it.N1, it.flags + 1);
@@ -1117,6 +1151,22 @@ hipError_t andi_launch_unpack_symbols(const uint8_t *N0, size_t bytes, uint8_t *
 	const int64_t pairs = (int64_t)(bytes / 16);
 	if (pairs == 0) return hipSuccess;
 	k_unpack_symbols<<<(unsigned)((pairs + 255) / 256), 256, 0, st>>>((const uint2 *)N0, pairs, (uint4 *)dst);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_pack_planes(const uint8_t *N0, size_t symbols, uint32_t *planes, hipStream_t st) {
+	const int64_t blocks = (int64_t)((symbols + 31) / 32);
+	if (blocks == 0) return hipSuccess;
+	k_pack_planes<<<(unsigned)((blocks + 255) / 256), 256, 0, st>>>((const uint4 *)N0, blocks, planes);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_pack_planes_subjects(const EsaDev *subjects, uint32_t nsub, size_t max_n, hipStream_t st) {
+	const int64_t blocks = (int64_t)((max_n + 1 + 64 + 31) / 32);
+	if (blocks == 0 || nsub == 0) return hipSuccess;
+	k_pack_planes_subjects<<<dim3((unsigned)((blocks + 255) / 256), nsub), 256, 0, st>>>(subjects);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
