@@ -44,6 +44,12 @@ struct KnobSnapshot {
 #undef X
 		};
 		for (int k = 0; k < KNOB_COUNT; ++k) {
+#ifndef ANDI_TEST_HOOKS
+			if (k >= ANDI_KNOBS_SHIPPED) { // (the shipped library does not even look)
+				set[k] = false;
+				continue;
+			}
+#endif
 			const char *v = getenv(names[k]);
 			set[k] = v != nullptr;
 			value[k] = v ? v : "";
@@ -64,7 +70,7 @@ const KnobSnapshot &knob_store() {
 }
 } // namespace
 
-const char *andi_knob(AndiKnob k) {
+const char *andi_knob_value(AndiKnob k) {
 	const KnobSnapshot &s = knob_store();
 	return s.set[k] ? s.value[k].c_str() : nullptr;
 }
@@ -125,7 +131,7 @@ struct andi_hip_ctx {
 	uint32_t *h_quad_waves = nullptr; // pinned: the length of k_lane_quad's list of a scan call
 	hipStream_t coop_stream = nullptr; // routed scan calls: pass A by wavefronts runs beside the lane scan's kernels
 	hipEvent_t coop_fork = nullptr, coop_join = nullptr, l2_fork = nullptr, l2_join = nullptr;
-	uint32_t *h_any_left = nullptr;    // pinned: [0] the wavefront kernel handed some pair back, [1 ... 6] the layout's counters (restitch_count[ANDI_LANE_WAVES ...]: [1] wavefronts of the lane layout)
+	uint32_t *h_any_left = nullptr;    // pinned: [0] the wavefront kernel handed some pair back, [1 + k] the layout's counter restitch_count[k] (ANDI_LANE_WAVES: wavefronts of the lane layout, ...)
 	void *pool_scratch = nullptr;      // pass A by wavefronts with pooled walks (coop_pool.h): a scratch per resident wavefront
 	size_t pool_bytes = 0;
 	uint32_t pool_waves = 0;
@@ -389,7 +395,7 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_join, hipEventDisableTiming);
-	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_any_left, 8 * sizeof(uint32_t), hipHostMallocDefault);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_any_left, 20 * sizeof(uint32_t), hipHostMallocDefault);
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_route, 4 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_route, 0, 4 * sizeof(unsigned long long));
 	if (e != hipSuccess) {
@@ -1284,7 +1290,11 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	a.coop = coop && !a.adaptive;
 	a.pool_scratch = nullptr, a.pool_ticket = nullptr, a.pool_waves = 0, a.pool_bytes = 0;
-	a.pool_maxchunks = a.pool_hc = 0, a.pool_first = 0;
+	a.pool_maxchunks = a.pool_hc = 0, a.pool_first = 0, a.pool_use = 0;
+	{
+		const char *pm = andi_knob(KNOB_POOL_MATCH); // (experiments: mean sampled match from which a routed pair's wavefront kernel is k_pool_cold)
+		a.pool_match = pm && atoi(pm) >= 0 ? (uint32_t)atoi(pm) : 48u;
+	}
 	if ((a.coop || routed) && model != ANDI_M_LOGDET && model != ANDI_M_ANI) { // pooled walks: the scratch of the resident wavefronts, once per context
 		if (!ctx->pool_scratch) {
 			uint32_t waves = 0;
@@ -1366,11 +1376,14 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			// (Small calls do not look: the wavefront kernel first, the lane layout's passes whether it has pairs or not --
 			// a look costs them 40 us of their few hundred.)
 			const bool look = !a.route_all_few;
-			ctx->h_any_left[1] = 1;
+			for (int k = 0; k < 16; ++k) ctx->h_any_left[1 + k] = 0;
+			ctx->h_any_left[1 + ANDI_LANE_WAVES] = 1;
 			e = hipSuccess;
-			if (look) e = hipMemcpyAsync(ctx->h_any_left + 1, a.restitch_count + ANDI_LANE_WAVES, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+			if (look) e = hipMemcpyAsync(ctx->h_any_left + 1, a.restitch_count, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
 			if (look && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-			const bool lanes_first = look && e == hipSuccess && (uint64_t)ctx->h_any_left[1] * 20 < ctx->h_any_left[1 + ANDI_ALL_WAVES - ANDI_LANE_WAVES];
+			const bool lanes_first = look && e == hipSuccess && (uint64_t)ctx->h_any_left[1 + ANDI_LANE_WAVES] * 20 < ctx->h_any_left[1 + ANDI_ALL_WAVES];
+			// which wavefront kernel: the pooled one where the pairs that suit it hold at least half of the segments (scan.h)
+			b.pool_use = look && e == hipSuccess && 2 * (uint64_t)ctx->h_any_left[1 + ANDI_POOL_SEGS] >= ctx->h_any_left[1 + ANDI_COOP_SEGS] && ctx->h_any_left[1 + ANDI_COOP_SEGS] != 0;
 			if (e == hipSuccess) e = hipEventRecord(ctx->coop_fork, ctx->stream);
 			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->coop_stream, ctx->coop_fork, 0);
 			if (e == hipSuccess && lanes_first) e = andi_launch_scan_cold(a, ctx->stream);
@@ -1382,7 +1395,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 			if (e != hipSuccess) return bail("scan pass A", e);
 			any_left = ctx->h_any_left[0] != 0;
-			const bool any_lanes = ctx->h_any_left[1] != 0; // (no pair in the lane layout: its passes B and C have nothing to do)
+			const bool any_lanes = ctx->h_any_left[1 + ANDI_LANE_WAVES] != 0; // (no pair in the lane layout: its passes B and C have nothing to do)
 			ScanArgs a2 = a;
 			if (any_left) { // the pairs handed back: a lane layout of their own (as large as the first at most)
 				const size_t need2 = slots * ANDI_SLOT_BYTES + 256 + pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16;

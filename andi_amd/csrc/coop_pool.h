@@ -864,7 +864,9 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, cons
 	uint32_t same[4] = {0, 0, 0, 0}; // equal pairs the windows found in gaps, by nucleotide
 	// windows one after the other while the chain stays canonical on the diagonal and moves; false: the pair was handed back
 	auto windows = [&]() {
-		uint32_t chunks = a.pool_first;
+		// (behind an anchor of thousands of symbols the next mismatch is far: genomes 1e-5 apart -- a window finds one or two, and nothing is
+		// decided behind the last: short windows first)
+		uint32_t chunks = st.lastLen >= 4096 ? 4u : a.pool_first;
 		bool through = false;
 		for (;;) {
 			if (!(st.p < end && st.lastQ + st.lastLen < c.qlen)) break;

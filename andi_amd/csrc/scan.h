@@ -118,6 +118,11 @@ struct ScanArgs {
 	uint32_t pool_waves;
 	size_t pool_bytes;    // host side: what the context holds behind pool_ticket's 4096 bytes
 	uint32_t pool_maxchunks, pool_hc; // a scratch's size: rounds of 2048 positions of a window, heads of a window
+	// routed calls: WHICH wavefront kernel -- k_pool_cold where the pairs whose sampled mean match is pool_match ... 4095 (few heads per position:
+	// streaming decides) hold at least half of the wavefront kernel's segments, k_coop_cold otherwise (many heads: its windows in LDS walk them at
+	// less cost; near-identical genomes: a window sees one mismatch).  One kernel per call: side by side they were slower than either.
+	uint32_t pool_match;
+	int pool_use; // host side, routed calls: this call's wavefront kernel is k_pool_cold (the pairs with long sampled matches hold most of its wavefronts)
 	uint32_t pool_first; // rounds of 2048 positions of a chain's first window (doubled after every window the chain got through)
 	uint32_t knock;      // diagnostic builds (-DANDI_LANE_STATS): parts of pass A switched off to time them (results are then wrong)
 };
@@ -167,6 +172,9 @@ static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at
 #define ANDI_ROUTE_SOFT 0x10u /* (k_pair_estimate to k_pair_route) the lane scan is better at it, if such pairs are more than a few */
 #define ANDI_ROUTE_GUESS 0x04u /* (k_pair_estimate to k_pair_route, small calls) marked for the wavefront kernel although the sampling cannot judge the pair: not where the call has pairs with unrelated stretches */
 #define ANDI_ROUTE_L2 0x08u   /* a pair handed back: in the second lane layout */
+#define ANDI_ROUTE_POOLCAND 0x08u /* (k_pair_estimate to k_pair_route) mean sampled match in [ScanArgs.pool_match, 4096): a pair that suits k_pool_cold (coop_pool.h) */
+#define ANDI_POOL_SEGS 6 /* restitch_count[this] after k_pair_route: segments of the wavefront kernel's pairs that suit k_pool_cold */
+#define ANDI_COOP_SEGS 7 /* ... of all its pairs */
 #define ANDI_LAYOUT_LANES 1   /* ScanArgs.route: the lane scan's pairs */
 #define ANDI_LAYOUT_LANES2 2  /* the pairs pass A by wavefronts handed back */
 #define ANDI_LAYOUT_COOP 3    /* the wavefront kernel's pairs (one segment length) */

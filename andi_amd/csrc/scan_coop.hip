@@ -1087,15 +1087,17 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 	const dim3 grid((a.total_segs + COOP_WAVES - 1) / COOP_WAVES, a.nsub);
 	const int nch = andi_coop_enabled();
 	const bool pooled = !a.exact_equal && a.pool_scratch && a.pool_waves && pool_enabled() && (nch < 0 || nch == 4);
-	if (pooled) { // the windows' walks pooled through global memory: persistent wavefronts take the segments in order
+	// The windows' walks pooled through global memory (k_pool_cold: persistent wavefronts take the segments in order): segments long enough
+	// to fill its windows; in a routed call where the pairs with long sampled matches hold most of the segments (ScanArgs.pool_use)
+	if (pooled && a.seg >= 32768 && (!a.route || a.pool_use)) {
 		const uint64_t items = (uint64_t)a.total_segs * a.nsub;
 		ScanArgs b = a;
 		b.pool_first = 64;
 		if (const char *pf = andi_knob(KNOB_POOL_FIRST)) // (experiments)
 			if (atoi(pf) >= 1 && atoi(pf) <= (int)POOL_FUSED_CHUNKS) b.pool_first = (uint32_t)atoi(pf);
+		b.pool_maxchunks = POOL_FUSED_CHUNKS, b.pool_hc = POOL_FUSED_HC;
 		hipError_t e = hipMemsetAsync(a.pool_ticket, 0, sizeof(uint32_t), st);
 		if (e != hipSuccess) return e;
-		b.pool_maxchunks = POOL_FUSED_CHUNKS, b.pool_hc = POOL_FUSED_HC;
 		k_pool_cold<<<(uint32_t)(items < a.pool_waves ? items : a.pool_waves), 64, 0, st>>>(b);
 	} else
 	switch (nch < 0 ? -nch : nch) {

@@ -172,7 +172,8 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 		const bool soft = (sum >> 6) < ANDI_SPARSE_MATCH || (sum >> 6) >= a.route_soft_match;
 		const bool quad = (sum >> 6) >= a.quad_min_match && !(islands && (sum >> 6) < ANDI_ISLAND_MEAN_MAX);
 		a.pair_class[pair] = (uint8_t)(cls | (quad ? 0x80u : 0u) | (coop_cand && !islands ? ANDI_ROUTE_COOP : 0u) | (soft ? ANDI_ROUTE_SOFT : 0u) |
-										 (coop_cand && islands ? ANDI_ROUTE_LEFT : 0u) | (coop_cand && guess ? ANDI_ROUTE_GUESS : 0u));
+										 (coop_cand && islands ? ANDI_ROUTE_LEFT : 0u) | (coop_cand && guess ? ANDI_ROUTE_GUESS : 0u) |
+										 (a.route && (sum >> 6) >= a.pool_match && (sum >> 6) < 4096u ? ANDI_ROUTE_POOLCAND : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
 	}
 }
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_pair_totals(ScanArgs a) {
 }
 
 // routed calls: which pairs take pass A by wavefronts (they get no wavefronts in the lane layout)
-__device__ __forceinline__ uint32_t route_pair(const ScanArgs &a, uint32_t pair) {
+__device__ __forceinline__ uint32_t route_pair(const ScanArgs &a, uint32_t pair, uint32_t &pool_segs, uint32_t &coop_segs) {
 	uint32_t cls = a.pair_class[pair];
 	const bool lanes_few = 10 * a.restitch_count[ANDI_SPARSE_WAVES] <= a.restitch_count[ANDI_ALL_WAVES]; // (the lane scan's and those it would like)
 	// (small calls: the soft pairs are the wavefront kernel's as well -- 3 x 1 Mbp 10 % apart, BASELINE's configs[0]: pass A
@@ -273,12 +274,17 @@ __device__ __forceinline__ uint32_t route_pair(const ScanArgs &a, uint32_t pair)
 	// unrelated stretches -- structured genomes: 12 x 1 Mbp took 5.4 ms with such pairs tried by wavefronts and handed
 	// back, 3.9 ms by lanes)
 	if ((cls & ANDI_ROUTE_GUESS) && 20 * a.restitch_count[ANDI_ISLAND_WAVES] > a.restitch_count[ANDI_ALL_WAVES]) cls &= ~ANDI_ROUTE_COOP;
-	cls &= ~(ANDI_ROUTE_SOFT | ANDI_ROUTE_LEFT | ANDI_ROUTE_GUESS);
+	const bool pool = (cls & ANDI_ROUTE_POOLCAND) != 0;
+	cls &= ~(ANDI_ROUTE_SOFT | ANDI_ROUTE_LEFT | ANDI_ROUTE_GUESS | ANDI_ROUTE_POOLCAND);
 	// Small calls (route_all_few): pass A by wavefronts takes a fraction of a millisecond, and a lane's chain over one
 	// segment as long as it ever does -- six pairs of 9900 left to the lane scan (100 x 30 kbp) made pass A 1.1 ms instead
 	// of 0.6.  Where the lane scan's pairs are that few, the wavefront kernel takes them all (and hands back what it must).
 	if (a.route_all_few && 20 * a.restitch_count[ANDI_HARD_WAVES] <= a.restitch_count[ANDI_ALL_WAVES] && a.self[pair / a.nq] != (int64_t)(pair % a.nq))
 		cls |= ANDI_ROUTE_COOP;
+	if (cls & ANDI_ROUTE_COOP) { // (which of the wavefront kernels: scan.h)
+		const uint32_t segs = (a.qlen[pair % a.nq] + a.route_seg - 1) / a.route_seg;
+		coop_segs += segs, pool_segs += pool ? segs : 0u;
+	}
 	a.pair_class[pair] = (uint8_t)cls;
 	if (cls & ANDI_ROUTE_COOP) a.pair_waves[pair] = 0;
 	return a.pair_waves[pair];
@@ -286,11 +292,13 @@ __device__ __forceinline__ uint32_t route_pair(const ScanArgs &a, uint32_t pair)
 
 __global__ __launch_bounds__(256) void k_pair_route(ScanArgs a) {
 	const uint32_t P = a.nsub * a.nq, pair = blockIdx.x * 256 + threadIdx.x;
-	uint32_t mine = 0; // wavefronts the pair keeps in the lane layout
-	if (pair < P) mine = route_pair(a, pair);
+	uint32_t mine = 0, pool_segs = 0, coop_segs = 0; // wavefronts the pair keeps in the lane layout; the wavefront kernel's segments
+	if (pair < P) mine = route_pair(a, pair, pool_segs, coop_segs);
 #pragma unroll
-	for (int d = 32; d; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d);
+	for (int d = 32; d; d >>= 1)
+		mine += (uint32_t)__shfl_xor((int)mine, d), pool_segs += (uint32_t)__shfl_xor((int)pool_segs, d), coop_segs += (uint32_t)__shfl_xor((int)coop_segs, d);
 	if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&a.restitch_count[ANDI_LANE_WAVES], mine); // (the host looks: which kernel goes first)
+	if ((threadIdx.x & 63u) == 0 && coop_segs) atomicAdd(&a.restitch_count[ANDI_COOP_SEGS], coop_segs), atomicAdd(&a.restitch_count[ANDI_POOL_SEGS], pool_segs); // (... and which wavefront kernel)
 }
 
 // routed calls, after pass A: the pairs the wavefront kernel handed back get the wavefronts of the second lane layout

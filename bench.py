@@ -52,6 +52,7 @@ def parse():
                     help="star: substitutions only (the reference's generator, test/test_fasta.cxx); realistic: repeats on "
                          "both strands, indels, inversions, unrelated islands (andi_amd/synth.py: realistic_set); tree: "
                          "substitutions along a random tree, pairwise distances 4.4e-4 ... 2.6e-2 (tree_set)")
+    ap.add_argument("--model", choices=("raw", "jc", "kimura"), default="jc", help="the estimator's model (andi -m): what the counts are made for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (structured genomes, tree-structured set)")
     ap.add_argument("--seam-child", default="", help=argparse.SUPPRESS)  # internal: the multi-GPU seam in a process of its own
@@ -135,8 +136,14 @@ def pass_a_of(tm):
     return ("k_coop_cold" if tm["coop_calls"] >= launches else "k_lane_cold"), None
 
 
+MODELS = {"raw": 0, "jc": 1, "kimura": 2}  # andi_amd.M_RAW, M_JC, M_KIMURA (include/andi_hip.h)
+MODEL_NAMES = {0: "RAW", 1: "JC", 2: "Kimura"}
+
+
 def make_set(kind, G, length, dlo, dhi, seed):
     from andi_amd import synth
+    if kind == "fast":  # hundreds of genomes (BASELINE's config 2): substitutions drawn position by position, by a pool of threads
+        return synth.genome_set_fast(G, length, dlo, dhi, seed=seed, threads=min(os.cpu_count() or 1, 32))[0]
     if kind == "realistic":
         return synth.realistic_set(G, length, dlo, dhi, seed=seed)[0]
     if kind == "tree":
@@ -144,21 +151,23 @@ def make_set(kind, G, length, dlo, dhi, seed):
     return synth.genome_set(G, length, dlo, dhi, seed=seed)[0]
 
 
-def workload_name(kind, G, S, length, dlo, dhi, seed, world):
+def workload_name(kind, G, S, length, dlo, dhi, seed, world, model=1):
     """what the set really is: the C2 name only for C2's shape (29 genomes of 4.9 Mbp per GPU tile)"""
     import andi_amd.shard as shard
     c2 = length == 4_900_000 and G == shard.weak_scaling_set_size(world) and (kind != "star" or (dlo, dhi) == (0.0004, 0.03))
     c4 = kind == "star" and G == 3085 and length == 2_100_000  # BASELINE's config 3 as synthetic data (SURVEY.md 8d: C4-synth)
-    tag = {"star": "synth", "realistic": "realistic", "tree": "tree"}[kind]
+    c3 = kind == "fast" and G == 109 and length == 5_100_000   # BASELINE's config 2 (109 E. coli ST131, Kimura) as synthetic data: C3-synth
+    tag = {"star": "synth", "fast": "synth", "realistic": "realistic", "tree": "tree"}[kind]
     what = {"star": "d~U[%g,%g] from a common base (star)" % (dlo, dhi),
+            "fast": "d~U[%g,%g] from a common base (star; substitutions drawn per position)" % (dlo, dhi),
             "realistic": "d~U[%g,%g] from a common base, with repeats, indels, inversions, 10%% unrelated sequence" % (dlo, dhi),
             "tree": "substitutions along a random tree, pairwise d 4.4e-4 ... 2.6e-2"}[kind]
-    return "%s: %d genomes x %d nt, %s, JC, seed %d; %s rows block-partitioned over %d GPU(s)" % (
-        ("C2-" + tag) if c2 else ("C4-synth" if c4 else "synthetic " + tag + " set"), G, length, what, seed,
-        "all" if S == G else "the first %d subject" % S, world)
+    return "%s: %d genomes x %d nt, %s, %s, seed %d; %s rows block-partitioned over %d GPU(s)" % (
+        ("C2-" + tag) if c2 else ("C4-synth" if c4 else "C3-synth" if c3 else "synthetic " + tag + " set"), G, length, what,
+        MODEL_NAMES[model], seed, "all" if S == G else "the first %d subject" % S, world)
 
 
-def secondary(kind, args, model, p_value, G=29, L=None, S=None, dlo=None, dhi=None):
+def secondary(kind, args, model, p_value, G=29, L=None, S=None, dlo=None, dhi=None, seam=False):
     """The same step on another set (one GPU, after the headline's timed region): structured genomes, the tree-structured
     variant, and a call of BASELINE's config 3 (S subject rows of the 3085-genome set: the shape the north_star's target
     is stated on) -- reported beside, never instead of, the star headline."""
@@ -191,18 +200,86 @@ def secondary(kind, args, model, p_value, G=29, L=None, S=None, dlo=None, dhi=No
     tm = ctx.timings()
     scan_ms = tm["scan_ms"] / max(int(tm["scan_launches"]), 1)
     alg = 2.0 * tm["scan_query_nt"] / max(int(tm["scan_launches"]), 1)
-    out = {"workload": workload_name(kind, G, S, L, dlo, dhi, args.seed, 1),
+    out = {"workload": workload_name(kind, G, S, L, dlo, dhi, args.seed, 1, model),
            "pairs_per_s": S * (G - 1) / (el / steps), "ms_per_step": 1e3 * el / steps,
            "roofline_frac": alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if scan_ms > 0 else None,
            "pass_a_kernel": pass_a_of(tm)[0], "pass_a_query_nt_fraction": pass_a_of(tm)[1],
            "index_build_ms": tm["build_ms"] / steps, "scan_cold_pass_ms": tm["scan_ms"] / steps,
            "scan_stitch_reduce_ms": tm["stitch_ms"] / steps, "fixups_per_step": int(tm["fixups"]) // steps}
+    if seam:  # the same job once through the one-call seam (everything included), and its matrix against the step's
+        import numpy as np
+        step_M = np.empty((S, G, 17), np.uint32)
+        ctx._check(lib.load().andi_hip_copy_to_host(ctx._h, step_M.ctypes.data, M, step_M.nbytes), "copy_to_host")
     ctx.free(M)
     for e in esas:
         e.close()
     Q.close()
     ctx.close()
+    if seam:
+        t0 = time.time()
+        M1 = andi_amd.dist_matrix(seqs, p_value=p_value, model=model)
+        out["dist_matrix_e2e_s"] = time.time() - t0
+        out["dist_matrix_pairs_per_s"] = G * (G - 1) / out["dist_matrix_e2e_s"]
+        out["dist_matrix_equals_step"] = bool((M1[:S] == step_M).all())
+        i, j = 0, G - 1
+        out["sample_distance"] = andi_amd.estimate(M1[i, j].astype(np.uint64) + M1[j, i], model)
     return out
+
+
+def c3_strong(args, p_value, world, rank, local_rank, dist, torch):
+    """BASELINE's configs[2] as it is written -- 109 genomes of 5.1 Mbp, Kimura, 'pair-tile sharding 1 -> 8': the SAME matrix
+    whatever the number of GPUs (strong scaling), its rows block-partitioned over the ranks, one gather per step; all ranks
+    call this after the headline's timed region.  Returns the record on rank 0."""
+    import numpy as np
+    import andi_amd
+    from andi_amd import lib, shard
+    G, L, dlo, dhi, model = 109, 5_100_000, 1e-4, 5e-3, MODELS["kimura"]
+    seqs = make_set("fast", G, L, dlo, dhi, args.seed)
+    r0, r1 = shard.row_block(G, world, rank)
+    ctx = andi_amd.Context(local_rank)
+    ctx.expect_queries(G - 1)
+    Q = andi_amd.Queries(ctx, seqs)
+    esas = [andi_amd.Esa(ctx, seqs[i], p_value, build=False, sa="device") for i in range(r0, r1)]
+    block = torch.zeros((shard.max_rows(G, world), G, 17), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    dptr = andi_amd.lib._P(block.data_ptr())
+    selfs = list(range(r0, r1))
+    gathered = [None]
+
+    def step():
+        lib.build_indexes(ctx, esas)
+        lib.scan_rows_dev(ctx, esas, selfs, Q, model, 0, dptr)
+        ctx.sync()
+        gathered[0] = shard.gather_matrix(block, G, dist, world, rank, force=dist is not None)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step()
+    fence()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    for e in esas:
+        e.close()
+    Q.close()
+    ctx.close()
+    if rank != 0:
+        return None, None, None
+    full = gathered[0]
+    rec = {"workload": workload_name("fast", G, G, L, dlo, dhi, args.seed, world, model), "scaling": "strong",
+           "n_gpus": world, "ms_per_step": 1e3 * el / steps, "pairs_per_s": G * (G - 1) / (el / steps),
+           "sample_distance": andi_amd.estimate(full[0, G - 1].astype(np.uint64) + full[G - 1, 0], model)}
+    return rec, full, ("fast", G, L, dlo, dhi, model)
 
 
 def seam_child(spec):
@@ -212,12 +289,12 @@ def seam_child(spec):
     import numpy as np
     import andi_amd
     from andi_amd import lib
-    kind, G, length, dlo, dhi, seed, gpus, path = spec.split(",")
+    kind, G, length, dlo, dhi, seed, gpus, path, model = spec.split(",")
     seqs = make_set(kind, int(G), int(length), float(dlo), float(dhi), int(seed))
     out = {"gpus_visible": lib.device_count()}
     try:
         t0 = time.time()
-        M = andi_amd.dist_matrix(seqs, model=andi_amd.M_JC, num_gpus=int(gpus))
+        M = andi_amd.dist_matrix(seqs, model=int(model), num_gpus=int(gpus))
         out["seam_multi_gpu_s"] = time.time() - t0
         out["gather"] = lib.last_gather()
         np.save(path, M)
@@ -261,7 +338,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     G = args.genomes or shard.weak_scaling_set_size(world)
-    model = andi_amd.M_JC
+    model = MODELS[args.model]
     p_value = 0.025
     t_gen = time.time()
     seqs = make_set(args.set, G, args.length, args.dlo, args.dhi, args.seed)
@@ -369,8 +446,8 @@ def main():
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload_name(args.set, G, S, args.length, args.dlo, args.dhi, args.seed, world),
-                       "genomes": G, "subjects": S, "length": args.length, "model": "JC", "pairs": pairs_total,
+            "config": {"workload": workload_name(args.set, G, S, args.length, args.dlo, args.dhi, args.seed, world, model),
+                       "genomes": G, "subjects": S, "length": args.length, "model": MODEL_NAMES[model], "pairs": pairs_total,
                        "segment": args.segment or ("auto (pass A routed per pair: by wavefronts on segments of 32768 ... 524288 symbols (shorter in small calls), by lanes on segments chosen per pair, 2048 ... 16384)" if tm["routed_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -446,9 +523,9 @@ def main():
             "dist_matrix_traced_call": traced, "host_load_average": list(os.getloadavg()),
             "dist_matrix_e2e_s_suffix_arrays_on_host": e2e_host, "host_cores": os.cpu_count(),
             "dist_matrix_equals_step": bool((M1 == full).all() and (M1w == full).all() and (M2 == full).all())})
-    if rank == 0 and world > 1:
-        # the product's own multi-GPU path (api.hip: andi_hip_dist_matrix with num_gpus = N, RCCL gather behind the C-ABI) on
-        # the same set, in a child process, after the timed region; the other ranks wait at the barrier below
+    def seam_on_all_gpus(kind, G_, L_, dlo_, dhi_, model_, full_):
+        """the product's own multi-GPU path (api.hip: andi_hip_dist_matrix with num_gpus = N, RCCL gather behind the C-ABI) on a
+        set, in a child process (a subprocess -- never a re-exec), after the timed region; the other ranks wait at the barrier"""
         import subprocess
         import tempfile
         path = os.path.join(tempfile.gettempdir(), "andi_seam_%d.npy" % os.getpid())
@@ -456,25 +533,38 @@ def main():
                if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
                and not k.startswith("TORCHELASTIC") and not k.startswith("TORCH_NCCL")}
         env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-        spec = ",".join(str(x) for x in (args.set, G, args.length, args.dlo, args.dhi, args.seed, world, path))
+        spec = ",".join(str(x) for x in (kind, G_, L_, dlo_, dhi_, args.seed, world, path, model_))
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--seam-child", spec], env=env, cwd=ROOT,
                                capture_output=True, text=True, timeout=900)
             line = [l for l in r.stdout.splitlines() if l.startswith("SEAM ")]
             res = json.loads(line[-1][5:]) if line else {"error": "no result; rc %d; %s" % (r.returncode, r.stderr[-600:])}
             if os.path.exists(path):
-                res["equals_gathered_matrix"] = bool((np.load(path)[:S] == full).all())
+                res["equals_gathered_matrix"] = bool((np.load(path)[:len(full_)] == full_).all())
                 os.remove(path)
         except Exception as e:
             res = {"error": repr(e)}
-        out["end_to_end"]["seam_multi_gpu"] = res
+        return res
+
+    if rank == 0 and world > 1:
+        out["end_to_end"]["seam_multi_gpu"] = seam_on_all_gpus(args.set, G, args.length, args.dlo, args.dhi, model, full)
+    strong = world > 1 or os.environ.get("ANDI_BENCH_C3_STRONG")  # (the variable: the code path on one GPU, for testing)
+    if strong and args.set == "star" and not args.subjects and not args.genomes:
+        # BASELINE's configs[2] itself: the same 109-genome Kimura matrix on the N ranks, and through the seam's own tiler
+        rec, c3_full, c3_spec = c3_strong(args, p_value, world, rank, local_rank, dist if use_dist else None, torch)
+        if rank == 0:
+            rec["seam_multi_gpu"] = seam_on_all_gpus(*c3_spec, c3_full)
+            out.setdefault("extra", {})["c3_strong"] = rec
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and world == 1 and not args.no_extra and args.set == "star" and not args.subjects:
-        out["extra"] = {"realistic": secondary("realistic", args, model, p_value),
-                        "tree_structured": secondary("tree", args, model, p_value),
-                        "c4_shape": secondary("star", args, model, p_value, G=3085, L=2_100_000, S=8, dlo=0.001, dhi=0.015)}
+        out.setdefault("extra", {}).update({
+            "realistic": secondary("realistic", args, model, p_value),
+            "tree_structured": secondary("tree", args, model, p_value),
+            "c4_shape": secondary("star", args, model, p_value, G=3085, L=2_100_000, S=8, dlo=0.001, dhi=0.015),
+            # BASELINE's configs[2] at full size on one GPU: the step, and the whole job once through the one-call seam
+            "c3": secondary("fast", args, MODELS["kimura"], p_value, G=109, L=5_100_000, dlo=1e-4, dhi=5e-3, seam=True)})
     if rank == 0:
         print(json.dumps(out))
 

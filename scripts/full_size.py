@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""BASELINE configs 3 and 4 at FULL size through the one-call seam andi_hip_dist_matrix, on one GPU.
+"""BASELINE configs 2, 3 and 4 at FULL size through the one-call seam andi_hip_dist_matrix, on one GPU.
 
+  c3: 109 genomes x 5.1 Mbp (C3-synth: d ~ U[1e-4, 5e-3]), Kimura -- BASELINE.json configs[2] on one GPU.
   c4: 3085 genomes x 2.1 Mbp (C4-synth, SURVEY.md 8d: d ~ U[1e-3, 1.5e-2]) -- the 3085 x 3085 matrix,
       386 batches of slot reuse, 3085 device suffix sorts, a 647 MB matrix.
   c5: 256 genomes x 50 Mbp (d ~ U[1e-3, 5e-2]) + 99 bootstrap matrices on the device.
 
-Evidence written to gpurun_out/r05_<config>_full.json: wall-clock of the call, the ANDI_E2E_TRACE split (stderr of
+Evidence written to gpurun_out/r06_<config>_full.json: wall-clock of the call, the ANDI_E2E_TRACE split (stderr of
 the library, captured), sampled rows against the oracle, and the oracle's OpenMP port timed on a row sample on all
 host cores (checker code: timed as a baseline only).  /root/reference is not needed.
 """
@@ -47,7 +48,7 @@ def fast_set(n, length, d_lo, d_hi, seed, threads):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=("c4", "c5"))
+    ap.add_argument("config", choices=("c3", "c4", "c5"))
     ap.add_argument("--genomes", type=int, default=0)
     ap.add_argument("--length", type=int, default=0)
     ap.add_argument("--check-rows", type=int, default=3)
@@ -56,7 +57,9 @@ def main():
     ap.add_argument("--low-memory", action="store_true")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
-    if args.config == "c4":
+    if args.config == "c3":
+        G, L, dlo, dhi, model_name = args.genomes or 109, args.length or 5_100_000, 1e-4, 5e-3, "Kimura"
+    elif args.config == "c4":
         G, L, dlo, dhi, model_name = args.genomes or 3085, args.length or 2_100_000, 1e-3, 1.5e-2, "JC"
     else:
         G, L, dlo, dhi, model_name = args.genomes or 256, args.length or 50_000_000, 1e-3, 5e-2, "JC"
@@ -69,7 +72,7 @@ def main():
     t0 = time.time()
     seqs, ds = fast_set(G, L, dlo, dhi, 1729, min(cores, 64))
     t_gen = time.time() - t0
-    model = andi_amd.M_JC
+    model = andi_amd.M_KIMURA if model_name == "Kimura" else andi_amd.M_JC
 
     # the library's trace goes to the C stderr: capture it through a file
     os.environ["ANDI_E2E_TRACE"] = "1"
@@ -145,7 +148,19 @@ def main():
                             "mean_total_ratio": float(np.mean(B[0][:, :, :16].astype(np.int64).sum(axis=2)[iu] / np.maximum(1, (tot + tot.T)[iu])))}
         ctx.close()
 
-    path = args.out or os.path.join(ROOT, "gpurun_out", "r05_%s_full.json" % args.config)
+    if model_name == "Kimura":  # the distances themselves for a few pairs (src/model.c:103-127): within 1e-9 of the oracle's -- they are equal
+        i = rows[0]
+        js = [j for j in (0, G // 2, G - 1) if j != i][:2]
+        O = orc.OracleEsa(seqs[i])
+        out["kimura_distances"] = []
+        for j in js:
+            Oj = orc.OracleEsa(seqs[j])
+            want = orc.estimate(O.dist_anchor(seqs[j], model).astype(np.uint64) + Oj.dist_anchor(seqs[i], model), model)
+            got = andi_amd.estimate(M[i, j].astype(np.uint64) + M[j, i], model)
+            out["kimura_distances"].append({"pair": [i, j], "gpu": got, "oracle": want, "abs_diff": abs(got - want)})
+            Oj.close()
+        O.close()
+    path = args.out or os.path.join(ROOT, "gpurun_out", "r06_%s_full.json" % args.config)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The suite drives the engine through its experiment switches and test hooks (forced kernels, layouts, segment lengths:
+# andi_amd/csrc/knobs.h); the shipped library does not have them.  So the suite loads libandihip_test.so -- the same
+# sources with -DANDI_TEST_HOOKS -- unless told otherwise (ANDI_HIP_LIB; ANDI_TESTS_SHIPPED_LIB=1: the shipped library, for
+# the tests that set no switch -- tests/test_configs_gpu.py::test_shipped_library_on_the_default_path runs those that way).
+if not os.environ.get("ANDI_HIP_LIB") and not os.environ.get("ANDI_TESTS_SHIPPED_LIB"):
+    os.environ["ANDI_HIP_LIB"] = os.path.join(ROOT, "andi_amd", "libandihip_test.so")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -19,7 +26,7 @@ def pytest_sessionstart(session):
     """The shared library is built in-tree and git-ignored: build it if this checkout has none
     (hipcc cross-compiles without a GPU; nothing here ever falls back to a CPU path)."""
     so = os.path.join(ROOT, "andi_amd", "libandihip.so")
-    if not os.path.exists(so):
+    if not os.path.exists(so) or not os.path.exists(os.path.join(ROOT, "andi_amd", "libandihip_test.so")):
         import __graft_entry__
         __graft_entry__.build()
 

@@ -283,3 +283,19 @@ def test_headline_set_every_ordered_pair_against_the_oracle(orc):
         c.close()
     # and the one-call seam on the same set
     assert (andi_amd.dist_matrix(seqs, model=andi_amd.M_JC) == want).all()
+
+
+def test_shipped_library_on_the_default_path():
+    """The suite loads libandihip_test.so (the sources with the test hooks compiled in, tests/conftest.py).  The tests that set
+    no switch -- the headline set's 812 pairs, the default path at 4.9 and 2.1 Mbp -- once more against libandihip.so itself, the
+    library the CLI and bench.py load, in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ANDI_TESTS_SHIPPED_LIB="1")
+    env.pop("ANDI_HIP_LIB", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_configs_gpu.py"), "-q", "-m", "gpu", "-x", "-k",
+                        "headline_set_every or default_path_at_headline or c4_shaped_call_at_full_length"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]

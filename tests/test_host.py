@@ -19,6 +19,19 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
     for name in declared:
         assert getattr(L, name) is not None
+    # the suite's library carries the test hooks (tests/conftest.py); the SHIPPED one exports the same symbols -- and knows none
+    # of the hooks' names (andi_amd/csrc/knobs.h: seven switches)
+    shipped_path = os.path.join(ROOT, "andi_amd", "libandihip.so")
+    shipped = C.CDLL(shipped_path)
+    for name in declared:
+        assert getattr(shipped, name) is not None
+    blob = open(shipped_path, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"ANDI_[A-Z0-9_]{3,}", blob))
+    knobs_h = open(os.path.join(ROOT, "andi_amd", "csrc", "knobs.h")).read()
+    listed = set("ANDI_" + n for n in re.findall(r"X\((\w+)\)", knobs_h.split("#define ANDI_KNOB_LIST_HOOKS")[0].split("#define ANDI_KNOB_LIST_SHIPPED(X)")[1]))
+    hooks = set("ANDI_" + n for n in re.findall(r"X\((\w+)\)", knobs_h.split("#define ANDI_KNOB_LIST_HOOKS(X)")[1].split("#define ANDI_KNOB_LIST(X)")[0]))
+    assert len(listed) <= 8 and listed <= names, (listed, listed - names)
+    assert hooks and not (hooks & names), hooks & names
     assert L.andi_hip_abi_version() == 4  # 2: opts.num_gpus, opts.devices; timings.adaptive_calls.  3: timings.routed_calls ...; andi_hip_esa_single_form.  4: andi_hip_trim (chunks outlive contexts)
     assert C.sizeof(lib.Model) == 68 and C.sizeof(lib.Interval) == 16
 
