@@ -532,7 +532,7 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 // Put a (new) subject into a slot: uploads only.  The caller may release RS/SA
 // as soon as this returns.
 static int esa_upload(andi_hip_ctx *ctx, andi_hip_esa *e, const char *RS, const int32_t *SA, size_t n,
-					  size_t threshold) {
+					  size_t threshold, hipEvent_t done = nullptr) { // done: do not wait -- the event says when RS (and SA) may be reused
 	if (n > e->cap) {
 		ctx->err = "subject does not fit its slot";
 		return 1;
@@ -543,13 +543,13 @@ static int esa_upload(andi_hip_ctx *ctx, andi_hip_esa *e, const char *RS, const 
 	e->ref_built = e->index_built = false;
 	e->rec_valid = false;
 	// the flags are functions of the text and its suffix array: cleared here, only ever set by the builds
-	hipError_t err = hipStreamSynchronize(ctx->stream);
+	hipError_t err = done ? hipSuccess : hipStreamSynchronize(ctx->stream); // (the slot is the caller's: nothing of it is in flight)
 	memset(e->h_flags, 0, 4 * sizeof(int32_t));
 	if (err == hipSuccess) err = hipMemsetAsync(e->S + n, 0, 1 + ANDI_PAD, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(e->S, RS, n, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess && SA)
 		err = hipMemcpyAsync(e->SA, SA, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+	if (err == hipSuccess) err = done ? hipEventRecord(done, ctx->stream) : hipStreamSynchronize(ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "uploading a subject", err);
 	return 0;
 }
@@ -1761,10 +1761,12 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	// the reference's threads build one subject's index while others scan (src/dist_hack.h:46-52).
 	struct Dev {
 		andi_hip_ctx *ctx = nullptr;  // scans, row copies
-		andi_hip_ctx *prep = nullptr; // uploads, suffix arrays, index builds
+		andi_hip_ctx *prep = nullptr; // suffix arrays, index builds
+		andi_hip_ctx *up = nullptr;   // uploads (a thread and a stream of their own: the copies of batch k + 1 run beside the sorts of batch k)
 		andi_hip_queries *Q = nullptr;
 		andi_hip_model *d_rows = nullptr; // rccl: the whole row block; direct: one batch of rows
-		char *pinned = nullptr;           // staging buffer for RS: uploads from pinned memory go through the DMA engines, beside a scan
+		char *pinned = nullptr;           // staging buffers for RS (two: one is filled while the other's copy runs): uploads from pinned memory go through the DMA engines, beside a scan
+		hipEvent_t pinned_free[2] = {nullptr, nullptr};
 		std::vector<andi_hip_esa *> slots; // sets x batch
 	};
 	std::vector<Dev> dv(ndev);
@@ -1807,6 +1809,8 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		};
 		if (andi_hip_ctx_create(&D.ctx, devs[d], eb, sizeof eb)) return bail("creating a context", nullptr);
 		if (ctx_create(&D.prep, devs[d], eb, sizeof eb, true)) return bail("creating a context", nullptr);
+		if (ctx_create(&D.up, devs[d], eb, sizeof eb, true)) return bail("creating a context", nullptr);
+		andi_hip_ctx_expect_queries(D.up, n - 1);
 		andi_hip_ctx_expect_queries(D.ctx, n - 1);
 		andi_hip_ctx_expect_queries(D.prep, n - 1);
 		lap(t_ctx);
@@ -1855,7 +1859,11 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		if (andi_hip_sync(D.prep)) return bail("allocating subject slots", D.prep);
 		double t_reserve = 0, t_pinned = 0;
 		lap(t_reserve);
-		if (hipHostMalloc((void **)&D.pinned, rs_cap + 1, hipHostMallocDefault) != hipSuccess) D.pinned = nullptr; // (then from where RS lies)
+		if (hipHostMalloc((void **)&D.pinned, 2 * (rs_cap + 64), hipHostMallocDefault) != hipSuccess) D.pinned = nullptr; // (then from where RS lies)
+		if (D.pinned && (hipEventCreateWithFlags(&D.pinned_free[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.pinned_free[1], hipEventDisableTiming) != hipSuccess)) {
+			(void)hipHostFree(D.pinned);
+			D.pinned = nullptr;
+		}
 		lap(t_pinned);
 		if (andi_hip_dev_alloc(D.ctx, (use_rccl ? rows : batch) * n * sizeof(andi_hip_model), (void **)&D.d_rows)) return bail("row buffer", D.ctx);
 		lap(t_slots);
@@ -1869,18 +1877,20 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		bool prep_failed = false;
 		double p_take = 0, p_upload = 0, p_sort = 0, p_build = 0;
 
-		auto stage = [&]() { // the staging thread of this device
+		size_t uploaded = 0; // batches whose texts are on the device
+		auto give_up = [&]() {
+			std::lock_guard<std::mutex> lk(pm);
+			prep_failed = true;
+			pcv.notify_all();
+		};
+		auto upload = [&]() { // the upload thread of this device: texts from the host pool into the slot sets, a batch ahead of the sorts
 			(void)hipSetDevice(devs[d]);
 			double tl = now_ms();
 			auto plap = [&](double &acc) {
 				const double t = now_ms();
 				acc += t - tl, tl = t;
 			};
-			auto give_up = [&]() {
-				std::lock_guard<std::mutex> lk(pm);
-				prep_failed = true;
-				pcv.notify_all();
-			};
+			size_t nup = 0; // texts uploaded so far
 			for (size_t k = 0; k < nbatches; ++k) {
 				{
 					std::unique_lock<std::mutex> lk(pm);
@@ -1901,9 +1911,14 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 						fail_all(msg);
 						ok = false;
 					}
+					// through one of two pinned buffers: the next text is copied into the other while this one's transfer runs
+					const bool two = D.pinned && !o.sa_on_host; // (a suffix array from the host is pageable memory: that copy waits anyway)
+					const size_t pb = nup++ & 1;
+					char *pin = D.pinned ? D.pinned + pb * (rs_cap + 64) : nullptr;
+					if (ok && two && nup > 2 && hipEventSynchronize(D.pinned_free[pb]) != hipSuccess) bail("staging subject", D.up), ok = false;
 					const char *src = p->RS;
-					if (ok && D.pinned) memcpy(D.pinned, p->RS, p->n), src = D.pinned; // (esa_upload waits for the copy: one buffer does)
-					if (ok && esa_upload(D.prep, set[b], src, o.sa_on_host ? p->SA.data() : nullptr, p->n, p->thr)) bail("staging subject", D.prep), ok = false;
+					if (ok && pin) memcpy(pin, p->RS, p->n), src = pin;
+					if (ok && esa_upload(D.up, set[b], src, o.sa_on_host ? p->SA.data() : nullptr, p->n, p->thr, two ? D.pinned_free[pb] : nullptr)) bail("staging subject", D.up), ok = false;
 					plap(p_upload);
 					andi_hip_free(p->RS);
 					delete p;
@@ -1914,12 +1929,34 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 					cv.notify_all();
 					if (!ok) return give_up();
 				}
-				if (sets == 3) { // the device's compute is this batch's once the scan of batch k - 2 is done
-					std::unique_lock<std::mutex> lk(pm);
-					pcv.wait(lk, [&] { return k < scanned + 2 || prep_failed; });
-					if (prep_failed) return;
-					tl = now_ms();
+				if (andi_hip_sync(D.up)) { // (the batch's transfers)
+					bail("staging subject", D.up);
+					return give_up();
 				}
+				plap(p_upload);
+				{
+					std::lock_guard<std::mutex> lk(pm);
+					uploaded = k + 1;
+				}
+				pcv.notify_all();
+			}
+		};
+		auto stage = [&]() { // the staging thread of this device: suffix sorts and index builds
+			(void)hipSetDevice(devs[d]);
+			double tl = now_ms();
+			auto plap = [&](double &acc) {
+				const double t = now_ms();
+				acc += t - tl, tl = t;
+			};
+			for (size_t k = 0; k < nbatches; ++k) {
+				{ // the batch's texts are there; with three sets the device's compute is this batch's once the scan of batch k - 2 is done
+					std::unique_lock<std::mutex> lk(pm);
+					pcv.wait(lk, [&] { return (uploaded > k && (sets < 3 || k < scanned + 2)) || prep_failed; });
+					if (prep_failed) return;
+				}
+				tl = now_ms();
+				const size_t i0 = first[d] + k * batch, nb = std::min(batch, last[d] - i0);
+				andi_hip_esa **set = D.slots.data() + (k % sets) * batch;
 				for (size_t b = 0; b < nb && !o.sa_on_host; ++b) {
 					if (esa_sort_suffixes(D.prep, set[b])) {
 						bail("suffix array", D.prep);
@@ -1939,6 +1976,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 				pcv.notify_all();
 			}
 		};
+		std::thread uploader(upload);
 		std::thread stager(stage);
 
 		std::vector<int64_t> self(batch);
@@ -1979,6 +2017,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		}
 		pcv.notify_all();
 		stager.join();
+		uploader.join();
 		if (trace && d == 0)
 			fprintf(stderr, "andi_hip_dist_matrix trace (ms): contexts %.1f, queries %.1f, slots %.1f | staging thread: waiting for the host pool %.1f, subject uploads %.1f, suffix arrays %.1f, index builds %.1f | scan thread: waiting for staged subjects %.1f, scans %.1f, row copies %.1f; driver total %.1f (%zu batches of %zu, %zu slot sets)\n",
 					t_ctx, t_queries, t_slots, p_take, p_upload, p_sort, p_build, acc_wait, acc_scan, acc_copy, now_ms() - t_call, nbatches, batch, sets);
@@ -2081,6 +2120,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	for (auto &D : dv) {
 		if (!D.ctx) {
 			if (D.prep) andi_hip_ctx_destroy(D.prep);
+			if (D.up) andi_hip_ctx_destroy(D.up);
 			continue;
 		}
 		for (auto *e : D.slots)
@@ -2088,7 +2128,10 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		if (D.d_rows) andi_hip_dev_free(D.ctx, D.d_rows);
 		if (D.Q) andi_hip_queries_free(D.ctx, D.Q);
 		if (D.pinned) (void)hipHostFree(D.pinned);
+		for (hipEvent_t ev : D.pinned_free)
+			if (ev) (void)hipEventDestroy(ev);
 		if (D.prep) andi_hip_ctx_destroy(D.prep);
+		if (D.up) andi_hip_ctx_destroy(D.up);
 		andi_hip_ctx_destroy(D.ctx);
 	}
 	if (trace) fprintf(stderr, "andi_hip_dist_matrix trace: call total %.1f ms\n", now_ms() - t_call);
