@@ -45,6 +45,7 @@ struct EsaDev {
 	const uint2 *deep;
 	const int32_t *flags;
 	const uint8_t *N0, *N1; // nibble-packed text, two alignments (scan_lane.hip)
+	const uint16_t *R2;     // per suffix, in suffix-array order: the (up to min(4, 16 - K)) nucleotides behind its first K symbols: count << 8 | 2-bit codes, first in the low bits (the device sorter's by-product; null: not there)
 	const uint32_t *P;      // the text bit-sliced (coop_pool.h): block b = words 3b, 3b+1, 3b+2 = bit 0, 1, 2 of the symbols 32b ... 32b+31; a block of padding in front
 	int32_t n;
 	int32_t thr;
@@ -70,6 +71,7 @@ typedef ANDI_GLOBAL const int32_t *g_i32p;
 typedef ANDI_GLOBAL const int4 *g_i4p;
 typedef ANDI_GLOBAL const uint2 *g_u2p;
 typedef ANDI_GLOBAL const uint32_t *g_u32p;
+typedef ANDI_GLOBAL const uint16_t *g_u16p;
 
 struct EsaG {
 	g_u8p S;
@@ -79,6 +81,7 @@ struct EsaG {
 	g_u2p deep;
 	g_u8p N0, N1;
 	g_u32p P;
+	g_u16p R2;
 	int32_t n, thr, deepK, mode, deep_ext;
 };
 
@@ -89,6 +92,7 @@ __device__ __forceinline__ EsaG esa_global(const EsaDev &e) {
 	g.deep = (g_u2p)e.deep;
 	g.N0 = (g_u8p)e.N0, g.N1 = (g_u8p)e.N1;
 	g.P = (g_u32p)e.P;
+	g.R2 = (g_u16p)e.R2;
 	g.n = e.n, g.thr = e.thr, g.deepK = e.deepK, g.mode = e.mode, g.deep_ext = e.deep_ext;
 	return g;
 }

@@ -276,6 +276,7 @@ EsaDev esa_view(const andi_hip_esa *e, int mode) {
 	v.S = e->S, v.SA = e->SA, v.LCP = e->LCP, v.CLD = e->CLD, v.FVC = e->FVC, v.tab = e->tab;
 	v.deep = e->deep, v.flags = e->flags;
 	v.N0 = e->N0, v.N1 = e->N1, v.P = e->P;
+	v.R2 = e->rec_valid ? e->rec2 : nullptr; // (made by the device sorter for this K: api.hip esa_sort_suffixes)
 	v.n = e->n, v.thr = e->thr, v.deepK = e->deepK, v.mode = mode, v.deep_ext = e->deep_ext;
 	return v;
 }

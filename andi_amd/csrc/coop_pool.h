@@ -451,7 +451,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 				if (mn) {
 					bool seen;
 					const uint32_t r = run_ahead(p, seen);
-					have = coop_probe_multi(c, p, sd, mx, mn, mq, r, seen, pr, long_diag);
+					have = coop_probe_multi<false>(c, p, sd, mx, mn, mq, r, seen, pr, long_diag); // (the sorter's records -- k_coop_cold's first try -- cost this kernel 12 more spilled registers: C4 shape 24.7 -> 28.9 ms)
 				}
 				if (!have) pr = generic_probe(p), long_diag = false;
 				have = true, parked = false;

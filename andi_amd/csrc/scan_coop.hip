@@ -355,16 +355,56 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 // occurrences' own matches, unique iff one attains it (as lane_probe).  The occurrence on the window's diagonal, if
 // there is one, is the run of equal symbols the bits show (*diag_run; *diag_seen: a mismatch of the window ends it);
 // the others are compared 16 symbols deep, two per round trip.  false: a match goes deeper than that -- lane_probe's.
+template <bool USE_R2 = true>
 __device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, uint32_t sd, uint32_t x, uint32_t n, uint32_t behind,
 												 uint32_t diag_run, bool diag_seen, Probe &r, bool &on_diag_long) {
 	const EsaG &E = c.E;
 	const uint32_t K = (uint32_t)E.deepK, qrem = c.qlen - p;
+	// First from what the device sorter left beside the suffix array (EsaDev.R2): the nucleotides behind every occurrence's
+	// K-mer, `room` of them -- ONE load of eight bytes where the suffix array's entries and the text behind each of them were
+	// three or more.  An occurrence whose symbols differ from the query's within them (or whose text ends there) is settled;
+	// the diagonal's occurrence (there is one iff the diagonal's run is at least K long) is the run the bits show.  What is
+	// left open -- an occurrence off the diagonal that matches all `room` symbols (one in 256) -- goes the long way below.
+	on_diag_long = false;
+	if (USE_R2 && E.R2 && !(n & 0x80000000u) && K + 4 <= qrem) {
+		const uint32_t room = 16u - K < 4u ? 16u - K : 4u;
+		const uint64_t w = ld_u64_unaligned((g_u8p)(E.R2 + x));
+		const bool diag_in = diag_run >= K; // the K-mer at p occurs on the diagonal: one of these occurrences
+		uint32_t open_n = 0, bestLen = 0, bestCnt = 0, bestIdx = 0;
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t e16 = (uint32_t)(w >> (16 * i)) & 0xffffu, nval = e16 >> 8;
+			const uint32_t diff = (behind ^ e16) & ((1u << (2 * nval)) - 1u);
+			const uint32_t m = diff ? (uint32_t)__builtin_ctz(diff) >> 1 : nval;
+			if (m == nval && nval == room) {
+				++open_n; // matches as far as the record goes
+				continue;
+			}
+			const uint32_t len = K + m; // a mismatch, or the text has no nucleotide there (m == nval < room)
+			if (len > bestLen) bestLen = len, bestCnt = 1, bestIdx = i;
+			else if (len == bestLen) ++bestCnt;
+		}
+		const bool diag_open = diag_in && (diag_run >= K + room || !diag_seen);
+		if (open_n == (diag_open ? 1u : 0u)) { // nothing open but the diagonal's own occurrence
+			if (diag_open) { // ... which beats every settled one
+				r.unique = true, r.pos = p + sd;
+				r.len = diag_seen ? diag_run : 0x40000000u;
+				on_diag_long = !diag_seen;
+				return true;
+			}
+			r.len = bestLen, r.unique = bestCnt == 1;
+			if (diag_in && bestLen == diag_run && bestCnt == 1) {
+				r.pos = p + sd; // the one occurrence of that length is the diagonal's
+			} else {
+				r.pos = (r.unique && bestLen >= (uint32_t)E.thr) ? (uint32_t)E.SA[x + bestIdx] : 0u; // (an anchor off the diagonal: rare)
+			}
+			return true;
+		}
+	}
 	uint4 pos4 = make_uint4(x, 0, 0, 0); // (n & 0x80000000: x is the one occurrence's position itself)
 	if (!(n & 0x80000000u)) pos4 = ld_u128_unaligned((g_u8p)(E.SA + x)); // (SA is padded by eight entries)
 	n &= 0x7fffffffu;
 	uint32_t bestLen = 0, bestCnt = 0, bestPos = 0;
 	bool deep = false;
-	on_diag_long = false;
 	for (uint32_t i = 0; i < n; i += 2) { // two occurrences per round trip
 		const uint32_t pa = i == 0 ? pos4.x : pos4.z, pb = i == 0 ? pos4.y : pos4.w;
 		const uint4 sa = ld_subject(c, (int32_t)(pa + K));
