@@ -1389,6 +1389,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->coop_stream, ctx->coop_fork, 0);
 			if (e == hipSuccess && lanes_first) e = andi_launch_scan_cold(a, ctx->stream);
 			if (e == hipSuccess) e = andi_launch_coop_cold(b, ctx->coop_stream);
+			if (andi_coop_will_pool(b)) ctx->acc.pool_calls++;
 			if (e == hipSuccess) e = hipEventRecord(ctx->coop_join, ctx->coop_stream);
 			if (e == hipSuccess && !lanes_first) e = andi_launch_scan_cold(a, ctx->stream);
 			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->coop_join, 0);
@@ -1455,6 +1456,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			t.stop();
 			if (e != hipSuccess) return fail(ctx, "scan pass A", e);
 			if (a.coop) ctx->acc.coop_calls++;
+			if (a.coop && andi_coop_will_pool(a)) ctx->acc.pool_calls++;
 		}
 		Timed t(ctx, 2);
 		hipError_t e = andi_launch_scan_stitch(a, ctx->stream);

@@ -146,6 +146,7 @@ hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 // pass A with one wavefront per chain (scan_coop.hip)
 int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: the engine chooses -- tiny calls every pair, others routed per pair (the default); n = 2, 4, 8: every pair, windows of 2048 n symbols
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st);
+int andi_coop_will_pool(const ScanArgs &a); // that launch is k_pool_cold's (coop_pool.h), not k_coop_cold's
 size_t andi_pool_scratch_bytes(int device, uint32_t *waves); // the pooled kernels' scratch (4096 bytes for the ticket in front); 0: those kernels are off (ANDI_POOL=0)
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);
 hipError_t andi_launch_lane_quad_small(const ScanArgs &a, uint32_t count, hipStream_t st); // k_lane_quad, one wavefront per block (scan_lane.hip compiled a second time)

@@ -355,18 +355,19 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 // occurrences' own matches, unique iff one attains it (as lane_probe).  The occurrence on the window's diagonal, if
 // there is one, is the run of equal symbols the bits show (*diag_run; *diag_seen: a mismatch of the window ends it);
 // the others are compared 16 symbols deep, two per round trip.  false: a match goes deeper than that -- lane_probe's.
-template <bool USE_R2 = true>
-__device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, uint32_t sd, uint32_t x, uint32_t n, uint32_t behind,
-												 uint32_t diag_run, bool diag_seen, Probe &r, bool &on_diag_long) {
+// The probe of a K-mer that occurs n <= 4 times (at SA[x ...]) from what the device sorter left beside the suffix array
+// (EsaDev.R2): the nucleotides behind every occurrence's K-mer, `room` of them -- ONE load of eight bytes where the suffix
+// array's entries and the text behind each of them were three or more.  An occurrence whose symbols differ from the query's
+// within them (or whose text ends there) is settled; the diagonal's occurrence (there is one iff the diagonal's run is at
+// least K long) is the run the bits show.  false: something is left open -- an occurrence off the diagonal that matches all
+// `room` symbols (one in 256) -- or the records are not there: coop_probe_multi's long way.
+__device__ __forceinline__ bool coop_probe_r2(const PairCtx &c, uint32_t p, uint32_t sd, uint32_t x, uint32_t n, uint32_t behind,
+											  uint32_t diag_run, bool diag_seen, Probe &r, bool &on_diag_long) {
 	const EsaG &E = c.E;
 	const uint32_t K = (uint32_t)E.deepK, qrem = c.qlen - p;
-	// First from what the device sorter left beside the suffix array (EsaDev.R2): the nucleotides behind every occurrence's
-	// K-mer, `room` of them -- ONE load of eight bytes where the suffix array's entries and the text behind each of them were
-	// three or more.  An occurrence whose symbols differ from the query's within them (or whose text ends there) is settled;
-	// the diagonal's occurrence (there is one iff the diagonal's run is at least K long) is the run the bits show.  What is
-	// left open -- an occurrence off the diagonal that matches all `room` symbols (one in 256) -- goes the long way below.
 	on_diag_long = false;
-	if (USE_R2 && E.R2 && !(n & 0x80000000u) && K + 4 <= qrem) {
+	if (!E.R2 || (n & 0x80000000u) || K + 4 > qrem) return false;
+	{
 		const uint32_t room = 16u - K < 4u ? 16u - K : 4u;
 		const uint64_t w = ld_u64_unaligned((g_u8p)(E.R2 + x));
 		const bool diag_in = diag_run >= K; // the K-mer at p occurs on the diagonal: one of these occurrences
@@ -400,6 +401,16 @@ __device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, u
 			return true;
 		}
 	}
+	return false;
+}
+
+template <bool USE_R2 = true>
+__device__ __forceinline__ bool coop_probe_multi(const PairCtx &c, uint32_t p, uint32_t sd, uint32_t x, uint32_t n, uint32_t behind,
+												 uint32_t diag_run, bool diag_seen, Probe &r, bool &on_diag_long) {
+	const EsaG &E = c.E;
+	const uint32_t K = (uint32_t)E.deepK, qrem = c.qlen - p;
+	on_diag_long = false;
+	if (USE_R2 && coop_probe_r2(c, p, sd, x, n, behind, diag_run, diag_seen, r, on_diag_long)) return true;
 	uint4 pos4 = make_uint4(x, 0, 0, 0); // (n & 0x80000000: x is the one occurrence's position itself)
 	if (!(n & 0x80000000u)) pos4 = ld_u128_unaligned((g_u8p)(E.SA + x)); // (SA is padded by eight entries)
 	n &= 0x7fffffffu;
@@ -663,6 +674,20 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 				if (inwin && !res) { // the probe (the lucky attempt has failed or does not apply: it is not repeated)
 					bool on_diag;
 					have = coop_probe_fast<NCH>(c, L, wbase, clean, p, sd, pr, on_diag, mx, mn, mq);
+					if (!have && mn) { // a K-mer with a few occurrences: the sorter's records settle it as a rule -- no wait for the parked lanes' turn
+						bool long_diag;
+						if (coop_probe_r2(c, p, sd, mx, mn, mq, r, seen, pr, long_diag)) {
+							have = true;
+							if (long_diag && pr.unique) { // the diagonal's occurrence is the longest, longer than the bits at hand show
+								if (wbase + W - p >= 32) {
+									const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
+									res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
+								} else {
+									have = false; // (the window's end: lane_probe's)
+								}
+							}
+						}
+					}
 					if (on_diag) { // the K-mer's one occurrence is the diagonal's: the bits know the match
 						pr.unique = true, pr.pos = p + sd, pr.len = r;
 						if (!seen && left < 32) have = false; // (the window's end: lane_probe follows the occurrence)
@@ -1123,13 +1148,17 @@ size_t andi_pool_scratch_bytes(int device, uint32_t *waves) {
 	return 4096 + (size_t)*waves * pool_scratch_bytes(POOL_FUSED_CHUNKS, POOL_FUSED_HC);
 }
 
+int andi_coop_will_pool(const ScanArgs &a) {
+	const int nch = andi_coop_enabled();
+	return !a.exact_equal && a.pool_scratch && a.pool_waves && pool_enabled() && (nch < 0 || nch == 4) && a.seg >= 32768 && (!a.route || a.pool_use);
+}
+
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one segment length for the call, RAW/JC/Kimura
 	const dim3 grid((a.total_segs + COOP_WAVES - 1) / COOP_WAVES, a.nsub);
 	const int nch = andi_coop_enabled();
-	const bool pooled = !a.exact_equal && a.pool_scratch && a.pool_waves && pool_enabled() && (nch < 0 || nch == 4);
 	// The windows' walks pooled through global memory (k_pool_cold: persistent wavefronts take the segments in order): segments long enough
 	// to fill its windows; in a routed call where the pairs with long sampled matches hold most of the segments (ScanArgs.pool_use)
-	if (pooled && a.seg >= 32768 && (!a.route || a.pool_use)) {
+	if (andi_coop_will_pool(a)) {
 		const uint64_t items = (uint64_t)a.total_segs * a.nsub;
 		ScanArgs b = a;
 		b.pool_first = 64;

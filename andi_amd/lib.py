@@ -73,6 +73,7 @@ class Timings(C.Structure):
         ("routed_calls", C.c_uint64),
         ("coop_query_nt", C.c_uint64),
         ("lane_query_nt", C.c_uint64),
+        ("pool_calls", C.c_uint64),
     ]
 
 

@@ -130,10 +130,11 @@ def pass_a_of(tm):
     if tm["routed_calls"]:
         c, l = float(tm["coop_query_nt"]), float(tm["lane_query_nt"])
         tot = max(c + l, 1.0)
-        name = "k_coop_cold" if l == 0 else ("k_lane_cold" if c == 0 else "k_coop_cold+lanes")
-        return name, {"k_coop_cold": c / tot, "lanes (k_lane_cold, k_lane_quad)": l / tot,
+        wk = "k_pool_cold" if int(tm.get("pool_calls", 0)) >= max(int(tm["routed_calls"]), 1) else "k_coop_cold"  # which wavefront kernel the calls chose
+        name = wk if l == 0 else ("k_lane_cold" if c == 0 else wk + "+lanes")
+        return name, {wk: c / tot, "lanes (k_lane_cold, k_lane_quad)": l / tot,
                       "pairs_handed_back_per_call": int(tm["coop_fallbacks"]) / max(int(tm["routed_calls"]), 1)}
-    return ("k_coop_cold" if tm["coop_calls"] >= launches else "k_lane_cold"), None
+    return (("k_pool_cold" if int(tm.get("pool_calls", 0)) >= launches else "k_coop_cold") if tm["coop_calls"] >= launches else "k_lane_cold"), None
 
 
 MODELS = {"raw": 0, "jc": 1, "kimura": 2}  # andi_amd.M_RAW, M_JC, M_KIMURA (include/andi_hip.h)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ANDI_HIP_ABI_VERSION 4
+#define ANDI_HIP_ABI_VERSION 5
 
 /* enum in src/global.h:50 */
 enum { ANDI_M_RAW = 0, ANDI_M_JC = 1, ANDI_M_KIMURA = 2, ANDI_M_LOGDET = 3, ANDI_M_ANI = 4 };
@@ -251,6 +251,7 @@ typedef struct {
 	uint64_t routed_calls;   /* scan calls whose pass A was routed per pair (by default calls of 2^25 query symbols x subjects and more) */
 	uint64_t coop_query_nt;  /* routed calls: query nucleotides of the pairs whose pass A ran by wavefronts ... */
 	uint64_t lane_query_nt;  /* ... and by lanes */
+	uint64_t pool_calls;     /* scan calls whose pass A by wavefronts was k_pool_cold's (the windows' walks pooled through global memory), not k_coop_cold's (ABI 5) */
 } andi_hip_timings;
 
 /* The library's ANDI_* environment switches (experiments, diagnostics: INTEGRATION.md lists them) are read once, when

@@ -12,7 +12,7 @@ summary, bench, kept_as = sys.argv[1:4]
 line = json.loads(open(bench).read().strip().splitlines()[-1])
 kernel = line["roofline"]["kernel"]
 # a routed call's pass A ("k_coop_cold+lanes") is the wavefront kernel beside the lane scan's: their counters are added
-parts = ["k_coop_cold", "k_lane_cold", "k_lane_quad"] if "+lanes" in kernel else [kernel]
+parts = ["k_coop_cold", "k_pool_cold", "k_lane_cold", "k_lane_quad"] if "+lanes" in kernel else [kernel]
 fetch = write = 0.0
 seen = []
 name = None
@@ -32,7 +32,7 @@ for ln in open(summary):
 if not seen:
     sys.exit("traffic.py: no FETCH_SIZE / WRITE_SIZE of %s in %s" % (kernel, summary))
 raw = (fetch + write) * 1024.0
-stream = line["roofline"]["algorithmic_bytes_per_launch"] / 2.0 if "coop" in kernel else 0.0  # 1 B per query nt
+stream = line["roofline"]["algorithmic_bytes_per_launch"] / 2.0 if ("coop" in kernel or "pool" in kernel) else 0.0  # 1 B per query nt (k_pool_cold: 0.75 B, bit-sliced)
 cfg = line["config"]
 key = "G%d_L%d_seg0" % (cfg["genomes"], cfg["length"])
 print(json.dumps({

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     hooks = set("ANDI_" + n for n in re.findall(r"X\((\w+)\)", knobs_h.split("#define ANDI_KNOB_LIST_HOOKS(X)")[1].split("#define ANDI_KNOB_LIST(X)")[0]))
     assert len(listed) <= 8 and listed <= names, (listed, listed - names)
     assert hooks and not (hooks & names), hooks & names
-    assert L.andi_hip_abi_version() == 4  # 2: opts.num_gpus, opts.devices; timings.adaptive_calls.  3: timings.routed_calls ...; andi_hip_esa_single_form.  4: andi_hip_trim (chunks outlive contexts)
+    assert L.andi_hip_abi_version() == 5  # 2: opts.num_gpus, opts.devices; timings.adaptive_calls.  3: timings.routed_calls ...; andi_hip_esa_single_form.  4: andi_hip_trim (chunks outlive contexts).  5: timings.pool_calls
     assert C.sizeof(lib.Model) == 68 and C.sizeof(lib.Interval) == 16
 
 
