@@ -285,3 +285,69 @@ def test_ragged_rows_thresholds_and_windows_full_of_heads():
             with knobs(COOP=coop):
                 got = andi_amd.dist_matrix([a, b, c], p_value=p_value, model=andi_amd.M_RAW)
             assert (got == want).all(), (p_value, coop)
+
+
+# ------------------------------------------------------------------ k_pool_cold (coop_pool.h): the windows' walks pooled through global memory
+def _pooled_rows(seqs, model, segment, **kn):
+    """every pair by the forced wavefront kernel on segments long enough for its pooled form; checks that k_pool_cold ran"""
+    with knobs(COOP=4, POOL=None, **kn):
+        ctx = andi_amd.Context(0)
+        Q = andi_amd.Queries(ctx, seqs)
+        esas = [andi_amd.Esa(ctx, s, sa="device") for s in seqs]
+        ctx.timings_reset()
+        got = andi_amd.scan_rows(ctx, esas, list(range(len(seqs))), Q, model=model, segment=segment)
+        t = ctx.timings()
+        for e in esas:
+            e.close()
+        Q.close()
+        ctx.close()
+    assert t["pool_calls"] == 1 and t["coop_calls"] == 1 and t["fixups"] == 0, t
+    return got
+
+
+def test_pooled_walks_divergence_ladder():
+    base = synth.base_codes(300000, 5)
+    seqs = [synth.to_bytes(synth.mutate_codes(base, d, 10 + k)) for k, d in enumerate((0.0, 0.0005, 0.005, 0.02, 0.05, 0.15))]
+    want = orc.dist_matrix(seqs, model=orc.M_JC, threads=4)
+    for segment in (32768, 65536, 262144):
+        for first in (None, 1, 3):  # (the first window's length: whole segments, 2048 and 6144 positions)
+            got = _pooled_rows(seqs, andi_amd.M_JC, segment, POOL_FIRST=first)
+            assert (got == want).all(), "segment %d, first window %s: pairs %s" % (segment, first, np.argwhere((got != want).any(axis=2))[:8].tolist())
+
+
+def test_pooled_walks_structured_strands_contigs_edges():
+    seqs, _ = synth.realistic_set(5, 400000, 0.002, 0.04, seed=23)
+    want = orc.dist_matrix(seqs, model=orc.M_KIMURA, threads=5)
+    for segment in (32768, 131072):
+        assert (_pooled_rows(seqs, andi_amd.M_KIMURA, segment) == want).all(), "structured, segment %d" % segment
+    base = synth.base_codes(300000, 9)
+    s = synth.to_bytes(base)
+    seqs = [s, _revcomp(synth.to_bytes(synth.mutate_codes(base, 0.02, 3))),  # reverse strand
+            _revcomp(s)[-100000:] + s[:100000],  # across the '#' of RS
+            synth.join_contigs(synth.to_bytes(synth.mutate_codes(base, 0.01, 4)), 9),  # '!' separators: windows that are not clean
+            s, synth.unrelated(200000, 77), s[:700]]  # identical, unrelated, short
+    want = orc.dist_matrix(seqs, model=orc.M_RAW, threads=4)
+    for segment in (32768, 100000):
+        got = _pooled_rows(seqs, andi_amd.M_RAW, segment)
+        assert (got == want).all(), "segment %d: pairs %s" % (segment, np.argwhere((got != want).any(axis=2))[:8].tolist())
+
+
+def test_routed_calls_choose_one_wavefront_kernel():
+    """A routed call takes ONE wavefront kernel (scan.h: pool_match): k_pool_cold where the pairs whose sampled matches are long
+    hold half of its segments -- a set 1 % apart --, k_coop_cold on the bench set's kind (3 % apart on average) and on genomes
+    1e-5 apart; ANDI_POOL_MATCH=0 (a test hook) makes every pair suit k_pool_cold.  Same counts every way."""
+    for d_hi, expect_pool in ((0.006, 1), (0.03, 0)):
+        seqs, _ = synth.genome_set(16, 4_900_000, 0.0004, d_hi, seed=5)  # (2^30 query symbols x subjects and more: the host looks at the layout)
+        lane, t0 = _rows(seqs, {"ANDI_COOP": "0"})
+        got, t = _rows(seqs, {})
+        assert t["routed_calls"] == 1 and t["pool_calls"] == expect_pool, (d_hi, t)
+        assert (got == lane).all(), d_hi
+        forced, t = _rows(seqs, {"ANDI_POOL_MATCH": "0"})
+        assert t["pool_calls"] == 1 and (forced == lane).all(), (d_hi, t)
+    base = synth.base_codes(4_900_000, 3)
+    close = [synth.to_bytes(synth.mutate_codes(base, 2e-5, 40 + k)) for k in range(16)]
+    lane, _ = _rows(close, {"ANDI_COOP": "0"})
+    got, t = _rows(close, {})
+    assert t["pool_calls"] == 0 and (got == lane).all(), t
+    forced, t = _rows(close, {"ANDI_POOL_MATCH": "0", "ANDI_QUAD_MATCH": "-1"})  # (... and keeps them from k_lane_quad: the wavefront kernel's)
+    assert (forced == lane).all(), t
