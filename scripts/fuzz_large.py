@@ -81,15 +81,18 @@ def main():
         lane, t0 = rows(seqs, model, {"ANDI_COOP": "0"})
         got, t1 = rows(seqs, model, {})
         forced, t2 = rows(seqs, model, {"ANDI_COOP": "4"}) if kind in ("star", "tree", "joined", "strands") else (lane, t0)
+        # ... and with every routed pair taken for one that suits k_pool_cold (coop_pool.h): that kernel where the call is large enough for
+        # the host to look at the layout, whatever the pairs are like
+        pooled, t3 = rows(seqs, model, {"ANDI_POOL_MATCH": "0", "ANDI_ROUTE_SMALL": "20"}) if model < 3 else (lane, t0)
         k = int(rng.integers(0, n))
         want = orc.scan_row(orc.OracleEsa(seqs[k]), seqs, k, model, threads=0)
-        ok = bool((got == lane).all() and (forced == lane).all() and (lane[k] == want).all())
+        ok = bool((got == lane).all() and (forced == lane).all() and (pooled == lane).all() and (lane[k] == want).all())
         case += 1
-        print("case %3d %-9s n=%2d len=%d model=%d  routed calls %d, pairs handed back %d; fix-ups lane/routed %d/%d  %s" % (
-            case, kind, n, length, model, t1["routed_calls"], t1["coop_fallbacks"], t0["fixups"], t1["fixups"], "ok" if ok else "DIFFERENT"), flush=True)
+        print("case %3d %-9s n=%2d len=%d model=%d  routed calls %d (k_pool_cold: %d, forced: %d), pairs handed back %d/%d; fix-ups lane/routed %d/%d  %s" % (
+            case, kind, n, length, model, t1["routed_calls"], t1["pool_calls"], t3["pool_calls"], t1["coop_fallbacks"], t3["coop_fallbacks"], t0["fixups"], t1["fixups"], "ok" if ok else "DIFFERENT"), flush=True)
         if not ok:
             sys.exit(1)
-    print("fuzz_large: %d cases, all equal (routed = lane scan = forced kernel, sampled rows = oracle)" % case)
+    print("fuzz_large: %d cases, all equal (routed = lane scan = forced kernel = pooled kernel forced, sampled rows = oracle)" % case)
 
 
 if __name__ == "__main__":
