@@ -128,6 +128,7 @@ struct andi_hip_ctx {
 	void *sa_ws = nullptr;
 	size_t sa_ws_bytes = 0;
 	int32_t *sa_pinned = nullptr;
+	int stream_prio = 0; // of stream and side_stream (host_pool: they go back there)
 	uint32_t *h_quad_waves = nullptr; // pinned: the length of k_lane_quad's list of a scan call
 	hipStream_t coop_stream = nullptr; // routed scan calls: pass A by wavefronts runs beside the lane scan's kernels
 	hipEvent_t coop_fork = nullptr, coop_join = nullptr, l2_fork = nullptr, l2_join = nullptr;
@@ -316,8 +317,86 @@ int andi_hip_abi_version(void) {
 	return ANDI_HIP_ABI_VERSION;
 }
 
+// Streams and the seam's pinned upload buffer are kept from one call to the next (like the arena's chunks: andi_hip_trim
+// gives them back): creating a stream takes 3 ms on this runtime -- nine per call of andi_hip_dist_matrix, 30 of a warm
+// call's 105 ms -- and pinning 20 MB another 4.
+namespace host_pool {
+struct IdleStream {
+	int device, prio;
+	hipStream_t s;
+};
+static std::mutex mu;
+static std::vector<IdleStream> streams;
+struct IdlePinned {
+	void *p;
+	size_t bytes;
+};
+static std::vector<IdlePinned> pinned;
+constexpr size_t PINNED_KEEP = (size_t)256 << 20; // bytes of pinned buffers kept at most
+
+static hipError_t stream_get(hipStream_t *out, int device, int prio) {
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		for (size_t i = 0; i < streams.size(); ++i)
+			if (streams[i].device == device && streams[i].prio == prio) {
+				*out = streams[i].s;
+				streams.erase(streams.begin() + (long)i);
+				return hipSuccess;
+			}
+	}
+	return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+}
+static void stream_put(hipStream_t s, int device, int prio) { // (idle: the caller has synchronised it)
+	if (!s) return;
+	std::lock_guard<std::mutex> lk(mu);
+	streams.push_back({device, prio, s});
+}
+static hipError_t pinned_get(void **out, size_t bytes) {
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		size_t best = pinned.size();
+		for (size_t i = 0; i < pinned.size(); ++i)
+			if (pinned[i].bytes >= bytes && pinned[i].bytes <= 2 * bytes + 4096 && (best == pinned.size() || pinned[i].bytes < pinned[best].bytes)) best = i;
+		if (best != pinned.size()) {
+			*out = pinned[best].p;
+			pinned.erase(pinned.begin() + (long)best);
+			return hipSuccess;
+		}
+	}
+	return hipHostMalloc(out, bytes, hipHostMallocDefault);
+}
+static void pinned_put(void *p, size_t bytes) {
+	if (!p) return;
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		size_t held = 0;
+		for (const IdlePinned &b : pinned) held += b.bytes;
+		if (held + bytes <= PINNED_KEEP) {
+			pinned.push_back({p, bytes});
+			return;
+		}
+	}
+	(void)hipHostFree(p);
+}
+static bool any() {
+	std::lock_guard<std::mutex> lk(mu);
+	return !streams.empty() || !pinned.empty();
+}
+static void trim() { // (the caller restores the current device)
+	std::vector<IdleStream> st;
+	std::vector<IdlePinned> pb;
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		st.swap(streams), pb.swap(pinned);
+	}
+	for (const IdleStream &x : st)
+		if (hipSetDevice(x.device) == hipSuccess) (void)hipStreamDestroy(x.s);
+	for (const IdlePinned &b : pb) (void)hipHostFree(b.p);
+}
+} // namespace host_pool
+
 size_t andi_hip_trim(void) {
-	if (!andi_arena::any_chunks()) return 0; // (a process that never used the library's device memory: no HIP call at all)
+	if (!andi_arena::any_chunks() && !host_pool::any()) return 0; // (a process that never used the library's device memory: no HIP call at all)
 	int ndev = 0, cur = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess) {
 		(void)hipGetLastError();
@@ -330,6 +409,7 @@ size_t andi_hip_trim(void) {
 		if (hipSetDevice(d) != hipSuccess) continue;
 		freed += andi_arena::trim(d);
 	}
+	host_pool::trim(); // (idle streams, pinned upload buffers)
 	(void)hipSetDevice(cur);
 	return freed;
 }
@@ -382,8 +462,9 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 		int least = 0, greatest = 0;
 		if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) prio = greatest;
 	}
-	e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
-	if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio);
+	ctx->stream_prio = prio;
+	e = host_pool::stream_get(&ctx->stream, device, prio);
+	if (e == hipSuccess) e = host_pool::stream_get(&ctx->side_stream, device, prio);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming);
@@ -391,7 +472,7 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_quad_waves, sizeof(uint32_t), hipHostMallocDefault);
-	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->coop_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = host_pool::stream_get(&ctx->coop_stream, device, 0);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_fork, hipEventDisableTiming);
@@ -438,7 +519,7 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->h_any_left) (void)hipHostFree(ctx->h_any_left);
 	if (ctx->coop_stream) {
 		(void)hipStreamSynchronize(ctx->coop_stream);
-		(void)hipStreamDestroy(ctx->coop_stream);
+		host_pool::stream_put(ctx->coop_stream, ctx->device, 0);
 	}
 	if (ctx->coop_fork) (void)hipEventDestroy(ctx->coop_fork);
 	if (ctx->coop_join) (void)hipEventDestroy(ctx->coop_join);
@@ -447,11 +528,14 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->desc_done) (void)hipEventDestroy(ctx->desc_done);
 	if (ctx->side_stream) {
 		(void)hipStreamSynchronize(ctx->side_stream);
-		(void)hipStreamDestroy(ctx->side_stream);
+		host_pool::stream_put(ctx->side_stream, ctx->device, ctx->stream_prio);
 	}
 	if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
 	if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
-	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	if (ctx->stream) {
+		(void)hipStreamSynchronize(ctx->stream); // (events resolved above may have left work behind them)
+		host_pool::stream_put(ctx->stream, ctx->device, ctx->stream_prio);
+	}
 	andi_arena::release(ctx->device); // (the device's last context gives its free chunks back)
 	delete ctx;
 }
@@ -565,7 +649,7 @@ static int esa_sort_suffixes(andi_hip_ctx *ctx, andi_hip_esa *e) {
 		HIP_TRY(ctx, andi_arena::dev_malloc(&ctx->sa_ws, need));
 		ctx->sa_ws_bytes = need;
 	}
-	if (!ctx->sa_pinned) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->sa_pinned, 2 * sizeof(int32_t), hipHostMallocDefault));
+	if (!ctx->sa_pinned) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->sa_pinned, 4 * sizeof(int32_t), hipHostMallocDefault));
 	if (!e->rec && !andi_knob(KNOB_NO_SORTED_RECORDS)) { // (experiments: the index build then gathers from the text, as with a host-made suffix array)
 		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec, (e->cap + 8) * sizeof(uint32_t)));
 		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec2, (e->cap + 8) * sizeof(uint16_t)));
@@ -1768,6 +1852,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		andi_hip_ctx *up = nullptr;   // uploads (a thread and a stream of their own: the copies of batch k + 1 run beside the sorts of batch k)
 		andi_hip_queries *Q = nullptr;
 		andi_hip_model *d_rows = nullptr; // rccl: the whole row block; direct: one batch of rows
+		size_t pinned_bytes = 0;
 		char *pinned = nullptr;           // staging buffers for RS (two: one is filled while the other's copy runs): uploads from pinned memory go through the DMA engines, beside a scan
 		hipEvent_t pinned_free[2] = {nullptr, nullptr};
 		std::vector<andi_hip_esa *> slots; // sets x batch
@@ -1862,9 +1947,10 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		if (andi_hip_sync(D.prep)) return bail("allocating subject slots", D.prep);
 		double t_reserve = 0, t_pinned = 0;
 		lap(t_reserve);
-		if (hipHostMalloc((void **)&D.pinned, 2 * (rs_cap + 64), hipHostMallocDefault) != hipSuccess) D.pinned = nullptr; // (then from where RS lies)
+		D.pinned_bytes = 2 * (rs_cap + 64);
+		if (host_pool::pinned_get((void **)&D.pinned, D.pinned_bytes) != hipSuccess) D.pinned = nullptr; // (then from where RS lies)
 		if (D.pinned && (hipEventCreateWithFlags(&D.pinned_free[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.pinned_free[1], hipEventDisableTiming) != hipSuccess)) {
-			(void)hipHostFree(D.pinned);
+			host_pool::pinned_put(D.pinned, D.pinned_bytes);
 			D.pinned = nullptr;
 		}
 		lap(t_pinned);
@@ -2130,7 +2216,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			if (e) andi_hip_esa_free(D.ctx, e);
 		if (D.d_rows) andi_hip_dev_free(D.ctx, D.d_rows);
 		if (D.Q) andi_hip_queries_free(D.ctx, D.Q);
-		if (D.pinned) (void)hipHostFree(D.pinned);
+		if (D.pinned) host_pool::pinned_put(D.pinned, D.pinned_bytes);
 		for (hipEvent_t ev : D.pinned_free)
 			if (ev) (void)hipEventDestroy(ev);
 		if (D.prep) andi_hip_ctx_destroy(D.prep);

@@ -518,10 +518,21 @@ def main():
         t0 = time.time()
         M2 = andi_amd.dist_matrix(seqs, p_value=p_value, model=model, sa_on_host=True)
         e2e_host = time.time() - t0
+
+        def seam_ms(tr, what):  # a figure of the traced call's split, in seconds
+            import re
+            for ln in (tr or {}).get("split", []):
+                m = re.search(re.escape(what) + r" ([0-9.]+)", ln)
+                if m:
+                    return float(m.group(1)) * 1e-3
+            return None
         out["end_to_end"].update({
             "dist_matrix_e2e_s": e2e, "dist_matrix_pairs_per_s": pairs_total / e2e,
             "dist_matrix_e2e_warm_s": e2e_warm, "dist_matrix_warm_pairs_per_s": pairs_total / e2e_warm,
             "dist_matrix_traced_call": traced, "host_load_average": list(os.getloadavg()),
+            # the sorter inside the seam (its staging thread sorts back to back; device_suffix_sort_s above is the sum over the bench's own
+            # staging loop, one subject at a time with host work between them) and what the scan thread waited for it
+            "dist_matrix_suffix_sort_s": seam_ms(traced, "suffix arrays"), "dist_matrix_scan_wait_s": seam_ms(traced, "waiting for staged subjects"),
             "dist_matrix_e2e_s_suffix_arrays_on_host": e2e_host, "host_cores": os.cpu_count(),
             "dist_matrix_equals_step": bool((M1 == full).all() and (M1w == full).all() and (M2 == full).all())})
     def seam_on_all_gpus(kind, G_, L_, dlo_, dhi_, model_, full_):

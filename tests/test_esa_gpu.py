@@ -131,6 +131,12 @@ def _sa_texts():
     yield "length-21", rand_dna(rng, 21)
     yield "length-22", rand_dna(rng, 22)
     yield "random-2M", synth.to_bytes(synth.base_codes(2_000_000, 9))
+    # suffixes with a separator among their first 16 symbols (round 0 keys them with zeros from there on: they tie with
+    # "...AAAA" suffixes and with each other, and round 1 has to put them in their true order)
+    yield "short-contigs", b"!".join([b"ACG", b"ACGT", b"AC", b"ACGTA", b"ACG", b"A", b"AAAA", b"AAAAAAAAAAAAAAAAAAAA"] * 40)
+    yield "poly-a-at-separators", b";".join([b"GATTACA" + b"A" * k for k in range(0, 40)] * 3)
+    yield "same-contig-ends", b"!".join([rand_dna(rng, 50 + 7 * k) + b"ACGTTGCAACGTAC" for k in range(60)] + [b"TTTT" + rand_dna(rng, 300)] * 5)
+    yield "contigs-in-a-repeat", b"!".join([(lambda u: u[:900 + 13 * k])(rand_dna(np.random.default_rng(5), 4000)) for k in range(40)])
 
 
 @pytest.mark.parametrize("name,seq", list(_sa_texts()), ids=[n for n, _ in _sa_texts()])
@@ -201,6 +207,8 @@ def _table_subjects():
     yield "repeats", rand_dna(rng, 300) * 6 + rand_dna(rng, 200)
     yield "joined", synth.join_contigs(rand_dna(rng, 3000), 9)
     yield "short-contigs", b"!".join([b"ACG", b"ACGT", b"AC", b"ACGTA", b"ACG"] * 30)
+    yield "poly-a-at-separators", b";".join([b"GATTACA" + b"A" * k for k in range(0, 30)] * 2)
+    yield "same-contig-ends", b"!".join([rand_dna(rng, 40 + 5 * k) + b"ACGTTGCAACGTAC" for k in range(30)])
     yield "random-40k", rand_dna(rng, 40000)
 
 
