@@ -174,6 +174,7 @@ static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at
 #define ANDI_ROUTE_GUESS 0x04u /* (k_pair_estimate to k_pair_route, small calls) marked for the wavefront kernel although the sampling cannot judge the pair: not where the call has pairs with unrelated stretches */
 #define ANDI_ROUTE_L2 0x08u   /* a pair handed back: in the second lane layout */
 #define ANDI_ROUTE_POOLCAND 0x08u /* (k_pair_estimate to k_pair_route) mean sampled match in [ScanArgs.pool_match, 4096): a pair that suits k_pool_cold (coop_pool.h) */
+#define ANDI_STRUCT_WAVES 4 /* restitch_count[this] during the layout of a routed call: wavefronts of pairs with unrelated stretches that are not merely far apart (k_pair_estimate) */
 #define ANDI_POOL_SEGS 6 /* restitch_count[this] after k_pair_route: segments of the wavefront kernel's pairs that suit k_pool_cold */
 #define ANDI_COOP_SEGS 7 /* ... of all its pairs */
 #define ANDI_LAYOUT_LANES 1   /* ScanArgs.route: the lane scan's pairs */

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 	// such pairs in k_lane_quad, 10.6 ms without).  So a candidate is sampled at 192 more positions, and goes to
 	// k_lane_quad only if its short matches are no more than its mean explains (matches end at random: a fraction
 	// 1 - exp(-threshold / mean) of the positions sees less than the threshold), within two standard deviations.
-	bool islands = false, guess = false;
+	bool islands = false, guess = false, far_clean = false;
 	const bool quad_cand = (sum >> 6) >= a.quad_min_match && (sum >> 6) < ANDI_ISLAND_MEAN_MAX && a.quad_min_match != 0;
 	// routed calls: would the pair suit pass A by wavefronts?  (one whole segment of that kernel's at least)
 	// (one whole segment of that kernel's at least, or a query of a few windows: with many short queries a wavefront's chain is a query)
@@ -132,6 +132,14 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 		}
 		const float f5 = f0 * f0 * f0 * f0 * f0, expect = ns * f5;
 		islands = (float)runs > expect + 3.f * sqrtf(expect * (1.f - f5)) + 3.f;
+		// ... or the pair is simply far apart: runs of five as often as the rate of ALL short samples gives by itself (a clean pair 8 %
+		// apart: 76 % short, 25 % runs; a pair 3 % apart with a fifth of unrelated sequence: 51 % short, 20 % runs where that rate
+		// explains 4 %).  Such a pair stays the lane scan's -- beyond 6 % the equation above has no well-conditioned solution --, but it is
+		// no pair with unrelated stretches.
+		if (islands) {
+			const float fa = (float)shorts / ns, fa5 = fa * fa * fa * fa * fa, most = ns * fa5;
+			far_clean = (float)runs <= 2.f * most + 10.f; // (clean pairs 4-8 % apart show up to 1.8 times the runs that rate gives)
+		}
 		// (small calls: pairs so far apart that nearly every sample is short -- runs of five tell nothing there -- are the
 		// wavefront kernel's: what it hands back costs a small call less than the lanes' chains cost every such pair)
 		// (... and so are the pairs near the top of f0 - f0^5, 4 ... 7 % apart, where the rate has no well-conditioned solution:
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 										 (coop_cand && islands ? ANDI_ROUTE_LEFT : 0u) | (coop_cand && guess ? ANDI_ROUTE_GUESS : 0u) |
 										 (a.route && (sum >> 6) >= a.pool_match && (sum >> 6) < 4096u ? ANDI_ROUTE_POOLCAND : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
+		if (islands && !far_clean) atomicAdd(&a.restitch_count[ANDI_STRUCT_WAVES], (nseg + 63) / 64); // (k_pair_route: a call of structured genomes?)
 	}
 }
 
@@ -274,6 +283,16 @@ __device__ __forceinline__ uint32_t route_pair(const ScanArgs &a, uint32_t pair,
 	// unrelated stretches -- structured genomes: 12 x 1 Mbp took 5.4 ms with such pairs tried by wavefronts and handed
 	// back, 3.9 ms by lanes)
 	if ((cls & ANDI_ROUTE_GUESS) && 20 * a.restitch_count[ANDI_ISLAND_WAVES] > a.restitch_count[ANDI_ALL_WAVES]) cls &= ~ANDI_ROUTE_COOP;
+	// A call of structured genomes -- a third of its wavefronts belong to pairs with unrelated stretches (and not merely far apart) --
+	// gives the suspected pairs segments twice as long: what such pairs cost is pass B, where every segment boundary inside a stretch
+	// without homology is a replay of hundreds of steps by one lane, and pass A loses nothing (the structured set's passes B/C 6.8 ->
+	// 4.4 ms, its step 19.0 -> 16.6).  All of them or none: with the segment lengths mixed pass A was the slower for it (10.1 against
+	// 9.4 ms), and clean pairs 4-10 % apart -- suspected too -- lose 5-10 % with long segments where they are most of a call.
+	if ((cls & ANDI_ROUTE_LEFT) && !(cls & ANDI_ROUTE_COOP) && (cls & 3u) < a.max_class && 3 * a.restitch_count[ANDI_STRUCT_WAVES] >= a.restitch_count[ANDI_ALL_WAVES]) {
+		++cls;
+		const uint32_t seg = a.seg0 << (cls & 3u);
+		a.pair_waves[pair] = ((a.qlen[pair % a.nq] + seg - 1) / seg + 63) / 64;
+	}
 	const bool pool = (cls & ANDI_ROUTE_POOLCAND) != 0;
 	cls &= ~(ANDI_ROUTE_SOFT | ANDI_ROUTE_LEFT | ANDI_ROUTE_GUESS | ANDI_ROUTE_POOLCAND);
 	// Small calls (route_all_few): pass A by wavefronts takes a fraction of a millisecond, and a lane's chain over one
@@ -1260,7 +1279,7 @@ static hipError_t pair_offsets(const ScanArgs &a, hipStream_t st) {
 
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
 	const uint32_t P = a.nsub * a.nq;
-	(void)hipMemsetAsync(a.restitch_count + ANDI_HARD_WAVES, 0, 7 * sizeof(uint32_t), st); // k_lane_quad's list is empty, no wavefronts counted
+	(void)hipMemsetAsync(a.restitch_count, 0, 16 * sizeof(uint32_t), st); // k_lane_quad's list is empty, no wavefronts counted
 	if (P <= 4096) k_pair_estimate<<<P, P <= 1024 ? 64 * EST_WAVES_FEW : 64 * EST_WAVES, 0, st>>>(a, false);
 	else k_pair_estimate<<<(P + 3) / 4, 256, 0, st>>>(a, true);
 	CHECK_LAUNCH();
