@@ -374,7 +374,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 	__shared__ uint32_t s_before[PT_RANKED / 32]; // set bits in the words before this one
 	__shared__ uint16_t s_owner[PT_TILE];   // the owning gaps, in order
 
-	const int64_t r0 = (int64_t)block * PT_TILE;
+	const uint32_t r0 = block * PT_TILE; // (n < 2^31: gaps and suffixes in 32 bits)
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	// the suffixes' records: read in order if the device sorter left them (REC), else made here from one gather each
 	auto make_rec = [&](int32_t j) { return REC ? REC[j] : suffix_rec(N0, SA, j, K); };
@@ -383,31 +383,31 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		uint32_t mine[PT_GAPS];
 #pragma unroll
 		for (int u = 0; u < PT_GAPS; ++u) {
-			const int64_t g = r0 + threadIdx.x + u * PT_BLOCK;
-			mine[u] = g < n ? make_rec((int32_t)g) : 0u;
-			mine2[u] = (single_ext == 2 && REC2 && g < n) ? REC2[g] : 0u;
+			const uint32_t g = r0 + threadIdx.x + u * PT_BLOCK;
+			mine[u] = g < (uint32_t)n ? make_rec((int32_t)g) : 0u;
+			mine2[u] = (single_ext == 2 && REC2 && g < (uint32_t)n) ? REC2[g] : 0u;
 		}
 #pragma unroll
 		for (int u = 0; u < PT_GAPS; ++u) s_rec[threadIdx.x + u * PT_BLOCK + 2] = mine[u];
 	}
 	if (threadIdx.x < 2) s_rec[threadIdx.x] = r0 + threadIdx.x >= 2 ? make_rec((int32_t)(r0 + threadIdx.x - 2)) : 0u;
-	if (threadIdx.x == 2) s_rec[PT_TILE + 2] = r0 + PT_TILE < n ? make_rec((int32_t)(r0 + PT_TILE)) : 0u;
+	if (threadIdx.x == 2) s_rec[PT_TILE + 2] = r0 + PT_TILE < (uint32_t)n ? make_rec((int32_t)(r0 + PT_TILE)) : 0u;
 	if (threadIdx.x < PT_RANKED / 32) s_bits[threadIdx.x] = 0;
 	__syncthreads();
 	auto rec = [&](int32_t j) { // 0 <= j < n; inside the block's range from LDS
-		const int64_t k = (int64_t)j - r0 + 2;
-		return (k >= 0 && k < PT_TILE + 3) ? s_rec[k] : make_rec(j);
+		const uint32_t k = (uint32_t)j - r0 + 2; // (j >= r0 - 2 wraps to a small number; anything else to a large one)
+		return k < PT_TILE + 3 ? s_rec[k] : make_rec(j);
 	};
 	const uint32_t full = (uint32_t)K;
 	if (threadIdx.x == 0) s_h[0] = r0 >= 2 ? rec_lcp(s_rec[0], s_rec[1], K) : 0u;
-	if (threadIdx.x == 1) s_h[PT_TILE + 1] = r0 + PT_TILE < n ? rec_lcp(s_rec[PT_TILE + 1], s_rec[PT_TILE + 2], K) : 0u;
+	if (threadIdx.x == 1) s_h[PT_TILE + 1] = r0 + PT_TILE < (uint32_t)n ? rec_lcp(s_rec[PT_TILE + 1], s_rec[PT_TILE + 2], K) : 0u;
 
 	uint32_t counts[PT_GAPS], firsts[PT_GAPS];
 #pragma unroll
 	for (int u = 0; u < PT_GAPS; ++u) {
 		const uint32_t i = threadIdx.x + u * PT_BLOCK; // gap r0 + i
-		const int64_t gid = r0 + i;
-		const bool live = gid <= n;
+		const uint32_t gid = r0 + i;
+		const bool live = gid <= (uint32_t)n;
 		const int32_t r = (int32_t)(live ? gid : 0);
 		const bool hasL = live && r > 0, hasR = live && r < n;
 		const uint32_t L = hasL ? s_rec[i + 1] : 0u, R = hasR ? s_rec[i + 2] : 0u;
@@ -476,8 +476,8 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 				owns_present = 1;
 			}
 
-			// (c) closed run of suffixes "w <sep>" with 1 <= |w| <= 8
-			if (hasR) {
+			// (c) closed run of suffixes "w <sep>" with 1 <= |w| <= 8 (a wavefront none of whose suffixes is followed by a '!' or ';' skips it)
+			if (__builtin_amdgcn_ballot_w64(hasR && (REC_SEP(R) == 1 || REC_SEP(R) == 2)) != 0 && hasR) {
 				uint32_t k = REC_V(R), sp = REC_SEP(R);
 				if (k >= 1 && k <= 8 && k < full && (sp == 1 || sp == 2) && (!hasL || h < k)) {
 					int32_t j = r;
@@ -514,7 +514,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 	// piece is code base + t, and no prefix sums over the gaps' counts are needed.
 	__syncthreads();
 	const uint32_t base = first_code(r0 > 0, s_rec[1], K);
-	const uint32_t total = (r0 + PT_TILE <= n ? first_code(true, s_rec[PT_TILE + 1], K) : (1u << (2 * K))) - base;
+	const uint32_t total = (r0 + PT_TILE <= (uint32_t)n ? first_code(true, s_rec[PT_TILE + 1], K) : (1u << (2 * K))) - base;
 	// the owners of the first PT_RANKED entries by rank: a bit where an owning gap's entries start (starts are
 	// distinct), the owning gaps listed in order; the owner of entry t is then number (set bits up to t) of the list
 	uint32_t owners_before; // owning gaps in the ballot words before word `lane` (lane < PT_WORDS)
@@ -558,8 +558,8 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 			deep[c] = s_present[a];
 			continue;
 		}
-		const int64_t rr = r0 + a;
-		const bool gL = rr > 0, gR = rr < n;
+		const uint32_t rr = r0 + a;
+		const bool gL = rr > 0, gR = rr < (uint32_t)n;
 		// is the left (right) neighbour the only suffix sharing a given prefix length with it?
 		// lcp(suffix rr-2, rr-1) and lcp(suffix rr, rr+1) are the neighbouring gaps' h (0 outside the text)
 		const uint32_t gl = s_rec[a + 1], gr = s_rec[a + 2], hll = s_h[a], hrr = s_h[a + 2];
@@ -571,7 +571,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 			uniq = (rr < 2 || hll < l) ? 1u : 0u;
 		} else if (lR > lL) {
 			l = lR, idx = (uint32_t)rr;
-			uniq = (rr + 1 >= n || hrr < l) ? 1u : 0u;
+			uniq = (rr + 1 >= (uint32_t)n || hrr < l) ? 1u : 0u;
 		} else { // both neighbours share l characters (or l == 0: every suffix does)
 			l = lL, idx = 0, uniq = (n == 1) ? 1u : 0u;
 		}
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_probe_table(const uint8_t *__restr
 // the tables of several subjects in one launch (blockIdx.y = subject): no launch gaps, one tail
 __global__ __launch_bounds__(PT_BLOCK) void k_probe_table_batch(const AndiIndexBatchItem *__restrict__ items) {
 	const AndiIndexBatchItem it = items[blockIdx.y];
-	if ((int64_t)blockIdx.x * PT_TILE > (int64_t)it.n) return;
+	if ((uint64_t)blockIdx.x * PT_TILE > (uint64_t)it.n) return;
 	probe_table_block(it.N0, it.SA, it.rec, it.rec2, it.deep, it.flags, it.n, it.deepK, it.single_ext, blockIdx.x);
 }
 
