@@ -464,7 +464,6 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 	}
 	ctx->stream_prio = prio;
 	e = host_pool::stream_get(&ctx->stream, device, prio);
-	if (e == hipSuccess) e = host_pool::stream_get(&ctx->side_stream, device, prio);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->desc_done, hipEventDisableTiming);
@@ -472,7 +471,6 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_quad_waves, sizeof(uint32_t), hipHostMallocDefault);
-	if (e == hipSuccess) e = host_pool::stream_get(&ctx->coop_stream, device, 0);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_fork, hipEventDisableTiming);
@@ -1163,6 +1161,9 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		return 1;
 	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	// the streams only scans use (a context that stages or uploads never asks for them: a stream costs 3 ms to create)
+	if (!ctx->side_stream) HIP_TRY(ctx, host_pool::stream_get(&ctx->side_stream, ctx->device, ctx->stream_prio));
+	if (!ctx->coop_stream) HIP_TRY(ctx, host_pool::stream_get(&ctx->coop_stream, ctx->device, 0));
 	// segment == 0: the engine chooses.  With the lane scan and a moderate number of pairs
 	// the segment length is chosen per pair (scan_lane.hip: k_pair_estimate); otherwise one
 	// length for the call.
