@@ -80,8 +80,9 @@ int andi_hip_abi_version(void);
  * them (default 8192; 0: none, as up to ABI 3) stay with the process when the last context on a device is destroyed, so
  * that the next call of the seam does not pay the driver for them again (on some hosts 0.3 s per call for a 29-genome
  * job); what a larger job took beyond that goes back with its last context.  This gives every chunk nobody holds a block of
- * back to the driver -- all devices the library has used; waits for each --, and returns the bytes released.  A process that
- * never used the library's device memory makes no HIP call here. */
+ * back to the driver -- all devices the library has used; waits for each --, and returns the bytes released; the idle streams
+ * and pinned upload buffers destroyed contexts left behind (kept for the next call as well: a stream costs this runtime 3 ms to
+ * create, nine per call of the seam) go with them.  A process that never used the library makes no HIP call here. */
 size_t andi_hip_trim(void);
 
 /* Host helper: the 4-bit symbols of a byte string as the engine keeps its texts (A C G T ! ; # NUL = 0 ... 7; byte j of out
