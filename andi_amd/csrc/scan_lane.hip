@@ -177,13 +177,19 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 		// few lanes for those replays) -- take it where they are more than a tenth of the call; a few of them ride along
 		// with the wavefront kernel (k_pair_route).  (Pairs of k_lane_quad's class -- mean match 128 ... 511 -- were treated
 		// the same way at first: the wavefront kernel is the faster one for them, route_soft_match.)
-		const bool soft = (sum >> 6) < ANDI_SPARSE_MATCH || (sum >> 6) >= a.route_soft_match;
+		// (a pair that is merely far apart: a candidate of the wavefront kernel like the pairs small calls cannot judge -- not in a call
+		// that has pairs with unrelated stretches (k_pair_route: it may be one of them after all, and would be handed back), and a soft
+		// one: the lane scan's where such pairs are many.  The bench set's 18 farthest pairs ride along with the wavefront kernel
+		// instead of keeping the lane kernels busy beside it for 1.7 ms: step 7.63 -> 7.50 ms)
+		const bool far = islands && far_clean;
+		const bool soft = (sum >> 6) < ANDI_SPARSE_MATCH || (sum >> 6) >= a.route_soft_match || far;
+		if (far) islands = false, guess = true;
 		const bool quad = (sum >> 6) >= a.quad_min_match && !(islands && (sum >> 6) < ANDI_ISLAND_MEAN_MAX);
 		a.pair_class[pair] = (uint8_t)(cls | (quad ? 0x80u : 0u) | (coop_cand && !islands ? ANDI_ROUTE_COOP : 0u) | (soft ? ANDI_ROUTE_SOFT : 0u) |
 										 (coop_cand && islands ? ANDI_ROUTE_LEFT : 0u) | (coop_cand && guess ? ANDI_ROUTE_GUESS : 0u) |
 										 (a.route && (sum >> 6) >= a.pool_match && (sum >> 6) < 4096u ? ANDI_ROUTE_POOLCAND : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
-		if (islands && !far_clean) atomicAdd(&a.restitch_count[ANDI_STRUCT_WAVES], (nseg + 63) / 64); // (k_pair_route: a call of structured genomes?)
+		if (islands) atomicAdd(&a.restitch_count[ANDI_STRUCT_WAVES], (nseg + 63) / 64); // (k_pair_route: a call of structured genomes?)
 	}
 }
 
@@ -288,7 +294,7 @@ __device__ __forceinline__ uint32_t route_pair(const ScanArgs &a, uint32_t pair,
 	// without homology is a replay of hundreds of steps by one lane, and pass A loses nothing (the structured set's passes B/C 6.8 ->
 	// 4.4 ms, its step 19.0 -> 16.6).  All of them or none: with the segment lengths mixed pass A was the slower for it (10.1 against
 	// 9.4 ms), and clean pairs 4-10 % apart -- suspected too -- lose 5-10 % with long segments where they are most of a call.
-	if ((cls & ANDI_ROUTE_LEFT) && !(cls & ANDI_ROUTE_COOP) && (cls & 3u) < a.max_class && 3 * a.restitch_count[ANDI_STRUCT_WAVES] >= a.restitch_count[ANDI_ALL_WAVES]) {
+	if ((cls & (ANDI_ROUTE_LEFT | ANDI_ROUTE_GUESS)) && !(cls & ANDI_ROUTE_COOP) && (cls & 3u) < a.max_class && 3 * a.restitch_count[ANDI_STRUCT_WAVES] >= a.restitch_count[ANDI_ALL_WAVES]) {
 		++cls;
 		const uint32_t seg = a.seg0 << (cls & 3u);
 		a.pair_waves[pair] = ((a.qlen[pair % a.nq] + seg - 1) / seg + 63) / 64;
