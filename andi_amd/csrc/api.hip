@@ -1305,7 +1305,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	const size_t slots = adaptive ? (size_t)64 * max_waves : nsub * (size_t)q->total_segs;
 	const size_t slots2 = routed ? nsub * (size_t)q->c_total_segs : 0; // (the wavefront kernel's layout, beside the lane scan's)
 	const size_t need = (slots + slots2) * ANDI_SLOT_BYTES + 256 +
-						(adaptive || routed ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 : 0);
+						(adaptive || routed ? pairs_all * 9 + 64 + (pairs_all / 1024 + 2) * 4 + 16 + nsub * 8 + 32 : 0);
 	if (ctx->scratch_bytes < need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->scratch) (void)andi_arena::dev_free(ctx->scratch);
@@ -1358,6 +1358,11 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.pair_wave0 = a.pair_waves + pairs_all;
 	a.pair_bsum = a.pair_wave0 + pairs_all + 1;
 	a.pair_class = (uint8_t *)(a.pair_bsum + pairs_all / 1024 + 2);
+	a.sub_cost = nullptr, a.sub_order = nullptr;
+	if (routed) { // (the order in which pass A by wavefronts takes the subjects: scan.h)
+		a.sub_cost = (float *)(((uintptr_t)(a.pair_class + pairs_all) + 15) & ~(uintptr_t)15);
+		a.sub_order = (uint32_t *)(a.sub_cost + nsub);
+	}
 	{
 		const char *f = andi_knob(KNOB_SEG_FACTOR);
 		a.seg_factor = f && atoi(f) > 0 ? (uint32_t)atoi(f) : 16u; // measured best of 8/16/32 with seg0 = 2048
@@ -1424,7 +1429,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		b.adaptive = 0, b.coop = 1, b.route = ANDI_LAYOUT_COOP;
 		b.qseg_start = q->c_qseg_start, b.seg2query = q->c_seg2query, b.total_segs = q->c_total_segs, b.seg = coop_seg;
 		b.reduce_threads = (longest_q + coop_seg - 1) / coop_seg <= 64 ? 64u : 0u;
-		p = (char *)(a.pair_class + pairs_all);
+		p = (char *)(a.sub_order + nsub);
 		p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
 		carve(b, slots2);
 		hipError_t e;

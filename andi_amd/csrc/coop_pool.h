@@ -955,7 +955,8 @@ __global__ __launch_bounds__(64, POOL_OCC) void k_pool_cold(ScanArgs a) {
 	const uint32_t items = a.total_segs * a.nsub;
 	uint32_t item = blockIdx.x; // the first one; then whatever comes next
 	while (item < items) {
-		pool_segment(a, L, &Gs, item / a.total_segs, item % a.total_segs);
+		const uint32_t row = item / a.total_segs;
+		pool_segment(a, L, &Gs, a.sub_order ? uni(a.sub_order[row]) : row, item % a.total_segs);
 		wave_sync();
 		uint32_t nx = 0;
 		if (__lane_id() == 0) nx = atomicAdd(a.pool_ticket, 1u);

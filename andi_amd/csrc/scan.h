@@ -84,6 +84,13 @@ struct ScanArgs {
 	uint32_t *pair_wave0;
 	uint32_t *pair_bsum;  // scratch: sums / offsets of 1024 pairs each
 	uint32_t max_waves;   // upper bound (every pair in class 0): the grid
+	// Routed calls: pass A by wavefronts takes the subjects heaviest first (sub_order[k]: the subject the k-th row of its grid works
+	// on; null: as they come).  A wavefront's segment takes a millisecond and a launch is three or four rounds of them: what the
+	// device does while the last ones finish depends on which they are (the bench set's 29 subjects in order of rising
+	// divergence 4.82 ms, as they come 4.50, heaviest first 4.39).  sub_cost: what k_pair_estimate's samples say a subject's pairs
+	// cost -- nucleotides over mean match length, summed.
+	float *sub_cost;
+	uint32_t *sub_order;
 	// Pairs whose sampled mean match length is at least quad_min_match (per-pair segment lengths only) take pass A with
 	// the streams fetched by quads of lanes (scan_lane.hip: k_lane_quad), the others lane_step's; 0xffffffff: none do
 	uint32_t quad_min_match;

@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 	__shared__ CoopLds<NCH> s_lds[COOP_WAVES];
 	CoopLds<NCH> &L = s_lds[threadIdx.x >> 6];
 	const uint32_t lane = __lane_id();
-	const uint32_t sub = blockIdx.y;
+	const uint32_t sub = a.sub_order ? uni(a.sub_order[blockIdx.y]) : blockIdx.y; // (routed calls: the heaviest subjects first, scan.h)
 	if (a.subjects[sub].mode != ANDI_MODE_PROBE) return;
 	const uint32_t wseg = uni(blockIdx.x * COOP_WAVES + (threadIdx.x >> 6));
 	if (wseg >= a.total_segs) return;

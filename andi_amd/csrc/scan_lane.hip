@@ -189,6 +189,7 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 										 (coop_cand && islands ? ANDI_ROUTE_LEFT : 0u) | (coop_cand && guess ? ANDI_ROUTE_GUESS : 0u) |
 										 (a.route && (sum >> 6) >= a.pool_match && (sum >> 6) < 4096u ? ANDI_ROUTE_POOLCAND : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
+		if (a.sub_cost) atomicAdd(&a.sub_cost[sub], (float)c.qlen / (float)((sum >> 6) < 8u ? 8u : (sum >> 6))); // (scan.h: sub_order)
 		if (islands) atomicAdd(&a.restitch_count[ANDI_STRUCT_WAVES], (nseg + 63) / 64); // (k_pair_route: a call of structured genomes?)
 	}
 }
@@ -324,6 +325,19 @@ __global__ __launch_bounds__(256) void k_pair_route(ScanArgs a) {
 		mine += (uint32_t)__shfl_xor((int)mine, d), pool_segs += (uint32_t)__shfl_xor((int)pool_segs, d), coop_segs += (uint32_t)__shfl_xor((int)coop_segs, d);
 	if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(&a.restitch_count[ANDI_LANE_WAVES], mine); // (the host looks: which kernel goes first)
 	if ((threadIdx.x & 63u) == 0 && coop_segs) atomicAdd(&a.restitch_count[ANDI_COOP_SEGS], coop_segs), atomicAdd(&a.restitch_count[ANDI_POOL_SEGS], pool_segs); // (... and which wavefront kernel)
+}
+
+// routed calls: the subjects by falling cost (scan.h: sub_order); one block
+__global__ __launch_bounds__(1024) void k_sub_order(ScanArgs a) {
+	for (uint32_t s = threadIdx.x; s < a.nsub; s += 1024) {
+		const float c = a.sub_cost[s];
+		uint32_t rank = 0;
+		for (uint32_t t = 0; t < a.nsub; ++t) {
+			const float o = a.sub_cost[t];
+			rank += (o > c || (o == c && t < s)) ? 1u : 0u;
+		}
+		a.sub_order[rank] = s;
+	}
 }
 
 // routed calls, after pass A: the pairs the wavefront kernel handed back get the wavefronts of the second lane layout
@@ -1286,6 +1300,7 @@ static hipError_t pair_offsets(const ScanArgs &a, hipStream_t st) {
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
 	const uint32_t P = a.nsub * a.nq;
 	(void)hipMemsetAsync(a.restitch_count, 0, 16 * sizeof(uint32_t), st); // k_lane_quad's list is empty, no wavefronts counted
+	if (a.sub_cost) (void)hipMemsetAsync(a.sub_cost, 0, a.nsub * sizeof(float), st);
 	if (P <= 4096) k_pair_estimate<<<P, P <= 1024 ? 64 * EST_WAVES_FEW : 64 * EST_WAVES, 0, st>>>(a, false);
 	else k_pair_estimate<<<(P + 3) / 4, 256, 0, st>>>(a, true);
 	CHECK_LAUNCH();
@@ -1294,6 +1309,10 @@ hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st) {
 		CHECK_LAUNCH();
 		k_pair_route<<<(P + 255) / 256, 256, 0, st>>>(a);
 		CHECK_LAUNCH();
+		if (a.sub_order) {
+			k_sub_order<<<1, 1024, 0, st>>>(a);
+			CHECK_LAUNCH();
+		}
 	}
 	return a.adaptive ? pair_offsets(a, st) : hipSuccess; // (a routed call with one segment length for its lanes: the marks only)
 }
