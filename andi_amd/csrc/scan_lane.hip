@@ -189,7 +189,9 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 										 (coop_cand && islands ? ANDI_ROUTE_LEFT : 0u) | (coop_cand && guess ? ANDI_ROUTE_GUESS : 0u) |
 										 (a.route && (sum >> 6) >= a.pool_match && (sum >> 6) < 4096u ? ANDI_ROUTE_POOLCAND : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
-		if (a.sub_cost) atomicAdd(&a.sub_cost[sub], (float)c.qlen / (float)((sum >> 6) < 8u ? 8u : (sum >> 6))); // (scan.h: sub_order)
+		// (scan.h: sub_order; not in calls of thousands of pairs -- a few subjects with thousands of queries each, alike: their costs stay
+		// zero and the order is the subjects' own; 24 680 additions to eight words took 0.07 ms)
+		if (a.sub_cost && !many) atomicAdd(&a.sub_cost[sub], (float)c.qlen / (float)((sum >> 6) < 8u ? 8u : (sum >> 6)));
 		if (islands) atomicAdd(&a.restitch_count[ANDI_STRUCT_WAVES], (nseg + 63) / 64); // (k_pair_route: a call of structured genomes?)
 	}
 }

@@ -93,3 +93,27 @@ def test_small_calls_still_see_stretches_in_pairs_moderately_far_apart():
     shorts, runs, bad = _suspected(seqs[0], seqs[1])
     small_bad, _ = _small_call_verdict(shorts, runs, bad, _mean_match(seqs[0], seqs[1]))
     assert bad and small_bad, (shorts, runs)
+
+
+def _far_clean(shorts, runs, suspected, nsamples=512):
+    """Any call, a suspected pair (round 5): it is MERELY FAR APART if its runs of five are at most twice as many as the rate of
+    all its short samples gives by itself (k_pair_estimate: far_clean).  Such a pair is a candidate of the wavefront kernel
+    again (soft, and a guess), and it does not count towards a call of structured genomes (k_pair_route's longer segments)."""
+    fa = shorts / nsamples
+    return suspected and runs <= 2 * nsamples * fa ** 5 + 10
+
+
+@pytest.mark.parametrize("d", [0.06, 0.08, 0.1])
+def test_suspected_clean_pairs_are_told_from_structured_ones(d):
+    a, b = synth.pair(1_000_000, d, seed=int(d * 1e4))
+    shorts, runs, bad = _suspected(a, b)
+    assert not bad or _far_clean(shorts, runs, bad), (d, shorts, runs, bad)
+
+
+@pytest.mark.parametrize("d", [0.004, 0.03])
+def test_structured_pairs_are_not_taken_for_far_ones(d):
+    """(up to some 4 % apart; a structured pair 5 % and more apart passes for a far one -- in a call of structured genomes it
+    gets the others' segment length all the same, k_pair_route)"""
+    seqs, _ = synth.realistic_set(2, 1_000_000, d / 2, d / 2 + 1e-9, seed=7 + int(d * 1e3))
+    shorts, runs, bad = _suspected(seqs[0], seqs[1])
+    assert bad and not _far_clean(shorts, runs, bad), (d, shorts, runs)
