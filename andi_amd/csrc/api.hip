@@ -1381,7 +1381,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	a.coop = coop && !a.adaptive;
 	a.pool_scratch = nullptr, a.pool_ticket = nullptr, a.pool_waves = 0, a.pool_bytes = 0;
-	a.pool_maxchunks = a.pool_hc = 0, a.pool_first = 0, a.pool_use = 0;
+	a.pool_maxchunks = a.pool_hc = 0, a.pool_first = 0, a.pool_use = 0, a.pool_max_n = 0;
 	{
 		const char *pm = andi_knob(KNOB_POOL_MATCH); // (experiments: mean sampled match from which a routed pair's wavefront kernel is k_pool_cold)
 		a.pool_match = pm && atoi(pm) >= 0 ? (uint32_t)atoi(pm) : 48u;
@@ -1397,11 +1397,11 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		}
 		if (ctx->pool_scratch) {
 			a.pool_ticket = (uint32_t *)ctx->pool_scratch, a.pool_scratch = (char *)ctx->pool_scratch + 4096, a.pool_waves = ctx->pool_waves, a.pool_bytes = ctx->pool_bytes;
-			// that kernel streams the texts bit-sliced: the subjects' planes from their 4-bit symbols (one launch; 0.03 ms for 29 subjects)
+			// that kernel streams the texts bit-sliced: the subjects' planes are made from their 4-bit symbols in front of its launch (only
+			// there -- a call that takes k_coop_cold does not pay the 0.06 ms: andi_launch_coop_cold)
 			size_t max_n = 0;
 			for (size_t k = 0; k < nsub; ++k) max_n = std::max(max_n, (size_t)subjects[k]->n);
-			hipError_t pe = andi_launch_pack_planes_subjects(a.subjects, (uint32_t)nsub, max_n, ctx->stream);
-			if (pe != hipSuccess) return fail(ctx, "bit-sliced subjects", pe);
+			a.pool_max_n = max_n;
 		}
 	}
 	a.route = routed ? ANDI_LAYOUT_LANES : 0, a.route_seg = coop_seg, a.route_nt = ctx->d_route;

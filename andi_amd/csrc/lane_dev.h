@@ -130,12 +130,12 @@ __device__ __forceinline__ LaneItem lane_item_of_slot(const ScanArgs &a, unsigne
 // LAYOUT: 0 = whichever the call uses (a.adaptive), 1 = per-pair segments, 2 = one segment length.  A kernel compiled
 // for layout 1 knows that all lanes of a wavefront work on one pair: the query's base address and length stay in
 // scalar registers (five vector registers less per lane, query loads with a scalar base).
-template <int NT = BLOCK, int LAYOUT = 0> // NT: threads per block; `wave`: the wavefront to work as (per-pair segments), or ~0
-__device__ __forceinline__ LaneItem lane_item(const ScanArgs &a, uint32_t wave = ~0u) {
+template <int NT = BLOCK, int LAYOUT = 0> // NT: threads per block; `wave`: the wavefront to work as (per-pair segments), or ~0; `seg_w`: the segment to take (one segment length), or ~0
+__device__ __forceinline__ LaneItem lane_item(const ScanArgs &a, uint32_t wave = ~0u, uint32_t seg_w = ~0u) {
 	LaneItem it;
 	if (LAYOUT == 2 || (LAYOUT == 0 && !a.adaptive)) {
 		it.sub = blockIdx.y;
-		const uint32_t w = blockIdx.x * NT + threadIdx.x;
+		const uint32_t w = seg_w != ~0u ? seg_w : blockIdx.x * NT + threadIdx.x;
 		it.valid = w < a.total_segs;
 		it.qidx = it.seg_in_q = it.start = it.end = 0;
 		it.seg = a.seg, it.cls = 0;

@@ -55,6 +55,10 @@ struct ScanArgs {
 	ChainState *used_entry; // the state pass B let the true chain enter the segment in (pass C verifies it)
 	uint32_t *restitch_count; // [r]: stretches stitched again in round r (lane scan); [ANDI_RESTITCH_ROUNDS]: true chains that left their segment on their own
 	uint32_t restitch_round;
+	// pass B's first launch over a layout of few segments (one segment length: the wavefront kernel's): stitch_lanes < 64 lanes of
+	// every wavefront take a segment each -- 31 000 replays of up to 48 dependent steps in 490 full wavefronts took 154 us of the bench
+	// step, every step of a wavefront paying for the paths of all its lanes (0: all 64)
+	uint32_t stitch_lanes;
 	// Segments whose stitching takes more than ANDI_STITCH_BUDGET chain steps -- or more than ANDI_STITCH_FIRST
 	// when no more than ANDI_STITCH_FEW lanes of their wavefront are still at it and the call has had more than
 	// ANDI_STITCH_MANY such replays -- are put on a list and stitched
@@ -124,6 +128,7 @@ struct ScanArgs {
 	uint32_t *pool_ticket;
 	uint32_t pool_waves;
 	size_t pool_bytes;    // host side: what the context holds behind pool_ticket's 4096 bytes
+	size_t pool_max_n;    // host side: the longest subject text of the call (the launch of k_pool_cold packs the subjects' planes first)
 	uint32_t pool_maxchunks, pool_hc; // a scratch's size: rounds of 2048 positions of a window, heads of a window
 	// routed calls: WHICH wavefront kernel -- k_pool_cold where the pairs whose sampled mean match is pool_match ... 4095 (few heads per position:
 	// streaming decides) hold at least half of the wavefront kernel's segments, k_coop_cold otherwise (many heads: its windows in LDS walk them at

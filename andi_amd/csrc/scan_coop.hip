@@ -1159,6 +1159,8 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 	// The windows' walks pooled through global memory (k_pool_cold: persistent wavefronts take the segments in order): segments long enough
 	// to fill its windows; in a routed call where the pairs with long sampled matches hold most of the segments (ScanArgs.pool_use)
 	if (andi_coop_will_pool(a)) {
+		hipError_t pe = andi_launch_pack_planes_subjects(a.subjects, a.nsub, a.pool_max_n, st); // (the texts bit-sliced: coop_pool.h)
+		if (pe != hipSuccess) return pe;
 		const uint64_t items = (uint64_t)a.total_segs * a.nsub;
 		ScanArgs b = a;
 		b.pool_first = 64;

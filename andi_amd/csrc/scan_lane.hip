@@ -1065,7 +1065,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_lane_stitch(ScanArgs a) { // (4 wa
 		}
 	} else {
 		if (!a.adaptive && a.subjects[blockIdx.y].mode != ANDI_MODE_PROBE) return;
-		const LaneItem it = lane_item(a);
+		uint32_t seg_w = ~0u;
+		if (!a.adaptive && a.stitch_lanes) { // (few segments: some lanes of every wavefront, scan.h)
+			if ((threadIdx.x & 63u) >= a.stitch_lanes) return;
+			seg_w = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * a.stitch_lanes + (threadIdx.x & 63u);
+		}
+		const LaneItem it = lane_item(a, ~0u, seg_w);
 		if (it.valid) stitch_item<EXACT, false>(a, it, s_hist);
 	}
 }
@@ -1371,15 +1376,23 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 	const size_t slots = a.adaptive ? (size_t)64 * a.max_waves : (size_t)a.nsub * a.total_segs;
 	const uint32_t per_block = WAVES_PER_BLOCK * ANDI_LISTED_LANES;
 	const unsigned lblocks = (unsigned)std::min<size_t>((slots + per_block - 1) / per_block, ANDI_LISTED_BLOCKS); // (strides over the list)
-	auto stage = [&](auto main_kernel, auto listed_kernel) {
+	auto stage = [&](auto main_kernel, auto listed_kernel, dim3 main_grid) {
 		(void)hipMemsetAsync(a.defer_count, 0, sizeof(uint32_t), st);
-		main_kernel<<<grid, BLOCK, 0, st>>>(a);
+		main_kernel<<<main_grid, BLOCK, 0, st>>>(a);
 		listed_kernel<<<lblocks, BLOCK, 0, st>>>(a);
 	};
+	// the first launch over few segments of one length: some lanes of every wavefront (scan.h: stitch_lanes), 8192 wavefronts or so
+	dim3 grid0 = grid;
+	a.stitch_lanes = 0;
+	if (!a.adaptive && slots < (size_t)64 * 8192) {
+		uint32_t L = 1;
+		while ((size_t)L * 8192 < slots) L *= 2;
+		if (L < 64) a.stitch_lanes = L, grid0 = dim3((a.total_segs + WAVES_PER_BLOCK * L - 1) / (WAVES_PER_BLOCK * L), a.nsub);
+	}
 	if (a.exact_equal)
-		stage(k_lane_stitch<true, 0>, k_lane_stitch<true, 1>);
+		stage(k_lane_stitch<true, 0>, k_lane_stitch<true, 1>, grid0);
 	else
-		stage(k_lane_stitch<false, 0>, k_lane_stitch<false, 1>);
+		stage(k_lane_stitch<false, 0>, k_lane_stitch<false, 1>, grid0);
 #ifdef ANDI_LANE_STATS
 	if (andi_knob(KNOB_LANE_STATS)) { // pass B's first stage: how its segments were settled, and the chain steps that took
 		static const char *names[8] = {"entered behind the cold chain's first anchor", "met behind its first anchor", "met at a mark",
@@ -1397,9 +1410,9 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 	for (uint32_t r = 0; again && r < ANDI_RESTITCH_ROUNDS; ++r) {
 		a.restitch_round = r;
 		if (a.exact_equal)
-			stage(k_stitch_heads, k_lane_stitch<true, 2>);
+			stage(k_stitch_heads, k_lane_stitch<true, 2>, grid);
 		else
-			stage(k_stitch_heads, k_lane_stitch<false, 2>);
+			stage(k_stitch_heads, k_lane_stitch<false, 2>, grid);
 	}
 #ifdef ANDI_LANE_STATS
 	if (andi_knob(KNOB_LANE_STATS)) { // replays by length (steps: 0, 1, 2-3, 4-7, ...) per kind of launch
