@@ -1376,8 +1376,11 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 	const size_t slots = a.adaptive ? (size_t)64 * a.max_waves : (size_t)a.nsub * a.total_segs;
 	const uint32_t per_block = WAVES_PER_BLOCK * ANDI_LISTED_LANES;
 	const unsigned lblocks = (unsigned)std::min<size_t>((slots + per_block - 1) / per_block, ANDI_LISTED_BLOCKS); // (strides over the list)
-	auto stage = [&](auto main_kernel, auto listed_kernel, dim3 main_grid) {
-		(void)hipMemsetAsync(a.defer_count, 0, sizeof(uint32_t), st);
+	// (every stage counts its list in a word of its own among those the memset above has just cleared -- 8, and 13 ... 15 for the
+	// rounds, which only the layout and pass A use otherwise: no memset between the stages, four launches less per layout)
+	static_assert(ANDI_RESTITCH_ROUNDS <= 3, "a list counter per round: restitch_count[13 ... 15]");
+	auto stage = [&](auto main_kernel, auto listed_kernel, dim3 main_grid, uint32_t counter) {
+		a.defer_count = a.restitch_count + counter;
 		main_kernel<<<main_grid, BLOCK, 0, st>>>(a);
 		listed_kernel<<<lblocks, BLOCK, 0, st>>>(a);
 	};
@@ -1390,9 +1393,9 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 		if (L < 64) a.stitch_lanes = L, grid0 = dim3((a.total_segs + WAVES_PER_BLOCK * L - 1) / (WAVES_PER_BLOCK * L), a.nsub);
 	}
 	if (a.exact_equal)
-		stage(k_lane_stitch<true, 0>, k_lane_stitch<true, 1>, grid0);
+		stage(k_lane_stitch<true, 0>, k_lane_stitch<true, 1>, grid0, 8);
 	else
-		stage(k_lane_stitch<false, 0>, k_lane_stitch<false, 1>, grid0);
+		stage(k_lane_stitch<false, 0>, k_lane_stitch<false, 1>, grid0, 8);
 #ifdef ANDI_LANE_STATS
 	if (andi_knob(KNOB_LANE_STATS)) { // pass B's first stage: how its segments were settled, and the chain steps that took
 		static const char *names[8] = {"entered behind the cold chain's first anchor", "met behind its first anchor", "met at a mark",
@@ -1410,9 +1413,9 @@ hipError_t andi_launch_lane_stitch(const ScanArgs &a0, hipStream_t st) {
 	for (uint32_t r = 0; again && r < ANDI_RESTITCH_ROUNDS; ++r) {
 		a.restitch_round = r;
 		if (a.exact_equal)
-			stage(k_stitch_heads, k_lane_stitch<true, 2>, grid);
+			stage(k_stitch_heads, k_lane_stitch<true, 2>, grid, 13 + r);
 		else
-			stage(k_stitch_heads, k_lane_stitch<false, 2>, grid);
+			stage(k_stitch_heads, k_lane_stitch<false, 2>, grid, 13 + r);
 	}
 #ifdef ANDI_LANE_STATS
 	if (andi_knob(KNOB_LANE_STATS)) { // replays by length (steps: 0, 1, 2-3, 4-7, ...) per kind of launch
