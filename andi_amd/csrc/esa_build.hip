@@ -356,9 +356,9 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // the first code the gap behind the suffix with record L can own (has: there is such a suffix): behind a full K-mer
 // the next code; "w <sep>" sorts before every K-mer that starts with w
 __device__ __forceinline__ uint32_t first_code(bool has, uint32_t L, int K) {
-	if (!has) return 0u;
 	const uint32_t v = REC_V(L), sh = 2 * ((uint32_t)K - v);
-	return ((REC_CODE(L) >> sh) << sh) + (v == (uint32_t)K ? 1u : 0u);
+	const uint32_t c = ((REC_CODE(L) >> sh) << sh) + (v == (uint32_t)K ? 1u : 0u);
+	return has ? c : 0u;
 }
 
 __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0, const int32_t *__restrict__ SA,
@@ -368,7 +368,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 	__shared__ uint32_t s_absent[PT_TILE];  // number of absent codes it owns (they come first)
 	__shared__ uint32_t s_h[PT_TILE + 2];   // s_h[k + 1]: characters the suffixes r0 + k - 1 and r0 + k share
 	__shared__ uint2 s_present[PT_TILE];    // entry of the K-mer of suffix r, if the gap owns it
-	__shared__ uint32_t s_rec[PT_TILE + 3]; // rec of the suffixes r0 - 2 .. r0 + PT_TILE
+	__shared__ uint32_t s_rec[PT_TILE + 5]; // rec of the suffixes r0 - 2 .. r0 + PT_TILE (two more words: the run test below reads ahead of what it uses)
 	__shared__ uint64_t s_some[PT_WORDS];   // gap i owns entries
 	__shared__ uint32_t s_bits[PT_RANKED / 32]; // bit t: an owning gap's entries start at t
 	__shared__ uint32_t s_before[PT_RANKED / 32]; // set bits in the words before this one
@@ -410,7 +410,11 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		const bool live = gid <= (uint32_t)n;
 		const int32_t r = (int32_t)(live ? gid : 0);
 		const bool hasL = live && r > 0, hasR = live && r < n;
-		const uint32_t L = hasL ? s_rec[i + 1] : 0u, R = hasR ? s_rec[i + 2] : 0u;
+		// (the records around the gap and the three behind it, and the suffix's position: fetched whatever the gap turns out to be --
+		// a branch around every one of these loads cost more than the loads)
+		const uint32_t Lr = s_rec[i + 1], Rr = s_rec[i + 2], a1 = s_rec[i + 3], a2 = s_rec[i + 4], a3 = s_rec[i + 5];
+		const uint32_t L = hasL ? Lr : 0u, R = hasR ? Rr : 0u;
+		const uint32_t sa_r = hasR ? (uint32_t)SA[r] : 0u;
 		const uint32_t h = (hasL && hasR) ? rec_lcp(L, R, K) : 0u;
 		s_h[i + 1] = h;
 		uint32_t absent = 0, first = 1u << (2 * K), owns_present = 0; // (gaps beyond the text: behind every code)
@@ -427,13 +431,10 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 				// are looked at together; a longer run is walked a little further and then followed by binary search
 				// over the suffix array -- records of one K-mer are equal, later ones greater -- so that a K-mer with
 				// 10^6 occurrences (a homopolymer, a satellite) does not serialise on one lane
-				int32_t j = r;
-				bool more = true;
-				if (i + 5 < PT_TILE + 3) { // (records of suffixes beyond the text are 0: never equal to R)
-					const uint32_t a1 = s_rec[i + 3], a2 = s_rec[i + 4], a3 = s_rec[i + 5];
-					const int32_t m = a1 != R ? 0 : (a2 != R ? 1 : (a3 != R ? 2 : 3));
-					j = r + m, more = m == 3;
-				}
+				const bool in_tile = i + 5 < PT_TILE + 3; // (records of suffixes beyond the text are 0: never equal to R)
+				const int32_t m = a1 != R ? 0 : (a2 != R ? 1 : (a3 != R ? 2 : 3));
+				int32_t j = in_tile ? r + m : r;
+				const bool more = !in_tile || m == 3;
 				if (more) {
 					while (j + 1 < n && j - r < 16 && rec(j + 1) == R) ++j;
 					if (j - r == 16 && j + 1 < n && rec(j + 1) == R) {
@@ -449,7 +450,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 					// the K-mer occurs once.  For the scan in rounds (scan_rounds.hip) its entry also carries the
 					// (up to 13) nucleotides that follow it in the text, so that a chance match is settled
 					// without touching the text (costs the build a second gather: +11 %)
-					const uint32_t pos = (uint32_t)SA[r], e0 = pos + full;
+					const uint32_t pos = sa_r, e0 = pos + full;
 					if (single_ext == 2 && REC2) { // the short extended form: what the sorter's keys held behind the K-mer
 						const uint32_t w = mine2[u];
 						present = make_uint2(pos, DEEP_SINGLE | ((w >> 8) << 2) | ((w & 0xffu) << 6));
@@ -468,10 +469,9 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 						const uint32_t ext = (squeeze((uint32_t)w) | (squeeze((uint32_t)(w >> 32)) << 16)) & ((1u << (2 * nval)) - 1u);
 						present = make_uint2(pos, DEEP_SINGLE | (nval << 2) | (ext << 6));
 					}
-				} else if ((uint32_t)(j - r) < (1u << 24)) {
-					present = make_uint2((uint32_t)r, DEEP_MULTI | ((uint32_t)(j - r) << 8));
 				} else {
-					present = make_uint2(0, DEEP_SEARCH);
+					const bool fits = (uint32_t)(j - r) < (1u << 24);
+					present = make_uint2(fits ? (uint32_t)r : 0u, fits ? DEEP_MULTI | ((uint32_t)(j - r) << 8) : (uint32_t)DEEP_SEARCH);
 				}
 				owns_present = 1;
 			}
@@ -491,15 +491,8 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 
 			// (b) absent K-mers inside this gap
 			const int32_t lo = (int32_t)first_code(hasL, L, K); // codes are below 4^13: 32 bits do
-			int32_t hi;
-			if (!hasR) {
-				hi = (int32_t)((1u << (2 * K)) - 1u);
-			} else if (REC_V(R) == full) {
-				hi = (int32_t)REC_CODE(R) - 1;
-			} else {
-				uint32_t sh = 2 * (full - REC_V(R));
-				hi = (int32_t)((REC_CODE(R) >> sh) << sh) - 1;
-			}
+			const uint32_t shR = 2 * (full - REC_V(R)); // (0 for a full K-mer: the code itself; selects, not branches)
+			const int32_t hi = hasR ? (int32_t)((REC_CODE(R) >> shR) << shR) - 1 : (int32_t)((1u << (2 * K)) - 1u);
 			if (lo <= hi) absent = (uint32_t)(hi - lo + 1);
 			first = (uint32_t)lo; // (a gap that owns only its suffix's K-mer: lo is that K-mer; one that owns nothing: where the next one starts)
 		}
@@ -565,17 +558,12 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		const uint32_t gl = s_rec[a + 1], gr = s_rec[a + 2], hll = s_h[a], hrr = s_h[a + 2];
 		uint32_t lL = gL ? rec_lcp_code(c, gl, K) : 0u;
 		uint32_t lR = gR ? rec_lcp_code(c, gr, K) : 0u;
-		uint32_t l, uniq, idx;
-		if (lL > lR) {
-			l = lL, idx = (uint32_t)(rr - 1);
-			uniq = (rr < 2 || hll < l) ? 1u : 0u;
-		} else if (lR > lL) {
-			l = lR, idx = (uint32_t)rr;
-			uniq = (rr + 1 >= (uint32_t)n || hrr < l) ? 1u : 0u;
-		} else { // both neighbours share l characters (or l == 0: every suffix does)
-			l = lL, idx = 0, uniq = (n == 1) ? 1u : 0u;
-		}
-		if (l == 0) uniq = (n == 1) ? 1u : 0u;
+		// (selects: both neighbours sharing l characters -- or l == 0: every suffix does -- is the third case)
+		const bool left = lL > lR, right = lR > lL;
+		const uint32_t l = left ? lL : lR;
+		const uint32_t idx = left ? rr - 1 : (right ? rr : 0u);
+		const bool alone = left ? (rr < 2 || hll < l) : (rr + 1 >= (uint32_t)n || hrr < l);
+		const uint32_t uniq = ((left || right) && l != 0) ? (alone ? 1u : 0u) : (n == 1 ? 1u : 0u);
 		deep[c] = make_uint2(idx, DEEP_FINAL | (uniq << 2) | (l << 8));
 	}
 }
