@@ -332,6 +332,10 @@ __global__ __launch_bounds__(256) void k_pair_route(ScanArgs a) {
 // routed calls: the subjects by falling cost (scan.h: sub_order); one block
 __global__ __launch_bounds__(1024) void k_sub_order(ScanArgs a) {
 	for (uint32_t s = threadIdx.x; s < a.nsub; s += 1024) {
+		if (a.nsub > 8192u) { // (ranking is quadratic: calls of that many subjects take them as they come)
+			a.sub_order[s] = s;
+			continue;
+		}
 		const float c = a.sub_cost[s];
 		uint32_t rank = 0;
 		for (uint32_t t = 0; t < a.nsub; ++t) {
