@@ -6,7 +6,7 @@
 
 // bytes of device workspace andi_sa_device needs for a text of n characters
 size_t andi_sa_device_workspace(int32_t n);
-// SA[0..n) of the text S[0..n) (device pointers; S readable 32 bytes past n, zeros there), bytes in unsigned
+// SA[0..n) of the text S[0..n) (device pointers; S readable 64 bytes past n, zeros there), bytes in unsigned
 // order -- what divsufsort() computes at src/esa.c:303.  h_pinned4: four ints of pinned host memory.  Synchronises
 // the stream once per round.  hipErrorInvalidSymbol: the text holds a byte outside {A C G T ! ; #}.
 // rec (n entries, or null): the suffixes' records for a probe table of depth recK, in suffix-array order
