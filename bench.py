@@ -454,7 +454,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "measured_copy_GBps": copy_gbps,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_ms,
-                         "launches": int(tm["scan_launches"])},
+                         "launches": int(tm["scan_launches"]),
+                         "note": "the dominant kernel: pass A alone, HIP events around its launch(es) on the engine's streams; the sampling "
+                                 "and routing of the pairs, the layout and passes B/C are breakdown_ms_per_step.scan_stitch_reduce"},
             "breakdown_ms_per_step": {"index_build": tm["build_ms"] / args.steps,
                                       "scan_cold_pass": tm["scan_ms"] / args.steps,
                                       "scan_stitch_reduce": tm["stitch_ms"] / args.steps,
