@@ -547,10 +547,10 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 				if (s_first[mid] <= c) a = mid; else b = mid;
 			}
 		}
-		if (c - s_first[a] >= s_absent[a]) { // the K-mer of suffix r itself
-			deep[c] = s_present[a];
-			continue;
-		}
+		// (ONE store per entry, whatever it is: 256 consecutive entries by one instruction -- two stores under complementary masks wrote
+		// every line of the table in two pieces)
+		const bool is_present = c - s_first[a] >= s_absent[a]; // the K-mer of suffix r itself
+		const uint2 pres = s_present[a];
 		const uint32_t rr = r0 + a;
 		const bool gL = rr > 0, gR = rr < (uint32_t)n;
 		// is the left (right) neighbour the only suffix sharing a given prefix length with it?
@@ -564,7 +564,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		const uint32_t idx = left ? rr - 1 : (right ? rr : 0u);
 		const bool alone = left ? (rr < 2 || hll < l) : (rr + 1 >= (uint32_t)n || hrr < l);
 		const uint32_t uniq = ((left || right) && l != 0) ? (alone ? 1u : 0u) : (n == 1 ? 1u : 0u);
-		deep[c] = make_uint2(idx, DEEP_FINAL | (uniq << 2) | (l << 8));
+		deep[c] = is_present ? pres : make_uint2(idx, DEEP_FINAL | (uniq << 2) | (l << 8));
 	}
 }
 
