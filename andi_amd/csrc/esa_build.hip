@@ -564,7 +564,8 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		const uint32_t idx = left ? rr - 1 : (right ? rr : 0u);
 		const bool alone = left ? (rr < 2 || hll < l) : (rr + 1 >= (uint32_t)n || hrr < l);
 		const uint32_t uniq = ((left || right) && l != 0) ? (alone ? 1u : 0u) : (n == 1 ? 1u : 0u);
-		deep[c] = is_present ? pres : make_uint2(idx, DEEP_FINAL | (uniq << 2) | (l << 8));
+		const uint2 val = is_present ? pres : make_uint2(idx, DEEP_FINAL | (uniq << 2) | (l << 8));
+		__builtin_nontemporal_store(((unsigned long long)val.y << 32) | val.x, (unsigned long long *)(deep + c));
 	}
 }
 
