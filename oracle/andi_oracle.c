@@ -22,7 +22,8 @@
  *     / lucky / pair / gap-character counts of dist_anchor for -s 42 -l 1e6
  *     at d = 0.1 / 0.01 / 0.001, and the 4-decimal PHYLIP distances for
  *     -s 1729 -l 1e6 -d 0.1 -d 0.1 under RAW and JC.
- * Bootstrap (model.c:222-232) has no pin anywhere: "parity unpinned".
+ * Bootstrap (model.c:222-232): GSL's published multinomial restated at the end of this file; no pin anywhere
+ * (the reference seeds from the clock and has no test): "parity unpinned", the distribution is what is compared.
  */
 #include "andi_oracle.h"
 
@@ -857,4 +858,114 @@ int orc_dist_matrix(orc_model *M, const char *const *seqs, const size_t *lens,
 		times_out[1] = t_scan;
 	}
 	return failed;
+}
+
+/* ====================================================================== */
+/* bootstrap: model.c:222-232 + process.c:289-321                         */
+/* ====================================================================== */
+/*
+ * model_bootstrap calls gsl_ran_multinomial(RNG, 16, N, p, counts) (model.c:229).  GSL is a third-party dependency
+ * that is absent from the image (configure.ac:22-27, unpinned system library); its PUBLISHED algorithm (GSL manual,
+ * "The Multinomial Distribution"; randist/multinomial.c, after C.S. Davis, "The computer generation of multinomial
+ * random variates", Comp. Stat. Data Anal. 16 (1993) 205-217) is the conditional-binomial construction:
+ *
+ *     norm = sum_k p[k];  sum_p = 0;  sum_n = 0;
+ *     for k = 0 .. K-1:
+ *         n[k] = p[k] > 0 ? Binomial(p[k] / (norm - sum_p), N - sum_n) : 0;
+ *         sum_p += p[k];  sum_n += n[k];
+ *
+ * restated here in the same order and the same double arithmetic.  The reference seeds GSL's generator from the
+ * clock (andi.c:272-279) and holds no test for the bootstrap, so no stream can be reproduced: PARITY UNPINNED, the
+ * DISTRIBUTION is what tests/test_bootstrap_gpu.py compares (chi-square of the device's cells against these draws and
+ * against the exact binomial marginals).  The binomial sampler is exact inversion outward from the mode (any order of
+ * enumerating the support gives Binomial(n, p) exactly; O(sqrt(n p q)) terms per draw), the generator splitmix64.
+ */
+static uint64_t orc_rng_next(uint64_t *s) {
+	uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+static double orc_rng_uniform(uint64_t *s) { /* (0, 1) */
+	return ((double)(orc_rng_next(s) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+uint64_t orc_ran_binomial(uint64_t *rng, double p, uint64_t n) {
+	if (n == 0 || p <= 0.0) return 0;
+	if (p >= 1.0) return n;
+	const double q = 1.0 - p, nd = (double)n;
+	double md = floor((nd + 1.0) * p);
+	if (md > nd) md = nd;
+	const double fm = exp(lgamma(nd + 1.0) - lgamma(md + 1.0) - lgamma(nd - md + 1.0) + md * log(p) + (nd - md) * log(q));
+	double u = orc_rng_uniform(rng);
+	/* enumerate m, m+1, m-1, m+2, m-2, ...; f(k+1) = f(k) (n-k)/(k+1) p/q, f(k-1) = f(k) k/(n-k+1) q/p */
+	double up = md, dn = md, fu = fm, fd = fm;
+	u -= fm;
+	if (u < 0.0) return (uint64_t)md;
+	for (;;) {
+		int moved = 0;
+		if (up < nd) {
+			fu *= (nd - up) / (up + 1.0) * (p / q);
+			up += 1.0;
+			moved = 1;
+			u -= fu;
+			if (u < 0.0) return (uint64_t)up;
+		}
+		if (dn > 0.0) {
+			fd *= dn / (nd - dn + 1.0) * (q / p);
+			dn -= 1.0;
+			moved = 1;
+			u -= fd;
+			if (u < 0.0) return (uint64_t)dn;
+		}
+		if (!moved || (fu < 1e-300 && fd < 1e-300)) return (uint64_t)md; /* rounding left a sliver of u: the mode */
+	}
+}
+
+/* gsl_ran_multinomial as called at model.c:229 (K cells, N trials, weights p, result n) */
+void orc_ran_multinomial(uint64_t *rng, size_t K, uint64_t N, const double *p, uint32_t *n) {
+	double norm = 0.0, sum_p = 0.0;
+	uint64_t sum_n = 0;
+	for (size_t k = 0; k < K; ++k) norm += p[k];
+	for (size_t k = 0; k < K; ++k) {
+		if (p[k] > 0.0) {
+			n[k] = (uint32_t)orc_ran_binomial(rng, p[k] / (norm - sum_p), N - sum_n);
+		} else {
+			n[k] = 0;
+		}
+		sum_p += p[k];
+		sum_n += n[k];
+	}
+}
+
+/* model_bootstrap, model.c:222-232 */
+orc_model orc_model_bootstrap(orc_model datum, uint64_t *rng) {
+	size_t nucl = orc_model_total(&datum);
+	double p[16];
+	for (size_t i = 0; i < 16; ++i) p[i] = datum.counts[i] / (double)nucl;
+	orc_ran_multinomial(rng, 16, nucl, p, datum.counts);
+	return datum;
+}
+
+/* calculate_bootstrap's loop body for ONE replicate, process.c:299-316: B is n*n, diagonal {counts[0] = 1, seq_len = 1},
+ * B(j,i) = B(i,j) = model_bootstrap(model_average(M(i,j), M(j,i))) */
+void orc_bootstrap_matrix(orc_model *B, const orc_model *M, size_t n, uint64_t seed) {
+	uint64_t rng = seed;
+	for (size_t i = 0; i < n; ++i) {
+		for (size_t j = i; j < n; ++j) {
+			if (i == j) {
+				memset(&B[i * n + j], 0, sizeof(orc_model));
+				B[i * n + j].counts[0] = 1;
+				B[i * n + j].seq_len = 1;
+				continue;
+			}
+			orc_model datum = orc_model_average(&M[i * n + j], &M[j * n + i]);
+			if (orc_model_total(&datum) == 0) { /* (0/0 weights: GSL would be handed NaNs; an empty pair stays empty) */
+				B[j * n + i] = B[i * n + j] = datum;
+				continue;
+			}
+			datum = orc_model_bootstrap(datum, &rng);
+			B[j * n + i] = B[i * n + j] = datum;
+		}
+	}
 }

@@ -111,6 +111,14 @@ void orc_scan_row(orc_model *row, const orc_esa *E, size_t threshold,
 				  const char *const *seqs, const size_t *lens, size_t n,
 				  size_t self, int model, int threads);
 
+/* ---- bootstrap (model.c:222-232, process.c:289-321) -------------------- */
+/* GSL is absent from the image: its published conditional-binomial multinomial is restated; the reference seeds from the
+ * clock, so the distribution -- not a stream -- is what can be compared (parity unpinned, see andi_oracle.c). */
+uint64_t orc_ran_binomial(uint64_t *rng, double p, uint64_t n);                          /* gsl_ran_binomial's law */
+void orc_ran_multinomial(uint64_t *rng, size_t K, uint64_t N, const double *p, uint32_t *n); /* gsl_ran_multinomial, model.c:229 */
+orc_model orc_model_bootstrap(orc_model datum, uint64_t *rng);                           /* model.c:222-232 */
+void orc_bootstrap_matrix(orc_model *B, const orc_model *M, size_t n, uint64_t seed);    /* process.c:299-316, one replicate */
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,10 @@ def lib():
         L.orc_scan_row.argtypes = [
             C.c_void_p, C.POINTER(Esa), C.c_size_t, C.POINTER(C.c_char_p),
             C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+        L.orc_bootstrap_matrix.restype = None
+        L.orc_bootstrap_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
+        L.orc_ran_binomial.restype = C.c_uint64
+        L.orc_ran_binomial.argtypes = [C.POINTER(C.c_uint64), C.c_double, C.c_uint64]
         _lib = L
     return _lib
 
@@ -247,3 +251,16 @@ def suffix_array(text: bytes):
     if lib().orc_suffix_array(C.cast(buf, C.c_void_p), sa.ctypes.data, n):
         raise RuntimeError("orc_suffix_array failed")
     return sa
+
+
+def bootstrap(M, replicates, seed=1):
+    """calculate_bootstrap (src/process.c:289-321) with the restated gsl_ran_multinomial: (replicates, n, n, 17) uint32.
+    Not a stream anyone else produces (the reference seeds from the clock): draws of the right DISTRIBUTION."""
+    M = np.ascontiguousarray(M, dtype=np.uint32)
+    n = M.shape[0]
+    assert M.shape == (n, n, 17)
+    B = np.zeros((replicates, n, n, 17), dtype=np.uint32)
+    L = lib()
+    for r in range(replicates):
+        L.orc_bootstrap_matrix(B[r].ctypes.data, M.ctypes.data, n, (seed * 0x9E3779B97F4A7C15 + r * 0xD1B54A32D192ED03) & (2**64 - 1))
+    return B

@@ -12,8 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # The suite drives the engine through its experiment switches and test hooks (forced kernels, layouts, segment lengths:
 # andi_amd/csrc/knobs.h); the shipped library does not have them.  So the suite loads libandihip_test.so -- the same
-# sources with -DANDI_TEST_HOOKS -- unless told otherwise (ANDI_HIP_LIB; ANDI_TESTS_SHIPPED_LIB=1: the shipped library, for
-# the tests that set no switch -- tests/test_configs_gpu.py::test_shipped_library_on_the_default_path runs those that way).
+# sources with -DANDI_TEST_HOOKS -- unless told otherwise (ANDI_HIP_LIB; ANDI_TESTS_SHIPPED_LIB=1: the shipped library --
+# tests/test_configs_gpu.py::test_whole_suite_against_the_shipped_library runs EVERY -m gpu test that way, and a test is
+# skipped only where it asks for a hook the shipped library lacks: needs_hooks() below).
 if not os.environ.get("ANDI_HIP_LIB") and not os.environ.get("ANDI_TESTS_SHIPPED_LIB"):
     os.environ["ANDI_HIP_LIB"] = os.path.join(ROOT, "andi_amd", "libandihip_test.so")
 
@@ -101,6 +102,28 @@ def rand_dna(rng, n, alphabet=b"ACGT"):
 
 # ---------------------------------------------------------------- the library's environment switches
 # libandihip.so reads its ANDI_* switches once (andi_amd/csrc/knobs.h); a test that changes one tells it to look again.
+SHIPPED_LIB = bool(os.environ.get("ANDI_TESTS_SHIPPED_LIB")) and not os.environ.get("ANDI_HIP_LIB")
+
+
+def _shipped_knob_names():
+    import re
+    text = open(os.path.join(ROOT, "andi_amd", "csrc", "knobs.h")).read()
+    line = text.split("#define ANDI_KNOB_LIST_SHIPPED(X)")[1].split("\n")[0]
+    return set(re.findall(r"X\((\w+)\)", line))
+
+
+_SHIPPED_KNOBS = _shipped_knob_names()
+
+
+def needs_hooks(name, value):
+    """With ANDI_TESTS_SHIPPED_LIB=1 the suite runs against libandihip.so itself, which knows only the shipped switches:
+    a test that asks for one of the test hooks is skipped at that point (what it ran before that point ran on the shipped
+    library); a test that sets none, or only shipped switches, runs whole."""
+    name = name[len("ANDI_"):] if name.startswith("ANDI_") else name
+    if SHIPPED_LIB and value is not None and name not in _SHIPPED_KNOBS:
+        pytest.skip("ANDI_%s is a test hook: not in the shipped library" % name)
+
+
 def reload_knobs():
     from andi_amd import lib
     if lib._lib is not None:
@@ -113,6 +136,8 @@ import contextlib
 @contextlib.contextmanager
 def knobs(**kv):
     """ANDI_<NAME>=value for the block (None: unset), e.g. knobs(COOP=4); the library looks again on entry and exit."""
+    for k, v in kv.items():
+        needs_hooks(k, v)
     old = {k: os.environ.get("ANDI_" + k) for k in kv}
     try:
         for k, v in kv.items():
@@ -136,6 +161,7 @@ def knob(monkeypatch):
     """knob("ANDI_X", "1") / knob("ANDI_X", None): monkeypatch.setenv / delenv and the library looks again (and once more
     when the test is over, after monkeypatch has put the environment back: _knobs_restored below)."""
     def set_(name, value):
+        needs_hooks(name, value)
         if value is None:
             monkeypatch.delenv(name, raising=False)
         else:
@@ -148,3 +174,41 @@ def knob(monkeypatch):
 def _knobs_restored():
     yield
     reload_knobs()  # (set up before any fixture the test asks for, so torn down after monkeypatch's undo)
+
+
+# ---------------------------------------------------------------- distribution checks of the bootstrap (parity unpinned)
+def binomial_gof_pvalue(x, N, p, bins=24):
+    """chi-square goodness of fit of integer draws x against Binomial(N, p): cells = quantile bins of the exact law with
+    expected counts >= 8 (fewer bins for narrow laws)."""
+    from scipy import stats
+    x = np.asarray(x, dtype=np.int64)
+    law = stats.binom(int(N), float(p))
+    qs = np.unique(law.ppf(np.linspace(0, 1, bins + 1)[1:-1]).astype(np.int64))
+    edges = np.concatenate(([-1], qs, [int(N)]))
+    edges = np.unique(edges)
+    obs = np.histogram(x, bins=edges + 0.5)[0].astype(np.float64)
+    exp = np.diff(law.cdf(edges)) * len(x)
+    keep = exp > 0
+    obs, exp = obs[keep], exp[keep]
+    while len(exp) > 2 and exp.min() < 8:  # merge the thinnest cell into a neighbour
+        k = int(exp.argmin())
+        j = k - 1 if k > 0 else 1
+        exp[j] += exp[k]; obs[j] += obs[k]
+        exp, obs = np.delete(exp, k), np.delete(obs, k)
+    if len(exp) < 2:
+        return 1.0 if obs.sum() == len(x) else 0.0
+    return float(stats.chisquare(obs, exp * obs.sum() / exp.sum()).pvalue)
+
+
+def two_sample_pvalue(x, y, bins=24):
+    """chi-square test that integer samples x and y come from one law (cells = pooled quantiles)."""
+    from scipy import stats
+    x, y = np.asarray(x, dtype=np.int64), np.asarray(y, dtype=np.int64)
+    edges = np.unique(np.quantile(np.concatenate([x, y]), np.linspace(0, 1, bins + 1)[1:-1]).astype(np.int64))
+    edges = np.concatenate(([min(x.min(), y.min()) - 1], edges, [max(x.max(), y.max())])) + 0.5
+    edges = np.unique(edges)
+    a, b = np.histogram(x, edges)[0], np.histogram(y, edges)[0]
+    keep = (a + b) > 0
+    if keep.sum() < 2:
+        return 1.0
+    return float(stats.chi2_contingency(np.stack([a[keep], b[keep]]))[1])

@@ -206,3 +206,39 @@ def test_low_homology_is_below_the_warning_line(orc, seed):
     d = orc.estimate(M[0, 1].astype(np.uint64) + M[1, 0], orc.M_JC)
     assert np.isnan(d) or orc.coverage(M[0, 1]) < 0.2 or orc.coverage(M[1, 0]) < 0.2
     assert orc.coverage(M[0, 1]) < 0.2 and orc.coverage(M[1, 0]) < 0.2
+
+
+# ---------------------------------------------------------------- bootstrap: GSL's published multinomial, restated
+def test_oracle_multinomial_follows_the_published_law(orc):
+    """model_bootstrap (src/model.c:222-232) = gsl_ran_multinomial(RNG, 16, N, counts / N): the oracle restates GSL's
+    published conditional-binomial construction (oracle/andi_oracle.c).  The reference seeds GSL from the clock
+    (src/andi.c:272-279) and holds no vector for it -- parity unpinned --, so the LAW is pinned instead: N is preserved,
+    empty cells stay empty, every cell's marginal is Binomial(N, p_c) and so are sums of cells (which a wrong
+    conditioning would break), tiny counts and counts of 10^5..10^6; the binomial sampler itself against the exact law."""
+    import ctypes as C
+    from conftest import binomial_gof_pvalue
+    L = orc.lib()
+    rng = C.c_uint64(2024)
+    for n, p in ((5, 0.3), (40, 0.02), (1000, 0.5), (123456, 0.25), (3_000_000, 1e-5), (2_000_000, 0.9993)):
+        x = np.array([L.orc_ran_binomial(C.byref(rng), p, n) for _ in range(20000)])
+        assert x.min() >= 0 and x.max() <= n
+        assert binomial_gof_pvalue(x, n, p) > 1e-4, (n, p)
+    reps = 10000
+    M = np.zeros((3, 3, 17), np.uint32)
+    M[0, 1, :16] = [30, 0, 1, 0, 0, 7, 0, 0, 0, 2, 2, 0, 1, 0, 0, 1]          # tiny counts
+    M[1, 0, :16] = [0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    M[0, 2, :16] = [300000, 50, 700, 30, 60, 250000, 20, 10, 5, 3, 280000, 40, 9, 1, 0, 270000]
+    M[2, 0, :16] = [290000, 45, 650, 33, 70, 255000, 25, 12, 4, 2, 275000, 35, 11, 0, 0, 265000]
+    M[:, :, 16] = 1234
+    B = orc.bootstrap(M, reps, seed=11)
+    assert (B[:, 1, 2, :16] == 0).all() and (B[:, 0, 0, 0] == 1).all() and (B[:, 0, 0, 16] == 1).all()
+    for i, j in ((0, 1), (0, 2)):
+        c = M[i, j, :16].astype(np.int64) + M[j, i, :16]
+        N = int(c.sum())
+        x = B[:, i, j, :16].astype(np.int64)
+        assert (B[:, i, j] == B[:, j, i]).all() and (x.sum(axis=1) == N).all() and (x[:, c == 0] == 0).all()
+        assert (B[:, i, j, 16] == 2468).all()  # seq_len summed, src/model.c:44
+        for cell in np.nonzero(c)[0]:
+            assert binomial_gof_pvalue(x[:, cell], N, c[cell] / N) > 1e-5, (i, j, cell)
+        for cells in ((0, 5), (0, 5, 10, 15), (1, 2, 3, 4), (10, 15)):
+            assert binomial_gof_pvalue(x[:, list(cells)].sum(axis=1), N, c[list(cells)].sum() / N) > 1e-5, (i, j, cells)
