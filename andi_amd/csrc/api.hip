@@ -136,6 +136,7 @@ struct andi_hip_ctx {
 	void *pool_scratch = nullptr;      // pass A by wavefronts with pooled walks (coop_pool.h): a scratch per resident wavefront
 	size_t pool_bytes = 0;
 	uint32_t pool_waves = 0;
+	bool pool_failed = false;          // its allocation failed once: not tried again by this context
 	void *scratch2 = nullptr;          // the second lane layout (those pairs), grown on demand
 	size_t scratch2_bytes = 0;
 	unsigned long long *d_route = nullptr; // routed scan calls: query nucleotides whose pass A ran by wavefronts / by lanes, pairs handed back (read with the timings)
@@ -325,13 +326,30 @@ struct IdleStream {
 	int device, prio;
 	hipStream_t s;
 };
-static std::mutex mu;
-static std::vector<IdleStream> streams;
 struct IdlePinned {
 	void *p;
 	size_t bytes;
 };
-static std::vector<IdlePinned> pinned;
+struct IdleScratch { // k_pool_cold's scratch (0.8 GB on a 256-CU part: a mapping of its own, not the arena's)
+	int device;
+	void *p;
+	size_t bytes;
+};
+// The pool's state lives on the heap and is never destroyed (as dev_arena.h's arenas): a context may be released during or
+// after the destruction of this library's statics, and its streams come back here.
+struct State {
+	std::mutex mu;
+	std::vector<IdleStream> streams;
+	std::vector<IdlePinned> pinned;
+	std::vector<IdleScratch> scratch;
+};
+static State &state() {
+	static State *s = new State;
+	return *s;
+}
+#define mu state().mu
+#define streams state().streams
+#define pinned state().pinned
 constexpr size_t PINNED_KEEP = (size_t)256 << 20; // bytes of pinned buffers kept at most
 
 static hipError_t stream_get(hipStream_t *out, int device, int prio) {
@@ -378,21 +396,63 @@ static void pinned_put(void *p, size_t bytes) {
 	}
 	(void)hipHostFree(p);
 }
-static bool any() {
-	std::lock_guard<std::mutex> lk(mu);
-	return !streams.empty() || !pinned.empty();
-}
-static void trim() { // (the caller restores the current device)
-	std::vector<IdleStream> st;
-	std::vector<IdlePinned> pb;
+// the pooled wavefront kernel's scratch: one per device is kept from context to context (a context of the seam lives for one
+// call: 0.8 GB of hipMalloc + hipFree per call and device otherwise); andi_hip_trim returns it
+static void *scratch_get(int device, size_t bytes) {
 	{
 		std::lock_guard<std::mutex> lk(mu);
-		st.swap(streams), pb.swap(pinned);
+		auto &v = state().scratch;
+		for (size_t i = 0; i < v.size(); ++i)
+			if (v[i].device == device && v[i].bytes == bytes) {
+				void *p = v[i].p;
+				v.erase(v.begin() + (long)i);
+				return p;
+			}
+	}
+	void *p = nullptr;
+	if (hipMalloc(&p, bytes) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return p;
+}
+static void scratch_put(int device, void *p, size_t bytes) { // (idle: the caller has waited for the kernels that used it)
+	if (!p) return;
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		auto &v = state().scratch;
+		bool have = false;
+		for (const IdleScratch &x : v) have = have || x.device == device;
+		if (!have) {
+			v.push_back({device, p, bytes});
+			return;
+		}
+	}
+	(void)hipFree(p);
+}
+static bool any() {
+	std::lock_guard<std::mutex> lk(mu);
+	return !streams.empty() || !pinned.empty() || !state().scratch.empty();
+}
+static size_t trim() { // (the caller restores the current device); returns the device bytes given back
+	std::vector<IdleStream> st;
+	std::vector<IdlePinned> pb;
+	std::vector<IdleScratch> sc;
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		st.swap(streams), pb.swap(pinned), sc.swap(state().scratch);
 	}
 	for (const IdleStream &x : st)
 		if (hipSetDevice(x.device) == hipSuccess) (void)hipStreamDestroy(x.s);
 	for (const IdlePinned &b : pb) (void)hipHostFree(b.p);
+	size_t freed = 0;
+	for (const IdleScratch &x : sc)
+		if (hipSetDevice(x.device) == hipSuccess && hipFree(x.p) == hipSuccess) freed += x.bytes;
+	return freed;
 }
+#undef mu
+#undef streams
+#undef pinned
 } // namespace host_pool
 
 size_t andi_hip_trim(void) {
@@ -409,7 +469,7 @@ size_t andi_hip_trim(void) {
 		if (hipSetDevice(d) != hipSuccess) continue;
 		freed += andi_arena::trim(d);
 	}
-	host_pool::trim(); // (idle streams, pinned upload buffers)
+	freed += host_pool::trim(); // (idle streams, pinned upload buffers, the pooled kernel's scratch)
 	(void)hipSetDevice(cur);
 	return freed;
 }
@@ -513,7 +573,10 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	if (ctx->h_quad_waves) (void)hipHostFree(ctx->h_quad_waves);
 	if (ctx->d_route) (void)andi_arena::dev_free(ctx->d_route);
 	if (ctx->scratch2) (void)andi_arena::dev_free(ctx->scratch2);
-	if (ctx->pool_scratch) (void)andi_arena::dev_free(ctx->pool_scratch);
+	if (ctx->pool_scratch) { // (kept for the device's next context: host_pool)
+		(void)hipDeviceSynchronize();
+		host_pool::scratch_put(ctx->device, ctx->pool_scratch, ctx->pool_bytes + 4096);
+	}
 	if (ctx->h_any_left) (void)hipHostFree(ctx->h_any_left);
 	if (ctx->coop_stream) {
 		(void)hipStreamSynchronize(ctx->coop_stream);
@@ -634,6 +697,44 @@ static int esa_upload(andi_hip_ctx *ctx, andi_hip_esa *e, const char *RS, const 
 		err = hipMemcpyAsync(e->SA, SA, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess) err = done ? hipEventRecord(done, ctx->stream) : hipStreamSynchronize(ctx->stream);
 	if (err != hipSuccess) return fail(ctx, "uploading a subject", err);
+	return 0;
+}
+
+// seq_subject_init (src/sequence.c:210-219) for a sequence that is already resident as a query: RS is written into the slot
+// by a kernel from the query pool (esa_build.hip: k_rs_from_query) -- no host pass over the sequence, no upload.  The
+// threshold is the caller's (min_anchor_length on the host, from the device's G+C count: queries_gc_counts).
+static int esa_from_query(andi_hip_ctx *ctx, andi_hip_esa *e, const andi_hip_queries *Q, size_t i, size_t threshold) {
+	const size_t len = Q->len[i], n = 2 * len + 1;
+	if (n > e->cap) {
+		ctx->err = "subject does not fit its slot";
+		return 1;
+	}
+	e->n = (int32_t)n;
+	e->thr = (int32_t)threshold;
+	e->deepK = std::min(pick_deep_k(n, ctx->queries_hint), e->deepK_cap);
+	e->ref_built = e->index_built = false;
+	e->rec_valid = false;
+	memset(e->h_flags, 0, 4 * sizeof(int32_t)); // (the slot is the caller's: nothing of it is in flight)
+	hipError_t err = hipMemsetAsync(e->S + (n & ~(size_t)3), 0, (n & 3) + 1 + ANDI_PAD, ctx->stream);
+	if (err == hipSuccess) err = andi_launch_rs_from_query(e->S, Q->pool + Q->off[i], (uint32_t)len, ctx->stream);
+	if (err != hipSuccess) return fail(ctx, "writing a subject from its resident sequence", err);
+	return 0;
+}
+
+// calc_gc's numerators (src/sequence.c:197-208) of all staged sequences, counted where they lie
+static int queries_gc_counts(andi_hip_ctx *ctx, const andi_hip_queries *Q, std::vector<unsigned long long> &out) {
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	unsigned long long *d = nullptr;
+	HIP_TRY(ctx, dmalloc(&d, Q->nq));
+	uint32_t longest = 0;
+	for (uint32_t l : Q->len) longest = std::max(longest, l);
+	out.assign(Q->nq, 0);
+	hipError_t err = hipMemsetAsync(d, 0, Q->nq * sizeof(unsigned long long), ctx->stream);
+	if (err == hipSuccess) err = andi_launch_gc_counts(Q->pool, Q->d_off, Q->d_len, (uint32_t)Q->nq, longest, d, ctx->stream);
+	if (err == hipSuccess) err = hipMemcpyAsync(out.data(), d, Q->nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+	(void)andi_arena::dev_free(d);
+	if (err != hipSuccess) return fail(ctx, "counting G+C of the staged sequences", err);
 	return 0;
 }
 
@@ -1386,24 +1487,28 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		const char *pm = andi_knob(KNOB_POOL_MATCH); // (experiments: mean sampled match from which a routed pair's wavefront kernel is k_pool_cold)
 		a.pool_match = pm && atoi(pm) >= 0 ? (uint32_t)atoi(pm) : 48u;
 	}
-	if ((a.coop || routed) && model != ANDI_M_LOGDET && model != ANDI_M_ANI) { // pooled walks: the scratch of the resident wavefronts, once per context
-		if (!ctx->pool_scratch) {
+	// Pooled walks (k_pool_cold): the scratch of the resident wavefronts -- 0.8 GB on a 256-CU part, a mapping of its own -- is
+	// taken only by a call that is going to run that kernel (andi_coop_wants_pool: known behind the look at the layout in a
+	// routed call), from the device's idle one if a destroyed context left it (host_pool), once per context; a context whose
+	// attempt failed does not try again (the windows then stay in LDS: k_coop_cold).
+	auto give_pool_scratch = [&](ScanArgs &x) {
+		if (!andi_coop_wants_pool(x)) return;
+		if (!ctx->pool_scratch && !ctx->pool_failed) {
 			uint32_t waves = 0;
 			const size_t bytes = andi_pool_scratch_bytes(ctx->device, &waves);
-			if (bytes && hipMalloc(&ctx->pool_scratch, bytes) == hipSuccess) // (its own mapping: larger than half an arena chunk)
+			if (bytes && (ctx->pool_scratch = host_pool::scratch_get(ctx->device, bytes)))
 				ctx->pool_waves = waves, ctx->pool_bytes = bytes - 4096;
 			else
-				(void)hipGetLastError(), ctx->pool_scratch = nullptr; // (no room, or switched off: the windows stay in LDS)
+				ctx->pool_failed = true;
 		}
-		if (ctx->pool_scratch) {
-			a.pool_ticket = (uint32_t *)ctx->pool_scratch, a.pool_scratch = (char *)ctx->pool_scratch + 4096, a.pool_waves = ctx->pool_waves, a.pool_bytes = ctx->pool_bytes;
-			// that kernel streams the texts bit-sliced: the subjects' planes are made from their 4-bit symbols in front of its launch (only
-			// there -- a call that takes k_coop_cold does not pay the 0.06 ms: andi_launch_coop_cold)
-			size_t max_n = 0;
-			for (size_t k = 0; k < nsub; ++k) max_n = std::max(max_n, (size_t)subjects[k]->n);
-			a.pool_max_n = max_n;
-		}
-	}
+		if (!ctx->pool_scratch) return;
+		x.pool_ticket = (uint32_t *)ctx->pool_scratch, x.pool_scratch = (char *)ctx->pool_scratch + 4096, x.pool_waves = ctx->pool_waves, x.pool_bytes = ctx->pool_bytes;
+		// that kernel streams the texts bit-sliced: the subjects' planes are made from their 4-bit symbols in front of its launch (only
+		// there -- a call that takes k_coop_cold does not pay the 0.06 ms: andi_launch_coop_cold)
+		size_t max_n = 0;
+		for (size_t k = 0; k < nsub; ++k) max_n = std::max(max_n, (size_t)subjects[k]->n);
+		x.pool_max_n = max_n;
+	};
 	a.route = routed ? ANDI_LAYOUT_LANES : 0, a.route_seg = coop_seg, a.route_nt = ctx->d_route;
 	uint32_t longest_q = 0;
 	for (size_t i = 0; i < q->nq; ++i) longest_q = std::max(longest_q, (uint32_t)q->len[i]);
@@ -1475,6 +1580,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			const bool lanes_first = look && e == hipSuccess && (uint64_t)ctx->h_any_left[1 + ANDI_LANE_WAVES] * 20 < ctx->h_any_left[1 + ANDI_ALL_WAVES];
 			// which wavefront kernel: the pooled one where the pairs that suit it hold at least half of the segments (scan.h)
 			b.pool_use = look && e == hipSuccess && 2 * (uint64_t)ctx->h_any_left[1 + ANDI_POOL_SEGS] >= ctx->h_any_left[1 + ANDI_COOP_SEGS] && ctx->h_any_left[1 + ANDI_COOP_SEGS] != 0;
+			give_pool_scratch(b);
 			if (e == hipSuccess) e = hipEventRecord(ctx->coop_fork, ctx->stream);
 			if (e == hipSuccess) e = hipStreamWaitEvent(ctx->coop_stream, ctx->coop_fork, 0);
 			if (e == hipSuccess && lanes_first) e = andi_launch_scan_cold(a, ctx->stream);
@@ -1564,6 +1670,55 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	(adaptive ? ctx->acc.adaptive_calls : ctx->acc.uniform_calls)++;
 	ctx->acc.scan_pairs += pairs;
 	ctx->acc.scan_query_nt += nt;
+	return 0;
+}
+
+// ------------------------------------------------------------------ the measured copy ceiling (bench.py: roofline.measured_copy_GBps)
+namespace {
+__global__ __launch_bounds__(256) void k_stream_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+	const size_t stride = (size_t)gridDim.x * 256;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+		uint4 v;
+		v.x = __builtin_nontemporal_load(&src[i].x), v.y = __builtin_nontemporal_load(&src[i].y);
+		v.z = __builtin_nontemporal_load(&src[i].z), v.w = __builtin_nontemporal_load(&src[i].w);
+		__builtin_nontemporal_store(v.x, &dst[i].x), __builtin_nontemporal_store(v.y, &dst[i].y);
+		__builtin_nontemporal_store(v.z, &dst[i].z), __builtin_nontemporal_store(v.w, &dst[i].w);
+	}
+}
+} // namespace
+
+int andi_hip_copy_ceiling(andi_hip_ctx *ctx, size_t bytes, int reps, double *gbps) {
+	if (!ctx || !gbps || bytes < 4096 || reps < 1) {
+		if (ctx) ctx->err = "andi_hip_copy_ceiling: bad arguments";
+		return 1;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const size_t n16 = bytes / 16;
+	uint4 *src = nullptr, *dst = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	hipError_t err = hipMalloc((void **)&src, n16 * 16);
+	if (err == hipSuccess) err = hipMalloc((void **)&dst, n16 * 16);
+	if (err == hipSuccess) err = hipMemsetAsync(src, 1, n16 * 16, ctx->stream);
+	if (err == hipSuccess) err = hipEventCreate(&e0);
+	if (err == hipSuccess) err = hipEventCreate(&e1);
+	int cus = 256;
+	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+	const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)cus * 32);
+	float ms = 0;
+	if (err == hipSuccess) {
+		k_stream_copy<<<grid, 256, 0, ctx->stream>>>(src, dst, n16); // (untimed: first touch)
+		err = hipEventRecord(e0, ctx->stream);
+		for (int r = 0; r < reps && err == hipSuccess; ++r) k_stream_copy<<<grid, 256, 0, ctx->stream>>>(src, dst, n16);
+		if (err == hipSuccess) err = hipEventRecord(e1, ctx->stream);
+		if (err == hipSuccess) err = hipEventSynchronize(e1);
+		if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+	}
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	if (src) (void)hipFree(src);
+	if (dst) (void)hipFree(dst);
+	if (err != hipSuccess) return fail(ctx, "andi_hip_copy_ceiling", err);
+	*gbps = ms > 0 ? 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;
 	return 0;
 }
 
@@ -1689,6 +1844,13 @@ const char *andi_hip_last_gather(void) {
 	return g_last_gather;
 }
 
+void andi_hip_row_block(size_t total, size_t parts, size_t k, size_t *first, size_t *last) {
+	size_t f = 0, l = 0;
+	if (parts && k < parts) row_block(total, parts, k, f, l);
+	if (first) *first = f;
+	if (last) *last = l;
+}
+
 int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 						 const andi_hip_opts *opts_in, char *errbuf, size_t errlen) {
 	if (!M || !seqs || n == 0) {
@@ -1773,6 +1935,12 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 	int threads = o.host_threads > 0 ? o.host_threads : (int)std::thread::hardware_concurrency();
 	if (threads < 1) threads = 1;
 	if ((size_t)threads > n) threads = (int)n;
+	// Every subject is also a query, and the queries are staged in HBM before the first batch: unless the suffix arrays are
+	// the host's (sa_on_host: the sorter needs RS where it runs), a device writes RS = revcomp(S) '#' S into the subject's
+	// slot itself from its query pool (esa_from_query) and the host computes only min_anchor_length from the device's G+C
+	// counts -- no host pass over the sequences, no second upload of what is already resident (round 5's trace of the bench
+	// set's warm call: host pool 5.5 ms + subject uploads 12.9 ms of 54).
+	const bool dev_prep = !o.sa_on_host;
 	const size_t batch_max = o.low_memory ? 1 : 8;
 	const size_t window = (size_t)threads + ndev * batch_max + 1;
 
@@ -1856,6 +2024,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		andi_hip_ctx *ctx = nullptr;  // scans, row copies
 		andi_hip_ctx *prep = nullptr; // suffix arrays, index builds
 		andi_hip_ctx *up = nullptr;   // uploads (a thread and a stream of their own: the copies of batch k + 1 run beside the sorts of batch k)
+		std::vector<andi_hip_ctx *> sorters; // suffix sorts of a batch's subjects side by side (streams and workspaces of their own)
 		andi_hip_queries *Q = nullptr;
 		andi_hip_model *d_rows = nullptr; // rccl: the whole row block; direct: one batch of rows
 		size_t pinned_bytes = 0;
@@ -1903,8 +2072,22 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		};
 		if (andi_hip_ctx_create(&D.ctx, devs[d], eb, sizeof eb)) return bail("creating a context", nullptr);
 		if (ctx_create(&D.prep, devs[d], eb, sizeof eb, true)) return bail("creating a context", nullptr);
-		if (ctx_create(&D.up, devs[d], eb, sizeof eb, true)) return bail("creating a context", nullptr);
-		andi_hip_ctx_expect_queries(D.up, n - 1);
+		if (!dev_prep) {
+			if (ctx_create(&D.up, devs[d], eb, sizeof eb, true)) return bail("creating a context", nullptr);
+			andi_hip_ctx_expect_queries(D.up, n - 1);
+		}
+		// A suffix sort is two dozen launches with two or three host round trips between them (sa_device.hip): 0.73 ms per
+		// 9.8 M characters of which the device is busy half.  The subjects of a batch are sorted by up to four host threads,
+		// each with a stream and a workspace of its own, so one subject's small launches and waits hide behind another's
+		// radix passes.
+		size_t sort_width = dev_prep && !o.low_memory ? std::min<size_t>(4, std::min(batch_max, last[d] - first[d])) : 1;
+		if (andi_sa_device_workspace((int32_t)rs_cap) * sort_width > ((size_t)24 << 30)) sort_width = 1; // (45 bytes per character each)
+		for (size_t w = 1; w < sort_width; ++w) {
+			andi_hip_ctx *cx = nullptr;
+			if (ctx_create(&cx, devs[d], eb, sizeof eb, true)) return bail("creating a context", nullptr);
+			andi_hip_ctx_expect_queries(cx, n - 1);
+			D.sorters.push_back(cx);
+		}
 		andi_hip_ctx_expect_queries(D.ctx, n - 1);
 		andi_hip_ctx_expect_queries(D.prep, n - 1);
 		lap(t_ctx);
@@ -1915,7 +2098,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		size_t batch = batch_max < rows ? batch_max : rows;
 		auto sets_for = [&](size_t bt) { // (low_memory: one index resident at a time)
 			const size_t nb = (rows + bt - 1) / bt;
-			return o.low_memory ? (size_t)1 : (nb > 2 ? (size_t)3 : (nb > 1 ? (size_t)2 : (size_t)1));
+			return o.low_memory ? (size_t)1 : (nb > 2 && !dev_prep ? (size_t)3 : (nb > 1 ? (size_t)2 : (size_t)1)); // (the third set is the uploads')
 		};
 		{
 			size_t free_b = 0, total_b = 0;
@@ -1947,6 +2130,8 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		} else if (andi_hip_queries_stage(D.ctx, seqs, n, &D.Q)) {
 			return bail("staging queries", D.ctx);
 		}
+		std::vector<unsigned long long> gcs; // G+C of every sequence (calc_gc, src/sequence.c:197-208)
+		if (dev_prep && queries_gc_counts(D.ctx, D.Q, gcs)) return bail("staging queries", D.ctx);
 		lap(t_queries);
 		for (size_t b = 0; b < sets * batch; ++b)
 			if (esa_reserve(D.prep, rs_cap, &D.slots[b])) return bail("allocating subject slots", D.prep);
@@ -1954,7 +2139,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		double t_reserve = 0, t_pinned = 0;
 		lap(t_reserve);
 		D.pinned_bytes = 2 * (rs_cap + 64);
-		if (host_pool::pinned_get((void **)&D.pinned, D.pinned_bytes) != hipSuccess) D.pinned = nullptr; // (then from where RS lies)
+		if (dev_prep || host_pool::pinned_get((void **)&D.pinned, D.pinned_bytes) != hipSuccess) D.pinned = nullptr; // (then from where RS lies)
 		if (D.pinned && (hipEventCreateWithFlags(&D.pinned_free[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&D.pinned_free[1], hipEventDisableTiming) != hipSuccess)) {
 			host_pool::pinned_put(D.pinned, D.pinned_bytes);
 			D.pinned = nullptr;
@@ -1972,7 +2157,9 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		bool prep_failed = false;
 		double p_take = 0, p_upload = 0, p_sort = 0, p_build = 0;
 
-		size_t uploaded = 0; // batches whose texts are on the device
+		size_t uploaded = dev_prep ? nbatches : 0; // batches whose texts are on the device (written there by the staging thread itself: all of them)
+		// the device's compute alternates between the stages where a slot set is free for it: stage k + 1, then scan k
+		const bool alternate = sets >= (dev_prep ? (size_t)2 : (size_t)3);
 		auto give_up = [&]() {
 			std::lock_guard<std::mutex> lk(pm);
 			prep_failed = true;
@@ -2046,15 +2233,50 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 			for (size_t k = 0; k < nbatches; ++k) {
 				{ // the batch's texts are there; with three sets the device's compute is this batch's once the scan of batch k - 2 is done
 					std::unique_lock<std::mutex> lk(pm);
-					pcv.wait(lk, [&] { return (uploaded > k && (sets < 3 || k < scanned + 2)) || prep_failed; });
+					pcv.wait(lk, [&] { return (uploaded > k && (dev_prep ? k < scanned + sets : (sets < 3 || k < scanned + 2))) || prep_failed; });
 					if (prep_failed) return;
 				}
 				tl = now_ms();
 				const size_t i0 = first[d] + k * batch, nb = std::min(batch, last[d] - i0);
 				andi_hip_esa **set = D.slots.data() + (k % sets) * batch;
-				for (size_t b = 0; b < nb && !o.sa_on_host; ++b) {
-					if (esa_sort_suffixes(D.prep, set[b])) {
-						bail("suffix array", D.prep);
+				// RS from the resident sequence (the threshold on the host, same libm: src/sequence.c:210-219), then its suffix array
+				auto text_and_sort = [&](andi_hip_ctx *cx, size_t b) -> const char * {
+					const size_t i = i0 + b, len = seqs[i].len;
+					const size_t thr = andi_hip_min_anchor_length(o.p_value, (double)gcs[i] / len, 2 * len + 1);
+					if (esa_from_query(cx, set[b], D.Q, i, thr)) return "staging subject";
+					if (esa_sort_suffixes(cx, set[b])) return "suffix array";
+					return nullptr;
+				};
+				if (dev_prep) {
+					const size_t width = std::min(nb, D.sorters.size() + 1);
+					std::atomic<size_t> next_b{0};
+					std::mutex em;
+					const char *what = nullptr;
+					andi_hip_ctx *where = nullptr;
+					auto sort_some = [&](andi_hip_ctx *cx) {
+						(void)hipSetDevice(devs[d]);
+						for (;;) {
+							const size_t b = next_b.fetch_add(1);
+							if (b >= nb) break;
+							const char *w = text_and_sort(cx, b);
+							if (w) {
+								std::lock_guard<std::mutex> lk(em);
+								if (!what) what = w, where = cx;
+								next_b.store(nb);
+								break;
+							}
+						}
+						if (andi_hip_sync(cx)) {
+							std::lock_guard<std::mutex> lk(em);
+							if (!what) what = "suffix array", where = cx;
+						}
+					};
+					std::vector<std::thread> helpers;
+					for (size_t w = 1; w < width; ++w) helpers.emplace_back(sort_some, D.sorters[w - 1]);
+					sort_some(D.prep);
+					for (auto &t : helpers) t.join();
+					if (what) {
+						bail(what, where);
 						return give_up();
 					}
 					plap(p_sort);
@@ -2071,7 +2293,8 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 				pcv.notify_all();
 			}
 		};
-		std::thread uploader(upload);
+		std::thread uploader;
+		if (!dev_prep) uploader = std::thread(upload);
 		std::thread stager(stage);
 
 		std::vector<int64_t> self(batch);
@@ -2080,7 +2303,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		for (size_t k = 0; k < nbatches && !failed; ++k) {
 			{
 				std::unique_lock<std::mutex> lk(pm);
-				pcv.wait(lk, [&] { return (prepared > k && (sets < 3 || prepared > k + 1 || prepared == nbatches)) || prep_failed; });
+				pcv.wait(lk, [&] { return (prepared > k && (!alternate || prepared > k + 1 || prepared == nbatches)) || prep_failed; });
 				if (prepared <= k) break; // (the staging thread has reported why)
 			}
 			lap(acc_wait);
@@ -2112,14 +2335,14 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		}
 		pcv.notify_all();
 		stager.join();
-		uploader.join();
+		if (uploader.joinable()) uploader.join();
 		if (trace && d == 0)
-			fprintf(stderr, "andi_hip_dist_matrix trace (ms): contexts %.1f, queries %.1f, slots %.1f | staging thread: waiting for the host pool %.1f, subject uploads %.1f, suffix arrays %.1f, index builds %.1f | scan thread: waiting for staged subjects %.1f, scans %.1f, row copies %.1f; driver total %.1f (%zu batches of %zu, %zu slot sets)\n",
-					t_ctx, t_queries, t_slots, p_take, p_upload, p_sort, p_build, acc_wait, acc_scan, acc_copy, now_ms() - t_call, nbatches, batch, sets);
+			fprintf(stderr, "andi_hip_dist_matrix trace (ms): contexts %.1f, queries %.1f, slots %.1f | staging thread: waiting for the host pool %.1f, subject %s %.1f, suffix arrays %.1f, index builds %.1f | scan thread: waiting for staged subjects %.1f, scans %.1f, row copies %.1f; driver total %.1f (%zu batches of %zu, %zu slot sets)\n",
+					t_ctx, t_queries, t_slots, p_take, dev_prep ? "texts written on the device" : "uploads", p_upload, p_sort, p_build, acc_wait, acc_scan, acc_copy, now_ms() - t_call, nbatches, batch, sets);
 	};
 
 	std::vector<std::thread> pool, drivers;
-	for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+	for (int t = 0; t < threads && !dev_prep; ++t) pool.emplace_back(worker);
 	if (ndev == 1) {
 		drive(0); // the calling thread, as before
 	} else {
@@ -2214,10 +2437,12 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 
 	for (auto &D : dv) {
 		if (!D.ctx) {
+			for (auto *cx : D.sorters) andi_hip_ctx_destroy(cx);
 			if (D.prep) andi_hip_ctx_destroy(D.prep);
 			if (D.up) andi_hip_ctx_destroy(D.up);
 			continue;
 		}
+		for (auto *cx : D.sorters) andi_hip_ctx_destroy(cx);
 		for (auto *e : D.slots)
 			if (e) andi_hip_esa_free(D.ctx, e);
 		if (D.d_rows) andi_hip_dev_free(D.ctx, D.d_rows);

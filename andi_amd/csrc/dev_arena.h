@@ -140,10 +140,11 @@ inline void retain(int dev) {
 	++A.contexts;
 }
 
-inline size_t keep_bytes() { // ANDI_ARENA_KEEP: MiB of unused chunks that outlive a device's last context (1: the default, 8192)
+inline size_t keep_bytes() { // ANDI_ARENA_KEEP: MiB of unused chunks that outlive a device's last context; 0: none
+	// (the switch was a boolean once: 1 ... 15 -- "true" in whatever spelling -- mean the default, 8192, not a few MiB)
 	const char *e = andi_knob(KNOB_ARENA_KEEP);
 	const long mb = e ? atol(e) : 8192;
-	return mb == 1 ? (size_t)8192 << 20 : mb > 0 ? (size_t)mb << 20 : (size_t)0;
+	return mb >= 1 && mb < 16 ? (size_t)8192 << 20 : mb > 0 ? (size_t)mb << 20 : (size_t)0;
 }
 
 inline bool has_chunks(int dev) {

@@ -55,3 +55,8 @@ hipError_t andi_launch_pack_symbols_batch(const AndiIndexBatchItem *d_items, uin
 hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st);
 // scan index: deep, side, flags from S and SA alone
 hipError_t andi_launch_index_build(const EsaBuildArgs &a, int single_ext, hipStream_t st);
+// seq_subject_init for a sequence that already lies in device memory (the query pool): RS = revcomp(q) '#' q into a subject's
+// text buffer (the caller zeroes what lies behind 2 len + 1); the number of G and C of every sequence of a pool (calc_gc)
+hipError_t andi_launch_rs_from_query(uint8_t *RS, const uint8_t *q, uint32_t len, hipStream_t st);
+hipError_t andi_launch_gc_counts(const uint8_t *pool, const uint64_t *d_off, const uint32_t *d_len, uint32_t nq, uint32_t longest,
+								 unsigned long long *d_counts, hipStream_t st);

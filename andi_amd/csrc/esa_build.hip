@@ -681,3 +681,73 @@ hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st) {
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
+
+// ------------------------------------------------------------------ subjects from sequences that are already in HBM
+// seq_subject_init (src/sequence.c:210-219) for a sequence that lies in the query pool: RS = revcomp(S) '#' S
+// (catcomp, src/sequence.c:177-190; revcomp, 143-168: A<->T, C<->G, the contig separator '!' becomes ';') written
+// straight into the subject's slot -- what andi_hip_subject_prepare (host_seq.c) makes on the host and the seam used to
+// upload a second time.  One thread per aligned word of RS; the bytes behind the text are the slot's zero padding.
+__global__ __launch_bounds__(256) void k_rs_from_query(uint8_t *__restrict__ RS, const uint8_t *__restrict__ q, uint32_t len) {
+	const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x, o = 4 * w, n = 2 * (uint64_t)len + 1;
+	if (o >= n) return;
+	uint32_t word = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < 4; ++k) {
+		const uint64_t p = o + k;
+		uint32_t c = 0;
+		if (p < len) {
+			c = q[len - 1 - p];
+			c = c < 'A' ? (uint32_t)';' : (c ^ ((c & 2u) ? 4u : 21u));
+		} else if (p == len) {
+			c = '#';
+		} else if (p < n) {
+			c = q[p - len - 1];
+		}
+		word |= c << (8 * k);
+	}
+	((uint32_t *)RS)[w] = word;
+}
+
+// calc_gc's numerator (src/sequence.c:197-208) for every sequence of the pool: counts[q] = number of G and C.  Blocks of 64 KiB
+// of one sequence; 16 bytes per thread and step, one atomic per wavefront.
+#define GC_CHUNK 65536u
+__global__ __launch_bounds__(256) void k_gc_counts(const uint8_t *__restrict__ pool, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+													unsigned long long *__restrict__ counts) {
+	const uint32_t qi = blockIdx.y, L = len[qi];
+	const uint64_t c0 = (uint64_t)blockIdx.x * GC_CHUNK;
+	if (c0 >= L) return;
+	const uint8_t *s = pool + off[qi]; // (256-byte aligned; the pool is zero behind every sequence)
+	const uint64_t c1 = c0 + GC_CHUNK < L ? c0 + GC_CHUNK : L;
+	uint32_t cnt = 0;
+	for (uint64_t p = c0 + 16ull * threadIdx.x; p < c1; p += 16ull * 256) {
+		const uint4 v = *(const uint4 *)(s + p);
+		const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				const uint32_t c = (ws[j] >> (8 * b)) & 0xffu;
+				cnt += (p + 4 * j + b < c1) && ((c & 0xfbu) == 0x43u); // 'C' 0x43, 'G' 0x47
+			}
+	}
+	for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+	if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(&counts[qi], (unsigned long long)cnt);
+}
+
+hipError_t andi_launch_rs_from_query(uint8_t *RS, const uint8_t *q, uint32_t len, hipStream_t st) {
+	const uint64_t words = (2 * (uint64_t)len + 1 + 3) / 4;
+	k_rs_from_query<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(RS, q, len);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_gc_counts(const uint8_t *pool, const uint64_t *d_off, const uint32_t *d_len, uint32_t nq, uint32_t longest,
+								 unsigned long long *d_counts, hipStream_t st) {
+	if (!nq || !longest) return hipSuccess;
+	for (uint32_t q0 = 0; q0 < nq; q0 += 65535u) { // (grid.y is 16 bits)
+		const uint32_t cnt = nq - q0 < 65535u ? nq - q0 : 65535u;
+		k_gc_counts<<<dim3((longest + GC_CHUNK - 1) / GC_CHUNK, cnt), 256, 0, st>>>(pool, d_off + q0, d_len + q0, d_counts + q0);
+		CHECK_LAUNCH();
+	}
+	return hipSuccess;
+}

@@ -86,6 +86,8 @@ SYMBOLS = {
     "andi_hip_pack_symbols": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p]),
     "andi_hip_dist_matrix": (C.c_int, [_P, C.POINTER(Seq), C.c_size_t, C.POINTER(Opts), C.c_char_p, C.c_size_t]),
     "andi_hip_last_gather": (C.c_char_p, []),
+    "andi_hip_row_block": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "andi_hip_copy_ceiling": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "andi_hip_subject_prepare": (C.c_int, [C.c_char_p, C.c_size_t, C.c_double, C.POINTER(_P),
                                             C.POINTER(C.c_size_t), C.POINTER(C.c_double),
                                             C.POINTER(C.c_size_t)]),
@@ -465,6 +467,21 @@ def reload_knobs():
 
 def last_gather():
     return load().andi_hip_last_gather().decode()
+
+
+def row_block(total, parts, k):
+    """the seam's own tiling of the subject rows over `parts` devices (api.hip: row_block): [first, last) of part k"""
+    f, l = C.c_size_t(0), C.c_size_t(0)
+    load().andi_hip_row_block(total, parts, k, C.byref(f), C.byref(l))
+    return int(f.value), int(l.value)
+
+
+def copy_ceiling(ctx, nbytes=1 << 30, reps=5):
+    """GB/s (read + written) of the engine's 16-byte streaming copy kernel over nbytes: the measured ceiling beside the
+    nominal HBM peak (include/andi_hip.h: andi_hip_copy_ceiling)"""
+    g = C.c_double(0.0)
+    ctx._check(load().andi_hip_copy_ceiling(ctx._h, nbytes, reps, C.byref(g)), "copy_ceiling")
+    return float(g.value)
 
 
 def bootstrap(ctx: Context, M, replicates, seed=0):

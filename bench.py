@@ -411,31 +411,39 @@ def main():
     scan_ms = tm["scan_ms"] / launches
     alg_bytes = 2.0 * tm["scan_query_nt"] / launches  # (query lengths differ in the realistic sets: the sum over the scanned pairs)
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    traffic = None
+    traffic, traffic_source = None, None
     prof = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(prof):
         try:
             rec = json.load(open(prof))
             key = "G%d_L%d_seg%d" % (G, args.length, args.segment)
             traffic = rec.get(key, {}).get("hbm_bytes_per_launch")  # rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE
+            if traffic is not None:  # a constant from a counter run of this workload, NOT of this run: say where it is from
+                traffic_source = "profiles/traffic.json: %s (%s) -- rocprofv3 --pmc passes of the same command, corrected as " \
+                                 "MI355X_MICROARCH.md prescribes; a recorded figure, not measured by this run" % (
+                                     rec.get(key, {}).get("source", "counter summary under profiles/"), rec.get(key, {}).get("commit", "commit not recorded"))
         except Exception:
             traffic = None
 
     # measured device-copy ceiling beside the nominal peak: 1 GiB D2D, read + write bytes
+    # (the engine's own 16-byte streaming kernel, HIP events on its stream -- torch's int32 copy_ measured 4.75 TB/s where
+    # the guide's float4 copy does 6.29)
     copy_gbps = None
     if rank == 0:
-        src = torch.empty(1 << 28, dtype=torch.int32, device="cuda")
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbps = 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del src, dst
+        try:
+            copy_gbps = lib.copy_ceiling(ctx, 1 << 30, 5)
+        except Exception:
+            copy_gbps = None
 
+    # N > 1: the roofline of the slowest rank's launches (every rank runs the same kernel on its own rows)
+    frac = achieved / HBM_PEAK_GBPS
+    roofline_ranks = None
+    if use_dist:
+        t = torch.tensor([frac, -frac, scan_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        roofline_ranks = {"frac_best_rank": float(t[0].item()), "frac_worst_rank": -float(t[1].item()), "avg_launch_ms_slowest_rank": float(t[2].item())}
+        frac = roofline_ranks["frac_worst_rank"]
+        achieved = frac * HBM_PEAK_GBPS
     # pass A's kernel: one wavefront per chain (scan_coop.hip) where the call suits it, else one lane per chain
     scan_kernel, routed_fraction = pass_a_of(tm)
     out = None
@@ -451,8 +459,10 @@ def main():
                        "genomes": G, "subjects": S, "length": args.length, "model": MODEL_NAMES[model], "pairs": pairs_total,
                        "segment": args.segment or ("auto (pass A routed per pair: by wavefronts on segments of 32768 ... 524288 symbols (shorter in small calls), by lanes on segments chosen per pair, 2048 ... 16384)" if tm["routed_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "unit": "GB/s", "frac": frac, "traffic": traffic, "traffic_source": traffic_source,
+                         "ranks": roofline_ranks,
                          "measured_copy_GBps": copy_gbps,
+                         "measured_copy_kernel": "andi_hip_copy_ceiling: 16 bytes per lane, non-temporal, 1 GiB, 5 passes, read + written bytes",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_ms,
                          "launches": int(tm["scan_launches"]),
                          "note": "the dominant kernel: pass A alone, HIP events around its launch(es) on the engine's streams; the sampling "
@@ -476,6 +486,15 @@ def main():
         Mcpu, base = cpu_baseline(seqs, p_value, model)
         out["cpu_baseline"] = base
         out["parity_vs_cpu_baseline"] = bool((Mcpu[:S] == full).all())
+    elif rank == 0 and not args.no_cpu_baseline:
+        # N > 1: the baseline is carried forward on a bounded sample -- the first 29 genomes of the set, which ARE the
+        # N = 1 workload (same seed, same base, same divergences: one 29 x 29 tile, what every GPU of the weak-scaling job does);
+        # the other ranks wait at the barrier below.  Its counts check the gathered matrix's corner.
+        tile = min(G, shard.weak_scaling_set_size(1))
+        Mcpu, base = cpu_baseline(seqs[:tile], p_value, model)
+        base["sample"] = "bounded sample at N > 1: the first %d genomes of the set = the N = 1 workload (one tile of the weak-scaling job); %s" % (tile, base["sample"])
+        out["cpu_baseline"] = base
+        out["parity_vs_cpu_baseline"] = bool((Mcpu[:min(S, tile), :tile] == full[:tile, :tile]).all()) if S >= tile else None
     elif rank == 0:
         out["cpu_baseline"] = None
 

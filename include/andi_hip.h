@@ -105,6 +105,10 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
  * takes it back (its own calls serialised by a lock).  A caller with other threads that touch the environment sets
  * NCCL_SOCKET_IFNAME itself beforehand: the library then never writes the environment. */
 const char *andi_hip_last_gather(void);
+/* The seam's tiling of the parallel subject loop (src/dist_hack.h:46-47) over `parts` devices: part k owns the
+ * contiguous rows [*first, *last) of `total`; sizes differ by at most one, the longer blocks come first.  A caller that
+ * runs one process per GPU instead (bench.py --gpus N, andi_amd/shard.py) partitions with the same rule.  No GPU is touched. */
+void andi_hip_row_block(size_t total, size_t parts, size_t k, size_t *first, size_t *last);
 
 /* ------------------------------------------------------------------ */
 /* Host pieces of the path (stay on the host, same libm)               */
@@ -228,6 +232,11 @@ int andi_hip_bootstrap(andi_hip_ctx *ctx, const andi_hip_model *M, size_t n, uin
 int andi_hip_dev_alloc(andi_hip_ctx *ctx, size_t bytes, void **dptr);
 void andi_hip_dev_free(andi_hip_ctx *ctx, void *dptr);
 int andi_hip_copy_to_host(andi_hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* The measured device-copy ceiling the roofline is reported beside: `reps` passes of a 16-bytes-per-lane
+ * streaming copy kernel of the engine's own over `bytes` (source and destination allocated here, non-temporal loads and
+ * stores, grid-stride), timed with HIP events on the context's stream; *gbps = read + written bytes per second / 1e9. */
+int andi_hip_copy_ceiling(andi_hip_ctx *ctx, size_t bytes, int reps, double *gbps);
 
 /* Kernel timing, measured with HIP events on the stream the kernels run on.
  * Accumulates since the last reset; read after andi_hip_sync(). */

@@ -5,6 +5,7 @@ MI355X_MICROARCH.md prescribes for gfx950: wide coalesced streaming reads are co
 stream's bytes (one byte per scanned query nucleotide: two 4-bit texts) are added when the wavefront kernel ran; the
 scattered 8-64 byte probe loads are counted exactly (profiles/micro/r02_fetch_size_calibration.txt)."""
 import json
+import os
 import re
 import sys
 
@@ -40,4 +41,5 @@ print(json.dumps({
              "collected with scripts/pmc.sh on MI355X by scripts/evidence.sh; correction per MI355X_MICROARCH.md (see scripts/traffic.py)",
     key: {"hbm_bytes_per_launch": raw + stream / 2.0, "raw_bytes": raw, "kernel": kernel,
           "source": "%s: FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB (%s)" % (kept_as, fetch, write, " + ".join(seen)),
+          "commit": os.environ.get("ANDI_COMMIT", "commit not recorded"),  # (the GPU box has no .git: the caller passes `git rev-parse --short HEAD`)
           "correction": "+ half of the coalesced window stream (%.2f GB per launch)" % (stream / 1e9) if stream else "none"}}, indent=1))
