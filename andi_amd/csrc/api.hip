@@ -1646,6 +1646,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 			t.stop();
 			if (e != hipSuccess) return fail(ctx, "scan layout", e);
 		}
+		give_pool_scratch(a); // (a call whose pass A is the wavefront kernel's for every pair: ANDI_COOP=n, tiny calls)
 		{
 			Timed t(ctx, 1);
 			hipError_t e = andi_launch_scan_cold(a, ctx->stream);
@@ -2081,6 +2082,8 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		// each with a stream and a workspace of its own, so one subject's small launches and waits hide behind another's
 		// radix passes.
 		size_t sort_width = dev_prep && !o.low_memory ? std::min<size_t>(4, std::min(batch_max, last[d] - first[d])) : 1;
+		if (const char *sw = andi_knob(KNOB_SORT_WIDTH)) // (experiments)
+			if (atoi(sw) >= 1 && atoi(sw) <= 8) sort_width = std::min<size_t>((size_t)atoi(sw), std::min(batch_max, last[d] - first[d]));
 		if (andi_sa_device_workspace((int32_t)rs_cap) * sort_width > ((size_t)24 << 30)) sort_width = 1; // (45 bytes per character each)
 		for (size_t w = 1; w < sort_width; ++w) {
 			andi_hip_ctx *cx = nullptr;
@@ -2362,6 +2365,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		delete p;
 	}
 	int rc = abort_flag ? 1 : 0;
+	const double t_drivers_done = now_ms();
 
 	// ---- the gather: row blocks to the first device over RCCL, one copy to the host
 	snprintf(g_last_gather, sizeof g_last_gather, "%s", use_rccl ? "rccl" : "direct");
@@ -2434,6 +2438,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		}
 	}
 	if (rc) set_err(errbuf, errlen, "%s", first_error.empty() ? "andi_hip_dist_matrix failed" : first_error.c_str());
+	const double t_gathered = now_ms();
 
 	for (auto &D : dv) {
 		if (!D.ctx) {
@@ -2454,7 +2459,7 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		if (D.up) andi_hip_ctx_destroy(D.up);
 		andi_hip_ctx_destroy(D.ctx);
 	}
-	if (trace) fprintf(stderr, "andi_hip_dist_matrix trace: call total %.1f ms\n", now_ms() - t_call);
+	if (trace) fprintf(stderr, "andi_hip_dist_matrix trace: call total %.1f ms (gather %.1f, slots, queries and contexts released %.1f)\n", now_ms() - t_call, t_gathered - t_drivers_done, now_ms() - t_gathered);
 	return rc;
 }
 

@@ -158,6 +158,7 @@ hipError_t andi_launch_lane_cold(const ScanArgs &a, hipStream_t st);
 // pass A with one wavefront per chain (scan_coop.hip)
 int andi_coop_enabled(void); // 0: off (ANDI_COOP=0); < 0: the engine chooses -- tiny calls every pair, others routed per pair (the default); n = 2, 4, 8: every pair, windows of 2048 n symbols
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st);
+int andi_coop_wants_pool(const ScanArgs &a); // a launch of pass A by wavefronts that k_pool_cold would take if the context had its scratch
 int andi_coop_will_pool(const ScanArgs &a); // that launch is k_pool_cold's (coop_pool.h), not k_coop_cold's
 size_t andi_pool_scratch_bytes(int device, uint32_t *waves); // the pooled kernels' scratch (4096 bytes for the ticket in front); 0: those kernels are off (ANDI_POOL=0)
 hipError_t andi_launch_lane_stitch(const ScanArgs &a, hipStream_t st);

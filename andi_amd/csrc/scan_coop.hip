@@ -1148,9 +1148,15 @@ size_t andi_pool_scratch_bytes(int device, uint32_t *waves) {
 	return 4096 + (size_t)*waves * pool_scratch_bytes(POOL_FUSED_CHUNKS, POOL_FUSED_HC);
 }
 
-int andi_coop_will_pool(const ScanArgs &a) {
+// the pooled kernel would take this launch if it had its scratch (items and ticket are 32 bits: coop_pool.h)
+int andi_coop_wants_pool(const ScanArgs &a) {
 	const int nch = andi_coop_enabled();
-	return !a.exact_equal && a.pool_scratch && a.pool_waves && pool_enabled() && (nch < 0 || nch == 4) && a.seg >= 32768 && (!a.route || a.pool_use);
+	return a.coop && !a.exact_equal && pool_enabled() && (nch < 0 || nch == 4) && a.seg >= 32768 && (!a.route || a.pool_use) &&
+		   (uint64_t)a.total_segs * a.nsub < (1ull << 32);
+}
+
+int andi_coop_will_pool(const ScanArgs &a) {
+	return andi_coop_wants_pool(a) && a.pool_scratch && a.pool_waves;
 }
 
 hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one segment length for the call, RAW/JC/Kimura

@@ -9,8 +9,11 @@
 #include <err.h>
 #include <ctype.h>
 #include <errno.h>
+#include <fcntl.h>
 #include <getopt.h>
 #include <limits.h>
+#include <pthread.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -57,47 +60,101 @@ static void push_genome(genome_list *l, genome g) {
 	l->v[l->n++] = g;
 }
 
-/* normalize, src/sequence.c:260-282: keep ACGT and '!', upper-case acgt, drop the rest */
-static size_t normalize(char *s) {
+/* What reading ONE input file produced.  The files are read by a pool of threads (3085 assemblies, 6.5 GB: BASELINE's
+ * config 3 -- SURVEY.md 8 f2 names ingest as the next wall-clock term); the main thread takes the results in the order of
+ * the command line, so sequences, messages and flags come out as if the files had been read one after the other. */
+typedef struct {
+	genome_list seqs;
+	char *msgs; /* the lines warnx()/warn() would have printed, in order */
+	size_t mlen, mcap;
+	int soft, non_acgt;
+} file_result;
+
+static void fmsg(file_result *r, int with_errno, const char *fmt, ...) {
+	char line[4096];
+	const int saved = errno;
+	int k = snprintf(line, sizeof line, "%s: ", program_invocation_short_name);
+	va_list ap;
+	va_start(ap, fmt);
+	k += vsnprintf(line + k, sizeof line - (size_t)k - 2, fmt, ap);
+	va_end(ap);
+	if (k > (int)sizeof line - 2) k = (int)sizeof line - 2;
+	if (with_errno) k += snprintf(line + k, sizeof line - (size_t)k - 1, ": %s", strerror(saved));
+	if (k > (int)sizeof line - 2) k = (int)sizeof line - 2;
+	line[k++] = '\n';
+	if (r->mlen + (size_t)k + 1 > r->mcap) {
+		r->mcap = 2 * r->mcap + (size_t)k + 256;
+		r->msgs = realloc(r->msgs, r->mcap);
+		if (!r->msgs) err(errno, "Out of memory");
+	}
+	memcpy(r->msgs + r->mlen, line, (size_t)k);
+	r->mlen += (size_t)k;
+	r->msgs[r->mlen] = '\0';
+}
+#define file_soft_warnx(r, ...)                                                                    \
+	do {                                                                                           \
+		(r)->soft = 1;                                                                             \
+		fmsg((r), 0, __VA_ARGS__);                                                                 \
+	} while (0)
+
+/* normalize, src/sequence.c:260-282: keep ACGT and '!', upper-case acgt, drop the rest (by table: a byte maps to itself,
+ * to its upper case, or to 0 = dropped) */
+static unsigned char norm_table[256];
+static void norm_table_init(void) {
+	const char *keep = "ACGT!";
+	for (const char *k = keep; *k; k++) norm_table[(unsigned char)*k] = (unsigned char)*k;
+	norm_table['a'] = 'A', norm_table['c'] = 'C', norm_table['g'] = 'G', norm_table['t'] = 'T';
+}
+static size_t normalize(char *s, size_t len, int *dropped) {
 	char *w = s;
-	for (const char *r = s; *r; r++) {
-		switch (*r) {
-			case 'A': case 'C': case 'G': case 'T': case '!': *w++ = *r; break;
-			case 'a': *w++ = 'A'; break;
-			case 'c': *w++ = 'C'; break;
-			case 'g': *w++ = 'G'; break;
-			case 't': *w++ = 'T'; break;
-			default: saw_non_acgt = 1; break;
-		}
+	int lost = 0;
+	for (size_t i = 0; i < len; i++) {
+		const unsigned char c = norm_table[(unsigned char)s[i]];
+		*w = (char)c;
+		w += c != 0;
+		lost |= c == 0;
 	}
 	*w = '\0';
+	if (lost) *dropped = 1;
 	return (size_t)(w - s);
 }
 
-static char *slurp(const char *file_name, size_t *len_out) {
-	FILE *f = strcmp(file_name, "-") ? fopen(file_name, "r") : stdin;
-	if (!f) return NULL;
-	size_t cap = 1 << 16, len = 0;
-	char *buf = xmalloc(cap + 1);
+/* a reader thread's buffer, reused from file to file (read(), not a fresh allocation per file) */
+typedef struct {
+	char *buf;
+	size_t cap;
+} read_buffer;
+
+static char *slurp(const char *file_name, size_t *len_out, read_buffer *rb) {
+	const int fd = strcmp(file_name, "-") ? open(file_name, O_RDONLY) : STDIN_FILENO;
+	if (fd < 0) return NULL;
+	if (!rb->buf) rb->cap = (size_t)4 << 20, rb->buf = xmalloc(rb->cap + 1);
+	size_t len = 0;
+	int bad = 0;
 	for (;;) {
-		size_t got = fread(buf + len, 1, cap - len, f);
-		len += got;
-		if (got == 0) break;
-		if (len == cap) {
-			cap *= 2;
-			buf = realloc(buf, cap + 1);
-			if (!buf) err(errno, "Out of memory");
+		if (len == rb->cap) {
+			rb->cap *= 2;
+			rb->buf = realloc(rb->buf, rb->cap + 1);
+			if (!rb->buf) err(errno, "Out of memory");
 		}
+		const ssize_t got = read(fd, rb->buf + len, rb->cap - len);
+		if (got < 0) {
+			if (errno == EINTR) continue;
+			bad = 1;
+			break;
+		}
+		if (got == 0) break;
+		len += (size_t)got;
 	}
-	int bad = ferror(f);
-	if (f != stdin) fclose(f);
+	const int saved = errno;
+	if (fd != STDIN_FILENO) close(fd);
 	if (bad) {
-		free(buf);
+		errno = saved;
 		return NULL;
 	}
-	buf[len] = '\0';
+	rb->buf[len] = '\0';
 	*len_out = len;
-	return buf;
+	return rb->buf;
 }
 
 /* read_fasta, src/io.c:196-233: every record of the file becomes one sequence.  The record grammar and the
@@ -106,79 +163,90 @@ static char *slurp(const char *file_name, size_t *len_out) {
  * with a letter, '-' or '*', across blank lines and blanks inside lines, CR LF or LF; anything else must be the
  * next record's '>'.  A malformed record ends the file with a message (records read before it are kept). */
 #define IS_SPACE(c) (((c) >= '\t' && (c) <= '\r') || (c) == ' ')
-static void read_fasta(const char *file_name, genome_list *out) {
+static void read_fasta(const char *file_name, file_result *res, read_buffer *rb) {
+	genome_list *out = &res->seqs;
 	size_t len = 0;
-	char *text = slurp(file_name, &len);
+	char *text = slurp(file_name, &len, rb);
 	if (!text) {
-		soft_error = 1;
-		warn("%s", file_name);
+		res->soft = 1;
+		fmsg(res, 1, "%s", file_name);
 		return;
 	}
 	if (len == 0) {
-		soft_warnx("%s: File is empty.", file_name);
-		free(text);
+		file_soft_warnx(res, "%s: File is empty.", file_name);
 		return;
 	}
 	if (text[0] != '>') {
-		soft_warnx("%s: File must start with '>'.", file_name);
-		free(text);
+		file_soft_warnx(res, "%s: File must start with '>'.", file_name);
 		return;
 	}
 	char *p = text, *end = text + len;
 	size_t line = 1;
 	while (p < end) {
 		if (*p != '>') {
-			soft_warnx("%s: Expected '>' but found '%c' on line %zu.", file_name, *p, line);
+			file_soft_warnx(res, "%s: Expected '>' but found '%c' on line %zu.", file_name, *p, line);
 			break;
 		}
 		/* name */
 		char *h = ++p;
 		while (p < end && !IS_SPACE(*p)) p++;
 		if (p == end) {
-			soft_warnx("%s: Unexpected EOF in name on line %zu.", file_name, line);
+			file_soft_warnx(res, "%s: Unexpected EOF in name on line %zu.", file_name, line);
 			break;
 		}
 		if (p == h) {
-			soft_warnx("%s: Empty name on line %zu.", file_name, line);
+			file_soft_warnx(res, "%s: Empty name on line %zu.", file_name, line);
 			break;
 		}
 		char *name_end = p;
 		/* comment: the rest of the line */
-		while (p < end && *p != '\n') p++;
-		if (p == end) {
-			soft_warnx("%s: Unexpected EOF in comment on line %zu.", file_name, line);
+		p = memchr(p, '\n', (size_t)(end - p));
+		if (!p) {
+			file_soft_warnx(res, "%s: Unexpected EOF in comment on line %zu.", file_name, line);
 			break;
 		}
-		/* sequence */
+		/* sequence: first where it ends (the next line that starts with something else), then one copy of its words */
 		while (p < end && IS_SPACE(*p)) line += *p++ == '\n';
-		genome g;
-		g.seq = xmalloc((size_t)(end - p) + 1);
+		char *s0 = p;
 		size_t n = 0;
 		while (p < end && (isalpha((unsigned char)*p) || *p == '-' || *p == '*')) {
-			while (p < end && !IS_SPACE(*p)) g.seq[n++] = *p++;
+			char *w = p;
+			while (p < end && !IS_SPACE(*p)) p++;
+			n += (size_t)(p - w);
 			while (p < end && IS_SPACE(*p)) line += *p++ == '\n';
 		}
 		if (n == 0) {
-			soft_warnx("%s: Empty sequence on line %zu.", file_name, line);
-			free(g.seq);
+			file_soft_warnx(res, "%s: Empty sequence on line %zu.", file_name, line);
 			break;
 		}
-		g.seq[n] = '\0';
+		genome g;
+		g.seq = xmalloc(n + 1);
+		size_t k = 0;
+		for (char *q = s0; q < p;) { /* the words again: copied, then normalised in place */
+			char *w = q;
+			while (q < p && !IS_SPACE(*q)) q++;
+			memcpy(g.seq + k, w, (size_t)(q - w));
+			k += (size_t)(q - w);
+			while (q < p && IS_SPACE(*q)) q++;
+		}
 		g.name = strndup(h, (size_t)(name_end - h));
 		if (!g.name) err(errno, "Out of memory");
-		g.len = normalize(g.seq);
-		char *fit = realloc(g.seq, g.len + 1);
-		if (fit) g.seq = fit;
+		g.len = normalize(g.seq, n, &res->non_acgt);
+		if (g.len + 4096 < n) { /* (much was dropped: give the memory back) */
+			char *fit = realloc(g.seq, g.len + 1);
+			if (fit) g.seq = fit;
+		}
 		push_genome(out, g);
 	}
-	free(text);
 }
 
 /* read_fasta_join + dsa_join, src/io.c:159-194, src/sequence.c:78-125: all records of
  * a file joined by '!', named after the file without directory and extension */
-static void read_fasta_join(const char *file_name, genome_list *out) {
-	genome_list single = {0};
-	read_fasta(file_name, &single);
+static void read_fasta_join(const char *file_name, file_result *res, read_buffer *rb) {
+	file_result one = {0};
+	read_fasta(file_name, &one, rb);
+	res->msgs = one.msgs, res->mlen = one.mlen, res->mcap = one.mcap, res->soft = one.soft, res->non_acgt = one.non_acgt;
+	genome_list single = one.seqs;
 	if (single.n == 0) return;
 	size_t total = 0;
 	for (size_t i = 0; i < single.n; i++) total += single.v[i].len + 1;
@@ -197,12 +265,60 @@ static void read_fasta_join(const char *file_name, genome_list *out) {
 	const char *dot = strchrnul(left, '.');
 	g.name = strndup(left, (size_t)(dot - left));
 	if (!g.name) err(errno, "Out of memory");
-	push_genome(out, g);
+	push_genome(&res->seqs, g);
 	for (size_t i = 0; i < single.n; i++) {
 		free(single.v[i].name);
 		free(single.v[i].seq);
 	}
 	free(single.v);
+}
+
+/* the input files, read by up to `threads` threads (each takes the next unread file); results in command-line order */
+typedef struct {
+	char **files;
+	size_t nfiles;
+	int join;
+	file_result *results;
+	size_t next; /* atomic */
+} read_job;
+
+static void *read_worker(void *arg) {
+	read_job *job = arg;
+	read_buffer rb = {0};
+	for (;;) {
+		const size_t i = __atomic_fetch_add(&job->next, 1, __ATOMIC_RELAXED);
+		if (i >= job->nfiles) break;
+		if (job->join) read_fasta_join(job->files[i], &job->results[i], &rb);
+		else read_fasta(job->files[i], &job->results[i], &rb);
+	}
+	free(rb.buf);
+	return NULL;
+}
+
+static void read_all_files(char **files, size_t nfiles, int join, int threads, genome_list *all) {
+	norm_table_init();
+	read_job job = {files, nfiles, join, calloc(nfiles ? nfiles : 1, sizeof(file_result)), 0};
+	if (!job.results) err(errno, "Out of memory");
+	size_t nt = threads > 0 ? (size_t)threads : 1;
+	if (nt > nfiles) nt = nfiles;
+	if (nt > 64) nt = 64; /* (the files come from one file system: more readers do not make it faster) */
+	pthread_t *tid = xmalloc(nt * sizeof *tid);
+	size_t started = 0;
+	for (size_t t = 1; t < nt; t++)
+		if (pthread_create(&tid[started], NULL, read_worker, &job) == 0) started++;
+	read_worker(&job);
+	for (size_t t = 0; t < started; t++) pthread_join(tid[t], NULL);
+	free(tid);
+	for (size_t i = 0; i < nfiles; i++) {
+		file_result *r = &job.results[i];
+		if (r->msgs) fputs(r->msgs, stderr);
+		free(r->msgs);
+		soft_error |= r->soft;
+		saw_non_acgt |= r->non_acgt;
+		for (size_t k = 0; k < r->seqs.n; k++) push_genome(all, r->seqs.v[k]);
+		free(r->seqs.v);
+	}
+	free(job.results);
 }
 
 /* read_into_string_vector, src/io.c:103-144 */
@@ -276,15 +392,17 @@ static void print_matrix(const andi_hip_model *M, const genome *g, size_t n, int
 						 int truncate, int warnings) {
 	const char **names = xmalloc(n * sizeof *names);
 	for (size_t i = 0; i < n; i++) names[i] = g[i].name;
-	size_t cap = 64 + n * (300 + 16 * n), wcap = 4096 + n * n * 512;
+	/* the warnings' buffer grows on demand (a line per pair at worst -- n^2 x 512 bytes up front would be 4.9 GB for
+	 * BASELINE's 3085 genomes): a buffer that came back full is doubled and the call repeated */
+	size_t cap = 64 + n * (300 + 16 * n), wcap = (size_t)1 << 16;
 	char *out = xmalloc(cap), *wbuf = xmalloc(wcap);
 	int flags = 0;
-	size_t need = andi_hip_format_distances(M, names, n, model, vv, truncate, warnings, out, cap, wbuf, wcap, &flags);
-	if (need >= cap) { /* long names: the call says how much it needs */
-		free(out);
-		cap = need + 1;
-		out = xmalloc(cap);
-		andi_hip_format_distances(M, names, n, model, vv, truncate, warnings, out, cap, wbuf, wcap, &flags);
+	for (;;) {
+		const size_t need = andi_hip_format_distances(M, names, n, model, vv, truncate, warnings, out, cap, wbuf, wcap, &flags);
+		const int out_short = need >= cap, warn_short = strlen(wbuf) + 1 >= wcap; /* (long names: the call says how much it needs) */
+		if (!out_short && !warn_short) break;
+		if (out_short) free(out), cap = need + 1, out = xmalloc(cap);
+		if (warn_short) free(wbuf), wcap *= 4, wbuf = xmalloc(wcap);
 	}
 	for (char *line = strtok(wbuf, "\n"); line; line = strtok(NULL, "\n")) soft_warnx("%s", line);
 	fputs(out, stdout);
@@ -414,11 +532,13 @@ int main(int argc, char *argv[]) {
 		files[nfiles++] = strdup("-");
 	}
 
+	/* ANDI_HIP_CLI_TRACE=1: where the wall time goes -- reading the input, the matrix, printing it (stderr; scripts/full_size.py --cli) */
+	const int cli_trace = getenv("ANDI_HIP_CLI_TRACE") != NULL;
+	struct timespec ts0, ts1, ts2, ts3;
+	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	genome_list all = {0};
-	for (size_t i = 0; i < nfiles; i++) {
-		if (join) read_fasta_join(files[i], &all);
-		else read_fasta(files[i], &all);
-	}
+	read_all_files(files, nfiles, join, opts.host_threads, &all);
+	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	const size_t n = all.n;
 	if (n < 2)
 		errx(1, "I am truly sorry, but with less than two sequences (%zu given) there is nothing to compare.", n);
@@ -459,8 +579,18 @@ int main(int argc, char *argv[]) {
 	char msg[512];
 	if (andi_hip_dist_matrix(M, in, n, &opts, msg, sizeof msg)) errx(1, "%s", msg);
 	if (progress == P_ALWAYS) fprintf(stderr, ", done.\n");
+	clock_gettime(CLOCK_MONOTONIC, &ts2);
 
 	print_matrix(M, all.v, n, opts.model, verbose >= 2, truncate, 1);
+	if (cli_trace) {
+		fflush(stdout);
+		clock_gettime(CLOCK_MONOTONIC, &ts3);
+#define SECS(a, b) ((double)((b).tv_sec - (a).tv_sec) + 1e-9 * (double)((b).tv_nsec - (a).tv_nsec))
+		size_t nt_total = 0;
+		for (size_t i = 0; i < n; i++) nt_total += all.v[i].len;
+		fprintf(stderr, "andi-hip trace: %zu sequences, %zu nucleotides from %zu files: ingest %.3f s, matrix %.3f s, print %.3f s\n", n, nt_total,
+				nfiles, SECS(ts0, ts1), SECS(ts1, ts2), SECS(ts2, ts3));
+	}
 	if (verbose) { /* print_coverages, src/io.c:329-338 */
 		printf("\nCoverage:\n");
 		for (size_t i = 0; i < n; i++) {

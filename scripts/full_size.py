@@ -46,6 +46,93 @@ def fast_set(n, length, d_lo, d_hi, seed, threads):
         return list(pool.map(one, range(n))), [float(x) for x in ds]
 
 
+def cli_run(args, seqs, G, L, model, model_name, cores):
+    """BASELINE's job as a user runs it: FASTA files in, PHYLIP matrix out (src/andi.c:63-394, src/io.c:159-322)."""
+    import shutil
+    import subprocess
+    import andi_amd
+    from concurrent.futures import ThreadPoolExecutor
+    total = sum(len(s) for s in seqs)
+    d = args.dir
+    if not d:
+        for cand in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")):
+            try:
+                if shutil.disk_usage(cand).free > 1.3 * total + (2 << 30):
+                    d = cand
+                    break
+            except OSError:
+                pass
+    if not d:
+        sys.exit("full_size.py --cli: no directory with room for %.1f GB of FASTA" % (total / 1e9))
+    d = os.path.join(d, "andi_cli_%d" % os.getpid())
+    os.makedirs(d, exist_ok=True)
+    names = ["g%04d" % k for k in range(G)]
+
+    def write(k):
+        s, path = seqs[k], os.path.join(d, names[k] + ".fasta")
+        parts = [s]
+        if args.contigs > 1:
+            cut = sorted(set(int(x) for x in np.linspace(0, len(s), args.contigs + 1)))
+            parts = [s[a:b] for a, b in zip(cut[:-1], cut[1:])]
+        with open(path, "wb") as f:
+            for c, part in enumerate(parts):
+                f.write((">%s_%d some comment\n" % (names[k], c) if args.contigs > 1 else ">%s\n" % names[k]).encode())
+                a = np.frombuffer(part, np.uint8)
+                full = len(a) // 70 * 70
+                lines = np.empty((full // 70, 71), np.uint8)
+                lines[:, :70] = a[:full].reshape(-1, 70)
+                lines[:, 70] = 10
+                f.write(lines.tobytes())
+                if full < len(a):
+                    f.write(a[full:].tobytes() + b"\n")
+        return path
+    t0 = time.time()
+    with ThreadPoolExecutor(min(cores, 32)) as pool:
+        paths = list(pool.map(write, range(G)))
+    t_write = time.time() - t0
+    fof = os.path.join(d, "files.txt")
+    with open(fof, "w") as f:
+        f.write("\n".join(paths) + "\n")
+    exe = os.path.join(ROOT, "andi_amd", "andi-hip")
+    cmd = [exe, "--file-of-filenames", fof, "-m", model_name] + (["-j"] if args.contigs > 1 else [])
+    out_path = os.path.join(d, "matrix.phy")
+    try:
+        t0 = time.time()
+        with open(out_path, "wb") as fo:
+            r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=dict(os.environ, ANDI_HIP_CLI_TRACE="1"), timeout=3000)
+        wall = time.time() - t0
+        err = r.stderr.decode(errors="replace")
+        tr = [ln for ln in err.splitlines() if "andi-hip trace" in ln]
+        import re
+        m = re.search(r"ingest ([0-9.]+) s, matrix ([0-9.]+) s, print ([0-9.]+) s", tr[-1]) if tr else None
+        ingest, matrix, prnt = (float(x) for x in m.groups()) if m else (None, None, None)
+        printed = open(out_path, "rb").read().decode()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    # the same matrix through the seam, printed by the library's own formatter
+    joined = [b"!".join(s[a:b] for a, b in zip(cut[:-1], cut[1:])) for s in seqs for cut in [sorted(set(int(x) for x in np.linspace(0, len(s), args.contigs + 1)))]] if args.contigs > 1 else seqs
+    t0 = time.time()
+    M = andi_amd.dist_matrix(joined, model=model)
+    t_seam = time.time() - t0
+    text, _, _ = andi_amd.format_distances(M, names, model)
+    pairs = G * (G - 1)
+    out = {
+        "config": "%s-synth through the command line: %d FASTA files (%d nt each, 70-column lines%s), andi-hip --file-of-filenames -m %s%s, one GPU"
+                  % (args.config.upper(), G, L, ", %d records per file" % args.contigs if args.contigs > 1 else "", model_name, " -j" if args.contigs > 1 else ""),
+        "fasta_bytes": int(total + total // 70 + 16 * G), "files_written_s": t_write, "exit_code": r.returncode,
+        "cli_wall_s": wall, "ingest_s": ingest, "matrix_s": matrix, "print_s": prnt,
+        "ingest_plus_print_fraction_of_wall": (ingest + prnt) / wall if m else None,
+        "pairs_per_s_cli_wall": pairs / wall, "seam_alone_s": t_seam,
+        "output_bytes": len(printed), "output_equals_format_distances_of_the_seam_matrix": printed == text,
+        "stderr_tail": err.splitlines()[-3:],
+    }
+    path = args.out or os.path.join(ROOT, "gpurun_out", "r07_cli_%s.json" % args.config)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("config", choices=("c3", "c4", "c5"))
@@ -56,6 +143,12 @@ def main():
     ap.add_argument("--bootstrap", type=int, default=99)
     ap.add_argument("--low-memory", action="store_true")
     ap.add_argument("--out", default="")
+    ap.add_argument("--cli", action="store_true",
+                    help="the same job through the command line: the genomes as FASTA files (one per genome, 70-column lines) in --dir, "
+                         "`andi-hip --file-of-filenames` on them, ingest / matrix / print seconds (ANDI_HIP_CLI_TRACE), the printed matrix "
+                         "against andi_hip_format_distances of the seam's own matrix")
+    ap.add_argument("--contigs", type=int, default=0, help="--cli: every genome as that many records, joined again by -j (C4's assemblies)")
+    ap.add_argument("--dir", default="", help="--cli: where the FASTA files go (default: /dev/shm if it has room, else $TMPDIR)")
     args = ap.parse_args()
     if args.config == "c3":
         G, L, dlo, dhi, model_name = args.genomes or 109, args.length or 5_100_000, 1e-4, 5e-3, "Kimura"
@@ -73,6 +166,8 @@ def main():
     seqs, ds = fast_set(G, L, dlo, dhi, 1729, min(cores, 64))
     t_gen = time.time() - t0
     model = andi_amd.M_KIMURA if model_name == "Kimura" else andi_amd.M_JC
+    if args.cli:
+        return cli_run(args, seqs, G, L, model, model_name, cores)
 
     # the library's trace goes to the C stderr: capture it through a file
     os.environ["ANDI_E2E_TRACE"] = "1"

@@ -255,3 +255,60 @@ def test_host_packer_equals_the_alphabet_table():
         want = (code[a[0::2]] & 7) | ((code[a[1::2]] & 7) << 4)
         assert (got == want).all(), seq[:40]
         assert bad == any(c not in inside for c in seq), seq[:40]
+
+
+def test_format_distances_row_parallel_equals_the_sequential_loop(orc):
+    """andi_hip_format_distances deals the rows of a large matrix to a pool of threads (host_model.c): for n = 300 -- several
+    threads at work -- the bytes equal print_distances' sequential loop (src/io.c:246-322) restated here from the estimators:
+    averaging rule, the scientific switch taken for the WHOLE matrix from one small distance, NaN and low-homology warnings in
+    row order, -vv (no averaging), truncated names."""
+    import numpy as np
+    from andi_amd import lib
+    rng = np.random.default_rng(300)
+    n = 300
+    M = rng.integers(0, 900, size=(n, n, 17), dtype=np.uint32)
+    M[:, :, [0, 5, 10, 15]] += 30000
+    M[:, :, 16] = 140000
+    M[17, 230, :16] = M[230, 17, :16] = 0            # nan
+    M[5, 9, :16] //= 200                             # low coverage in one direction
+    M[250, 299, :16] //= 300
+    names = ["g%03d_%s" % (k, "x" * (k % 14)) for k in range(n)]
+
+    def sequential(M, model, vv, trunc, small):
+        M = M.copy()
+        if small:  # one distance in (0, 0.001): every number of the matrix in scientific notation (src/io.c:280-283)
+            M[1, 2, :16] = M[2, 1, :16] = 0
+            M[1, 2, [0, 5, 10, 15]] = M[2, 1, [0, 5, 10, 15]] = 50000
+            M[1, 2, 1] = 3
+        D = np.zeros((n, n))
+        warn = []
+        for i in range(n):
+            for j in range(n):
+                datum = M[i, j] if vv else (M[i, j].astype(np.uint64) + M[j, i]).astype(np.uint32)
+                d = D[i, j] = 0.0 if i == j else orc.estimate(datum, model)
+                if np.isnan(d):
+                    warn.append("For the two sequences '%s' and '%s' the distance computation failed and is reported as nan. "
+                                "Please refer to the documentation for further details.\n" % (names[i], names[j]))
+                elif i < j:
+                    c1, c2 = orc.coverage(M[i, j]), orc.coverage(M[j, i])
+                    if c1 < 0.2 or c2 < 0.2:
+                        warn.append("For the two sequences '%s' and '%s' very little homology was found (%f and %f, respectively).\n"
+                                    % (names[i], names[j], c1, c2))
+        sci = bool(((D > 0) & (D < 0.001)).any())
+        import ctypes
+        libc, buf = ctypes.CDLL(None), ctypes.create_string_buffer(64)
+
+        def c_printf(fmt, d):  # the C library's conversion (a NaN prints with its sign: "-nan")
+            libc.snprintf(buf, 64, fmt, ctypes.c_double(d))
+            return buf.value.decode()
+        rows = ["%d\n" % n]
+        for i in range(n):
+            rows.append(("%-10.10s" if trunc else "%-10s") % names[i] + "".join(c_printf(b" %1.4e" if sci else b" %1.4f", D[i, j]) for j in range(n)) + "\n")
+        return M, "".join(rows), "".join(warn)
+
+    for model, vv, trunc, small in ((lib.M_JC, False, False, False), (lib.M_KIMURA, True, True, True), (lib.M_RAW, False, False, True)):
+        M1, text, warn = sequential(M, model, vv, trunc, small)
+        got_text, got_warn, flags = lib.format_distances(M1, names, model, extra_verbose=vv, truncate_names=trunc)
+        assert got_text == text and got_warn == warn
+        assert flags == (1 if "reported as nan" in warn else 0) | (2 if "very little homology" in warn else 0)
+        assert ("e-0" in text.splitlines()[1]) == small
