@@ -342,6 +342,12 @@ struct State {
 	std::vector<IdleStream> streams;
 	std::vector<IdlePinned> pinned;
 	std::vector<IdleScratch> scratch;
+	// small pinned blocks (flags and counters the kernels write and the host reads: 16 ... 256 bytes each) out of slabs of
+	// 64 KiB: a context and its subjects took two dozen hipHostMalloc / hipHostFree of a few words per call of the seam,
+	// 5 of a warm call's 36 ms
+	std::vector<char *> slabs;
+	std::vector<void *> free_words;
+	size_t words_out = 0;
 };
 static State &state() {
 	static State *s = new State;
@@ -396,6 +402,32 @@ static void pinned_put(void *p, size_t bytes) {
 	}
 	(void)hipHostFree(p);
 }
+constexpr size_t WORD_BYTES = 256, SLAB_BYTES = 65536;
+static void *word_get() { // 256 zeroed bytes of pinned host memory (device-visible: unified addressing), 256-byte aligned
+	std::lock_guard<std::mutex> lk(mu);
+	State &S = state();
+	if (S.free_words.empty()) {
+		char *slab = nullptr;
+		if (hipHostMalloc((void **)&slab, SLAB_BYTES, hipHostMallocDefault) != hipSuccess) {
+			(void)hipGetLastError();
+			return nullptr;
+		}
+		S.slabs.push_back(slab);
+		for (size_t o = SLAB_BYTES; o >= WORD_BYTES; o -= WORD_BYTES) S.free_words.push_back(slab + o - WORD_BYTES);
+	}
+	void *p = S.free_words.back();
+	S.free_words.pop_back();
+	++S.words_out;
+	memset(p, 0, WORD_BYTES);
+	return p;
+}
+static void word_put(void *p) {
+	if (!p) return;
+	std::lock_guard<std::mutex> lk(mu);
+	state().free_words.push_back(p);
+	--state().words_out;
+}
+
 // the pooled wavefront kernel's scratch: one per device is kept from context to context (a context of the seam lives for one
 // call: 0.8 GB of hipMalloc + hipFree per call and device otherwise); andi_hip_trim returns it
 static void *scratch_get(int device, size_t bytes) {
@@ -432,7 +464,7 @@ static void scratch_put(int device, void *p, size_t bytes) { // (idle: the calle
 }
 static bool any() {
 	std::lock_guard<std::mutex> lk(mu);
-	return !streams.empty() || !pinned.empty() || !state().scratch.empty();
+	return !streams.empty() || !pinned.empty() || !state().scratch.empty() || !state().slabs.empty();
 }
 static size_t trim() { // (the caller restores the current device); returns the device bytes given back
 	std::vector<IdleStream> st;
@@ -441,6 +473,10 @@ static size_t trim() { // (the caller restores the current device); returns the 
 	{
 		std::lock_guard<std::mutex> lk(mu);
 		st.swap(streams), pb.swap(pinned), sc.swap(state().scratch);
+		if (state().words_out == 0) { // (slabs with blocks still out stay)
+			for (char *slab : state().slabs) pb.push_back({slab, SLAB_BYTES});
+			state().slabs.clear(), state().free_words.clear();
+		}
 	}
 	for (const IdleStream &x : st)
 		if (hipSetDevice(x.device) == hipSuccess) (void)hipStreamDestroy(x.s);
@@ -530,12 +566,12 @@ static int ctx_create(andi_hip_ctx **out, int device, char *errbuf, size_t errle
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->built, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fixups, sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_fixups, 0, sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_quad_waves, sizeof(uint32_t), hipHostMallocDefault);
+	if (e == hipSuccess && !(ctx->h_quad_waves = (uint32_t *)host_pool::word_get())) e = hipErrorOutOfMemory;
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->coop_join, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->l2_join, hipEventDisableTiming);
-	if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_any_left, 20 * sizeof(uint32_t), hipHostMallocDefault);
+	if (e == hipSuccess && !(ctx->h_any_left = (uint32_t *)host_pool::word_get())) e = hipErrorOutOfMemory;
 	if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_route, 4 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMemset(ctx->d_route, 0, 4 * sizeof(unsigned long long));
 	if (e != hipSuccess) {
@@ -562,22 +598,22 @@ void andi_hip_ctx_destroy(andi_hip_ctx *ctx) {
 	resolve_events(ctx);
 	if (ctx->scratch) (void)andi_arena::dev_free(ctx->scratch);
 	if (ctx->desc_dev) (void)andi_arena::dev_free(ctx->desc_dev);
-	if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
+	if (ctx->desc_host) host_pool::pinned_put(ctx->desc_host, ctx->desc_bytes);
 	if (ctx->d_fixups) (void)andi_arena::dev_free(ctx->d_fixups);
 	if (ctx->ib_dev) (void)andi_arena::dev_free(ctx->ib_dev);
-	if (ctx->ib_host) (void)hipHostFree(ctx->ib_host);
+	if (ctx->ib_host) host_pool::pinned_put(ctx->ib_host, ctx->ib_cap * sizeof(AndiIndexBatchItem));
 	if (ctx->ib_done) (void)hipEventDestroy(ctx->ib_done);
 	if (ctx->built) (void)hipEventDestroy(ctx->built);
 	if (ctx->sa_ws) (void)andi_arena::dev_free(ctx->sa_ws);
-	if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
-	if (ctx->h_quad_waves) (void)hipHostFree(ctx->h_quad_waves);
+	host_pool::word_put(ctx->sa_pinned);
+	host_pool::word_put(ctx->h_quad_waves);
 	if (ctx->d_route) (void)andi_arena::dev_free(ctx->d_route);
 	if (ctx->scratch2) (void)andi_arena::dev_free(ctx->scratch2);
 	if (ctx->pool_scratch) { // (kept for the device's next context: host_pool)
 		(void)hipDeviceSynchronize();
 		host_pool::scratch_put(ctx->device, ctx->pool_scratch, ctx->pool_bytes + 4096);
 	}
-	if (ctx->h_any_left) (void)hipHostFree(ctx->h_any_left);
+	host_pool::word_put(ctx->h_any_left);
 	if (ctx->coop_stream) {
 		(void)hipStreamSynchronize(ctx->coop_stream);
 		host_pool::stream_put(ctx->coop_stream, ctx->device, 0);
@@ -663,7 +699,7 @@ static int esa_reserve(andi_hip_ctx *ctx, size_t cap, andi_hip_esa **out) {
 	}
 	// flags: pinned host memory the kernels write directly (rare, idempotent plain stores) --
 	// no per-build memset or copy; the host reads them after a stream synchronisation
-	chk(hipHostMalloc((void **)&e->h_flags, 4 * sizeof(int32_t), hipHostMallocMapped));
+	if (!(e->h_flags = (int32_t *)host_pool::word_get())) chk(hipErrorOutOfMemory);
 	if (err == hipSuccess) chk(hipHostGetDevicePointer((void **)&e->flags, e->h_flags, 0));
 	e->bytes = (cap + 1 + ANDI_PAD) + 4 * cap + 8 * deep_entries + 80 +
 			   2 * (ANDI_NIB_FRONT + nib_part);
@@ -748,7 +784,7 @@ static int esa_sort_suffixes(andi_hip_ctx *ctx, andi_hip_esa *e) {
 		HIP_TRY(ctx, andi_arena::dev_malloc(&ctx->sa_ws, need));
 		ctx->sa_ws_bytes = need;
 	}
-	if (!ctx->sa_pinned) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->sa_pinned, 4 * sizeof(int32_t), hipHostMallocDefault));
+	if (!ctx->sa_pinned && !(ctx->sa_pinned = (int32_t *)host_pool::word_get())) HIP_TRY(ctx, hipErrorOutOfMemory);
 	if (!e->rec && !andi_knob(KNOB_NO_SORTED_RECORDS)) { // (experiments: the index build then gathers from the text, as with a host-made suffix array)
 		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec, (e->cap + 8) * sizeof(uint32_t)));
 		HIP_TRY(ctx, andi_arena::dev_malloc((void **)&e->rec2, (e->cap + 8) * sizeof(uint16_t)));
@@ -870,11 +906,11 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 	if (ctx->ib_cap < count) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->ib_dev) (void)andi_arena::dev_free(ctx->ib_dev);
-		if (ctx->ib_host) (void)hipHostFree(ctx->ib_host);
+		if (ctx->ib_host) host_pool::pinned_put(ctx->ib_host, ctx->ib_cap * sizeof(AndiIndexBatchItem));
 		ctx->ib_dev = ctx->ib_host = nullptr, ctx->ib_cap = 0;
 		const size_t cap = std::max<size_t>(count, 64);
-		HIP_TRY(ctx, hipMalloc(&ctx->ib_dev, cap * sizeof(AndiIndexBatchItem)));
-		HIP_TRY(ctx, hipHostMalloc(&ctx->ib_host, cap * sizeof(AndiIndexBatchItem), hipHostMallocDefault));
+		HIP_TRY(ctx, andi_arena::dev_malloc(&ctx->ib_dev, cap * sizeof(AndiIndexBatchItem)));
+		HIP_TRY(ctx, host_pool::pinned_get(&ctx->ib_host, cap * sizeof(AndiIndexBatchItem)));
 		if (!ctx->ib_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ib_done, hipEventDisableTiming));
 		ctx->ib_cap = cap;
 	} else {
@@ -954,7 +990,7 @@ void andi_hip_esa_free(andi_hip_ctx *ctx, andi_hip_esa *e) {
 	(void)hipDeviceSynchronize(); // once for the handle's ten buffers: nothing in flight uses them when they are handed out again
 	void *bufs[] = {e->S, e->SA, e->LCP, e->CLD, e->FVC, e->tab, e->deep, e->Nraw, e->Praw, e->rec, e->rec2, e->min_scratch};
 	for (void *b : bufs) (void)andi_arena::dev_free(b, false);
-	if (e->h_flags) (void)hipHostFree(e->h_flags);
+	host_pool::word_put(e->h_flags);
 	delete e;
 }
 
@@ -994,7 +1030,7 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 	chk(dmalloc(&q->pool, pool_bytes));
 	chk(dmalloc(&q->nib, pool_bytes / 2 + 64));
 	chk(dmalloc(&q->planes, 3 * (pool_bytes / 32) + 16));
-	chk(hipHostMalloc((void **)&q->h_foreign, sizeof(int32_t), hipHostMallocDefault));
+	if (!(q->h_foreign = (int32_t *)host_pool::word_get())) chk(hipErrorOutOfMemory);
 	int32_t *d_foreign = nullptr;
 	chk(dmalloc(&d_foreign, 1));
 	chk(dmalloc(&q->d_off, n));
@@ -1031,7 +1067,7 @@ void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q) {
 	(void)hipDeviceSynchronize();
 	void *bufs[] = {q->pool, q->nib, q->planes, q->d_off, q->d_len, q->d_qseg_start, q->d_seg2query, q->c_qseg_start, q->c_seg2query};
 	for (void *b : bufs) (void)andi_arena::dev_free(b, false);
-	if (q->h_foreign) (void)hipHostFree(q->h_foreign);
+	host_pool::word_put(q->h_foreign);
 	delete q;
 }
 
@@ -1168,7 +1204,7 @@ static int queries_stage_packed(andi_hip_ctx *ctx, const PackedQueries &P, andi_
 	chk(dmalloc(&q->pool, P.pool_bytes));
 	chk(dmalloc(&q->nib, P.pool_bytes / 2 + 64));
 	chk(dmalloc(&q->planes, 3 * (P.pool_bytes / 32) + 16));
-	chk(hipHostMalloc((void **)&q->h_foreign, sizeof(int32_t), hipHostMallocDefault));
+	if (!(q->h_foreign = (int32_t *)host_pool::word_get())) chk(hipErrorOutOfMemory);
 	chk(dmalloc(&q->d_off, n));
 	chk(dmalloc(&q->d_len, n));
 	if (err == hipSuccess) *q->h_foreign = P.foreign;
@@ -1325,12 +1361,13 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	if (ctx->desc_bytes < desc_need) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		if (ctx->desc_dev) (void)andi_arena::dev_free(ctx->desc_dev);
-		if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
+		if (ctx->desc_host) host_pool::pinned_put(ctx->desc_host, ctx->desc_bytes);
 		ctx->desc_dev = ctx->desc_host = nullptr;
 		ctx->desc_bytes = 0;
-		HIP_TRY(ctx, hipMalloc(&ctx->desc_dev, desc_need));
-		HIP_TRY(ctx, hipHostMalloc(&ctx->desc_host, desc_need, hipHostMallocDefault));
-		ctx->desc_bytes = desc_need;
+		const size_t desc_cap = std::max<size_t>(desc_need, 4096); // (one size for small calls: the pool of pinned buffers hands it back)
+		HIP_TRY(ctx, andi_arena::dev_malloc(&ctx->desc_dev, desc_cap));
+		HIP_TRY(ctx, host_pool::pinned_get(&ctx->desc_host, desc_cap));
+		ctx->desc_bytes = desc_cap;
 	} else {
 		HIP_TRY(ctx, hipEventSynchronize(ctx->desc_done)); // previous upload consumed
 	}
@@ -2084,7 +2121,10 @@ int andi_hip_dist_matrix(andi_hip_model *M, const andi_hip_seq *seqs, size_t n,
 		size_t sort_width = dev_prep && !o.low_memory ? std::min<size_t>(4, std::min(batch_max, last[d] - first[d])) : 1;
 		if (const char *sw = andi_knob(KNOB_SORT_WIDTH)) // (experiments)
 			if (atoi(sw) >= 1 && atoi(sw) <= 8) sort_width = std::min<size_t>((size_t)atoi(sw), std::min(batch_max, last[d] - first[d]));
-		if (andi_sa_device_workspace((int32_t)rs_cap) * sort_width > ((size_t)24 << 30)) sort_width = 1; // (45 bytes per character each)
+		// (a workspace of 45 bytes per character each: together at most one chunk of the arena -- eight of them for 9.8 M characters pushed a
+		// 29-genome call past the 8 GiB the arena keeps from call to call, and every call paid the driver for its chunks again: 37 -> 177 ms;
+		// two sorters measured like four, profiles/r07_seam/)
+		while (sort_width > 1 && andi_sa_device_workspace((int32_t)rs_cap) * sort_width > ((size_t)2 << 30)) --sort_width;
 		for (size_t w = 1; w < sort_width; ++w) {
 			andi_hip_ctx *cx = nullptr;
 			if (ctx_create(&cx, devs[d], eb, sizeof eb, true)) return bail("creating a context", nullptr);

@@ -596,8 +596,19 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 	uint32_t eq0 = 0, eq1 = 0, eq2 = 0, eq3 = 0;      // (per lane) equal pairs in the stretches, by nucleotide: summed over the lanes once per window
 	// (an LDS add of every lane to one cell is turned into a scalar loop over the lanes by the compiler: 1500 scalar instructions per round of heads)
 	bool done = false;
+#ifdef POOL_SEPARATE_EBITS
 	for (uint32_t w = lane; w < nwords + 4; w += 64) G->ebits[w] = 0;
 	pool_sync();
+#define POOL_GAPBITS ebits
+#else
+	// The stretches are or-ed into the window's mismatch bits themselves (round 6; until then a second bitmap, zeroed and read
+	// back per window: 32 KB of the scratch traffic of a window of 131072 positions).  Every reader of the bits inside this sweep
+	// decides the same with or without a stretch's bits, whichever it happens to see: the first bit at or after a landing
+	// (pool_next_bit) is a mismatch -- stretches start at heads, which are mismatches --, and the last bit before a head or
+	// before `cur` (pool_prev_bit*) is compared with where the hop before landed: a bit inside that hop's stretch lies before
+	// its landing like the mismatches it covers.  Sweep S writes every word anew for the next window.
+#define POOL_GAPBITS bits
+#endif
 	for (uint32_t base = 0; base < nheads && !done; base += 64) {
 		const uint32_t k = base + lane;
 		const bool valid = k < nheads;
@@ -679,12 +690,12 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 						uint32_t m = ~0u;
 						if (t == 0) m &= ~0u << (o0 & 31u);
 						if (32 * wd + 32 > o1) m &= (1u << (o1 & 31u)) - 1u;
-						if (32 * wd < o1) (void)__hip_atomic_fetch_or(&G->ebits[wd], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (two stretches may meet in a word)
+						if (32 * wd < o1) (void)__hip_atomic_fetch_or(&G->POOL_GAPBITS[wd], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (two stretches may meet in a word)
 					}
 					for (uint32_t wd = wd0 + 3; 32 * wd < o1; ++wd) {
 						uint32_t m = ~0u;
 						if (32 * wd + 32 > o1) m &= (1u << (o1 & 31u)) - 1u;
-						(void)__hip_atomic_fetch_or(&G->ebits[wd], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						(void)__hip_atomic_fetch_or(&G->POOL_GAPBITS[wd], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				}
 				// (2) the equal symbols of an ordinary stretch (its mismatches were counted in sweep S): from the head's record; stretches
@@ -757,10 +768,14 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 		const uint32_t span = (cur < wend ? cur : wend) - wbase; // (behind the window no bit is set)
 		for (uint32_t w0 = 0; 32 * w0 < span && !PKNOCK(3); w0 += 256) {
 			uint32_t u[4], before = 0;
+#ifdef POOL_SEPARATE_EBITS
 			const uint4 mv = *(const uint4 *)&G->bits[w0 + 4 * lane]; // (64 words of padding behind the window's)
+#else
+			const uint4 mv = make_uint4(0, 0, 0, 0); // (the bits with the stretches in them: ev, read past this CU's cache)
+#endif
 			uint4 ev = make_uint4(0, 0, 0, 0);
 			if (w0 + 4 * lane < nwords) {
-				const uint32_t *ep = &G->ebits[w0 + 4 * lane];
+				const uint32_t *ep = &G->POOL_GAPBITS[w0 + 4 * lane];
 				ev.x = __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ev.y = __hip_atomic_load(ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				ev.z = __hip_atomic_load(ep + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ev.w = __hip_atomic_load(ep + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}

@@ -149,8 +149,42 @@ void sais(const Sym *T, int32_t *SA, int32_t n, int32_t K) {
 
 } // namespace
 
+// libdivsufsort -- the sorter the reference links (configure.ac:33-38, called at src/esa.c:303; saidx_t = int32_t) -- is an
+// OPTIONAL link: where the host has it, it is loaded at first use and does the sorting (a suffix array is unique: the bits
+// downstream are the same); where it is absent (this project's image) or ANDI_HIP_NO_DIVSUFSORT is set, the SA-IS above does.
+#include <dlfcn.h>
+#include <mutex>
+namespace {
+typedef int32_t (*divsufsort_fn)(const unsigned char *, int32_t *, int32_t);
+divsufsort_fn g_divsufsort = nullptr;
+const char *g_sorter = "SA-IS (built in)";
+void resolve_sorter() {
+	static std::once_flag once;
+	std::call_once(once, [] {
+		if (getenv("ANDI_HIP_NO_DIVSUFSORT")) return;
+		const char *names[] = {"libdivsufsort.so.3", "libdivsufsort.so"};
+		for (const char *nm : names) {
+			void *h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+			if (!h) continue;
+			if (auto f = (divsufsort_fn)dlsym(h, "divsufsort")) {
+				g_divsufsort = f, g_sorter = "libdivsufsort (divsufsort, loaded at run time)";
+				return;
+			}
+			dlclose(h);
+		}
+	});
+}
+} // namespace
+
+extern "C" const char *andi_hip_suffix_sorter(void) {
+	resolve_sorter();
+	return g_sorter;
+}
+
 extern "C" int andi_hip_suffix_array(const unsigned char *T, int32_t *SA, int32_t n) {
 	if (!T || !SA || n < 0) return -1;
+	resolve_sorter();
+	if (g_divsufsort && n > 0) return g_divsufsort(T, SA, n) == 0 ? 0 : -2; // src/esa.c:303-304
 	try {
 		sais<unsigned char>(T, SA, n, 256);
 	} catch (...) {

@@ -95,6 +95,7 @@ SYMBOLS = {
     "andi_hip_min_anchor_length": (C.c_size_t, [C.c_double, C.c_double, C.c_size_t]),
     "andi_hip_shustring_cum_prob": (C.c_double, [C.c_size_t, C.c_double, C.c_size_t]),
     "andi_hip_suffix_array": (C.c_int, [_P, _P, C.c_int32]),
+    "andi_hip_suffix_sorter": (C.c_char_p, []),
     "andi_hip_model_average": (Model, [C.POINTER(Model), C.POINTER(Model)]),
     "andi_hip_model_coverage": (C.c_double, [C.POINTER(Model)]),
     "andi_hip_estimate": (C.c_double, [C.POINTER(Model), C.c_int]),

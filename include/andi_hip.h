@@ -124,6 +124,9 @@ double andi_hip_shustring_cum_prob(size_t x, double p, size_t l);
 /* divsufsort() as called at src/esa.c:303: T[0..n) unsigned bytes, T[n]
  * must be readable; SA[0..n).  Re-entrant. */
 int andi_hip_suffix_array(const unsigned char *T, int32_t *SA, int32_t n);
+/* which sorter that is: libdivsufsort where the host has it (loaded at first use with dlopen -- the reference's own,
+ * configure.ac:33-38; ANDI_HIP_NO_DIVSUFSORT in the environment keeps it away), else the built-in linear-time SA-IS */
+const char *andi_hip_suffix_sorter(void);
 /* model_average / model_coverage / estimate_* (src/model.c:39-210) */
 andi_hip_model andi_hip_model_average(const andi_hip_model *a, const andi_hip_model *b);
 double andi_hip_model_coverage(const andi_hip_model *m);

@@ -312,3 +312,54 @@ def test_format_distances_row_parallel_equals_the_sequential_loop(orc):
         assert got_text == text and got_warn == warn
         assert flags == (1 if "reported as nan" in warn else 0) | (2 if "very little homology" in warn else 0)
         assert ("e-0" in text.splitlines()[1]) == small
+
+
+def test_libdivsufsort_is_an_optional_link(tmp_path):
+    """north_star: 'SA via libdivsufsort on host' (configure.ac:33-38, src/esa.c:303).  The image has no libdivsufsort, so the
+    built-in SA-IS sorts (andi_hip_suffix_sorter says so); where the host has the library it is loaded at first use.  The
+    plumbing is exercised with a test double: a libdivsufsort.so.3 made here (a plain comparison sort that also leaves a mark),
+    found through LD_LIBRARY_PATH by a process of its own -- same suffix array, the double's mark proves who sorted."""
+    import subprocess
+    import sys
+    from andi_amd import lib
+    assert lib.load().andi_hip_suffix_sorter().decode().startswith("SA-IS")
+    src = tmp_path / "fake_divsufsort.c"
+    src.write_text(r"""
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+static const unsigned char *g_t; static int32_t g_n;
+static int cmp(const void *a, const void *b) {
+	int32_t i = *(const int32_t *)a, j = *(const int32_t *)b;
+	int32_t li = g_n - i, lj = g_n - j, m = li < lj ? li : lj;
+	int c = memcmp(g_t + i, g_t + j, (size_t)m);
+	return c ? c : (li < lj ? -1 : 1);
+}
+int32_t divsufsort(const unsigned char *T, int32_t *SA, int32_t n) {
+	g_t = T, g_n = n;
+	for (int32_t i = 0; i < n; i++) SA[i] = i;
+	qsort(SA, (size_t)n, sizeof *SA, cmp);
+	FILE *f = fopen(getenv("FAKE_DIVSUFSORT_MARK"), "w");
+	if (f) { fprintf(f, "%d", n); fclose(f); }
+	return 0;
+}
+""")
+    so = tmp_path / "libdivsufsort.so.3"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", str(so), str(src)])
+    mark = tmp_path / "mark"
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from andi_amd import lib\n"
+            "text = b'TGCAACGT#ACGTTGCA' * 50 + b'ACGT!GGTTAAC;'\n"
+            "sa = lib.suffix_array(text)\n"
+            "print(lib.load().andi_hip_suffix_sorter().decode()); print(' '.join(map(str, sa.tolist())))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""), FAKE_DIVSUFSORT_MARK=str(mark))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    name, sa_line = r.stdout.strip().splitlines()[-2:]
+    assert name.startswith("libdivsufsort") and mark.read_text() == str(17 * 50 + 13)
+    text = b"TGCAACGT#ACGTTGCA" * 50 + b"ACGT!GGTTAAC;"
+    assert [int(x) for x in sa_line.split()] == lib.suffix_array(text).tolist()  # the built-in sorter, in this process
+    env["ANDI_HIP_NO_DIVSUFSORT"] = "1"
+    r2 = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and r2.stdout.strip().splitlines()[-2].startswith("SA-IS")
