@@ -14,8 +14,9 @@
 //   W  the walks of ALL heads of the window, 64 per trip, a lane that is done takes the next head: the record is the
 //      lane's only load besides the probe table's entry (walks that leave their record read the scratch / the query).
 //   R  the chain hops from head to head (64 heads per round, ballots); the stretches behind the heads it came by are
-//      marked in a second bitmap (atomic or: two stretches may meet in a word); one pass over both bitmaps counts the
-//      anchors (src/model.c:247-253).
+//      or-ed into the window's bits (atomic or: two stretches may meet in a word; round 5 kept them in a second bitmap,
+//      zeroed and read back per window: C4 shape 25.7 -> 23.6 ms without it); one pass over the bits counts the anchors
+//      (src/model.c:247-253).
 //
 // The states and counts are those of the sequential loop (src/process.c:141-214), as coop_window's: tests/test_coop_gpu.py
 // runs both against the oracle and against each other.  LogDet / ANI (EXACT) stay with coop_window.
@@ -33,20 +34,28 @@ struct __attribute__((aligned(16))) PoolRes { // what it found
 };
 struct PoolScratch { // a window's scratch in global memory, one per resident wavefront
 	uint32_t *bits;  // [64 maxchunks + 64] bit (x - wbase): query symbol x != subject symbol x + dg
-	uint32_t *ebits; // [64 maxchunks + 64] sweep R: the stretches behind the heads the chain came by, [head, landing): gap positions too
+	uint32_t *ebits; // (-DPOOL_SEPARATE_EBITS, the A/B build of round 5's layout: [64 maxchunks + 64] sweep R's stretches in a bitmap of their own; by default they are or-ed into `bits` and this is null)
 	PoolRec *rec;    // [hc]
 	PoolRes *res;    // [hc]
 	uint32_t hc;        // heads of a window that are walked (more: nothing is decided from the first one dropped on)
 	uint32_t maxchunks; // rounds of 2048 positions of a window at most
 };
 __host__ __device__ inline size_t pool_scratch_bytes(uint32_t maxchunks, uint32_t hc) {
+#ifdef POOL_SEPARATE_EBITS
 	return 2 * (size_t)(64 * maxchunks + 64) * sizeof(uint32_t) + (size_t)hc * (sizeof(PoolRec) + sizeof(PoolRes));
+#else
+	return (size_t)(64 * maxchunks + 64) * sizeof(uint32_t) + (size_t)hc * (sizeof(PoolRec) + sizeof(PoolRes));
+#endif
 }
 __device__ __forceinline__ PoolScratch pool_scratch_at(void *base, size_t idx, uint32_t maxchunks, uint32_t hc) {
 	char *p = (char *)base + idx * pool_scratch_bytes(maxchunks, hc);
 	PoolScratch g;
 	g.bits = (uint32_t *)p, p += (size_t)(64 * maxchunks + 64) * sizeof(uint32_t);
+#ifdef POOL_SEPARATE_EBITS
 	g.ebits = (uint32_t *)p, p += (size_t)(64 * maxchunks + 64) * sizeof(uint32_t);
+#else
+	g.ebits = nullptr;
+#endif
 	g.rec = (PoolRec *)p, p += (size_t)hc * sizeof(PoolRec);
 	g.res = (PoolRes *)p;
 	g.hc = hc, g.maxchunks = maxchunks;

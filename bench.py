@@ -329,7 +329,7 @@ def main():
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run also with one rank
     # The RCCL process group is initialised AFTER the engine has allocated what it works on (below, behind one untimed
     # pass): device memory allocated once RCCL is up makes pass A -- scattered, latency-bound loads -- 9 % slower
-    # (6.05 -> 6.57 ms, measured with one rank, scripts/dev/r3_dist3.sh; ANDI_BENCH_EARLY_INIT=1 restores that order).
+    # (6.05 -> 6.57 ms, measured with one rank; ANDI_BENCH_EARLY_INIT=1 restores that order).
     # andi_hip_dist_matrix creates its communicators after the scans for the same reason.
     late_init = not os.environ.get("ANDI_BENCH_EARLY_INIT")
     if use_dist:

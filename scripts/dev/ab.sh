@@ -1,5 +1,5 @@
 #!/bin/bash
-# pass A time of the bench step under a list of environment settings: scripts/dev/r4_ab.sh "ANDI_COOP=4" "ANDI_COOP=8 ANDI_COOP_SEG=65536" ...
+# pass A time of the bench step under a list of environment settings: scripts/dev/ab.sh "ANDI_COOP=4" "ANDI_COOP=8 ANDI_COOP_SEG=65536" ...
 cd "$GRAFT_REPO_ROOT" || exit 1
 export ANDI_HIP_LIB=${ANDI_HIP_LIB:-$PWD/andi_amd/libandihip_test.so} # the build with the experiment switches (andi_amd/csrc/knobs.h)
 for cfg in "$@"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the bench step's parts with a list of builds of the library (andi_amd/<lib>): scripts/dev/r4_ablib.sh libandihip.so libandihip_x.so ...
+# the bench step's parts with a list of builds of the library (andi_amd/<lib>): scripts/dev/ablib.sh libandihip.so libandihip_x.so ...
 cd "$GRAFT_REPO_ROOT" || exit 1
 for lib in "$@"; do
   ANDI_HIP_LIB=$PWD/andi_amd/$lib python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra $BENCH_ARGS 2>/dev/null | tail -1 | python3 -c "
