@@ -30,8 +30,18 @@ struct __attribute__((aligned(16))) PoolRec { // what a head's walk reads
 	uint32_t pos, pad;
 };
 struct __attribute__((aligned(16))) PoolRes { // what it found
-	uint32_t pos, ha, hend, flag; // the head; landing position; length of the anchor landed on (W_LUCKY: not known); W_* flags
+	uint32_t pos, ha, hend, flag; // the head; landing position; length of the anchor landed on (W_LUCKY: not known); pool_pack_flag(W_* flags, equal symbols of the stretch)
 };
+// The flag word of a result: bits 0-4 the W_* status bits, 5-7 the anchors met off the diagonal (W_NX_SHIFT), 8-31 the equal
+// symbols of an ordinary stretch of at most POOL_EQ_MAX positions by nucleotide, six bits each (the walk has the head's record in
+// registers when it ends; until round 6 sweep R fetched every record a second time for them: 32 bytes per head)
+constexpr uint32_t POOL_EQ_MAX = 63;
+__device__ __forceinline__ uint32_t pool_pack_flag(uint32_t res, uint32_t eq) {
+	return (res & 0x1fu) | (((res >> W_NX_SHIFT) & 7u) << 5) | (eq << 8);
+}
+__device__ __forceinline__ uint32_t pool_flag_of(uint32_t w) {
+	return (w & 0x1fu) | (((w >> 5) & 7u) << W_NX_SHIFT);
+}
 struct PoolScratch { // a window's scratch in global memory, one per resident wavefront
 	uint32_t *bits;  // [64 maxchunks + 64] bit (x - wbase): query symbol x != subject symbol x + dg
 	uint32_t *ebits; // (-DPOOL_SEPARATE_EBITS, the A/B build of round 5's layout: [64 maxchunks + 64] sweep R's stretches in a bitmap of their own; by default they are or-ed into `bits` and this is null)
@@ -551,8 +561,23 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 			}
 			if (res) {
 				if ((res & W_LUCKY) && (ra + sd < c.border) != (e + sd <= c.border)) res = W_BREAK;
+				// the equal symbols of the stretch (e, ra) by nucleotide, for sweep R: from the record, if the stretch lies inside it
+				uint32_t eq = 0;
+				{
+					const uint32_t len = ra - e - 1;
+					if ((res & W_STATUS) == W_OK && !(res & W_HADX) && clean && len - 1u < POOL_EQ_MAX) {
+						uint32_t eqlo = ~cb0, eqhi = ~cb1; // the equal positions among the len <= 63 behind the head
+						if (len < 32) eqlo &= (1u << len) - 1u, eqhi = 0;
+						else eqhi &= (1u << (len - 32)) - 1u;
+						const uint32_t n0 = (uint32_t)__builtin_popcount(eqlo & ~cq2 & ~cq0) + (uint32_t)__builtin_popcount(eqhi & ~cq3 & ~cq1);
+						const uint32_t n1 = (uint32_t)__builtin_popcount(eqlo & ~cq2 & cq0) + (uint32_t)__builtin_popcount(eqhi & ~cq3 & cq1);
+						const uint32_t n2 = (uint32_t)__builtin_popcount(eqlo & cq2 & ~cq0) + (uint32_t)__builtin_popcount(eqhi & cq3 & ~cq1);
+						const uint32_t n3 = (uint32_t)__builtin_popcount(eqlo & cq2 & cq0) + (uint32_t)__builtin_popcount(eqhi & cq3 & cq1);
+						eq = n0 | (n1 << 6) | (n2 << 12) | (n3 << 18);
+					}
+				}
 				PoolRes rs;
-				rs.pos = e, rs.ha = ra, rs.hend = rlen, rs.flag = res;
+				rs.pos = e, rs.ha = ra, rs.hend = rlen, rs.flag = pool_pack_flag(res, eq);
 				G->res[hk] = rs;
 				hk = NOPOS;
 			}
@@ -622,11 +647,9 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 		const uint32_t k = base + lane;
 		const bool valid = k < nheads;
 		PoolRes rs;
-		PoolRec rc; // (the head's record, for the equal symbols of its stretch: fetched with the result, one round trip per round of heads)
 		rs.pos = NOPOS, rs.ha = 0, rs.hend = 0, rs.flag = 0;
-		rc.q2[0] = rc.q2[1] = rc.q2[2] = rc.q2[3] = rc.bits[0] = rc.bits[1] = 0;
-		if (valid) rs = G->res[k], rc = G->rec[k];
-		const uint32_t pos = rs.pos, fl = rs.flag, la = rs.ha;
+		if (valid) rs = G->res[k];
+		const uint32_t pos = rs.pos, fl = pool_flag_of(rs.flag), la = rs.ha, eqw = rs.flag >> 8; // (eqw: the stretch's equal symbols, from the walk)
 		// Where the anchor the walk landed on ends is the chain's next stand.  A probe's anchor: the result says; a lucky anchor's end
 		// is the next mismatch behind the landing -- looked up only where it matters: the next head, a mismatch itself, bounds it
 		const bool landed = (fl & W_STATUS) == W_OK, lucky = landed && (fl & W_LUCKY);
@@ -711,17 +734,8 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 				// longer than a record (one head in thirty) with all lanes, one after the other -- a lane's own loop over their text
 				// was run by every round of 64 heads
 				const uint32_t len = la - pos - 1;
-				const bool ord = onpath && !(fl & W_HADX) && len != 0, fast = ord && clean && len <= 64;
-				if (fast && !PKNOCK(8)) {
-					uint32_t eqlo = ~rc.bits[0], eqhi = ~rc.bits[1]; // the equal positions among the len <= 64 behind the head
-					if (len < 32) eqlo &= (1u << len) - 1u, eqhi = 0;
-					else if (len < 64) eqhi &= (1u << (len - 32)) - 1u;
-					const uint32_t n0 = (uint32_t)__builtin_popcount(eqlo & ~rc.q2[2] & ~rc.q2[0]) + (uint32_t)__builtin_popcount(eqhi & ~rc.q2[3] & ~rc.q2[1]);
-					const uint32_t n1 = (uint32_t)__builtin_popcount(eqlo & ~rc.q2[2] & rc.q2[0]) + (uint32_t)__builtin_popcount(eqhi & ~rc.q2[3] & rc.q2[1]);
-					const uint32_t n2 = (uint32_t)__builtin_popcount(eqlo & rc.q2[2] & ~rc.q2[0]) + (uint32_t)__builtin_popcount(eqhi & rc.q2[3] & ~rc.q2[1]);
-					const uint32_t n3 = (uint32_t)__builtin_popcount(eqlo & rc.q2[2] & rc.q2[0]) + (uint32_t)__builtin_popcount(eqhi & rc.q2[3] & rc.q2[1]);
-					eq0 += n0, eq1 += n1, eq2 += n2, eq3 += n3;
-				}
+				const bool ord = onpath && !(fl & W_HADX) && len != 0, fast = ord && clean && len <= POOL_EQ_MAX; // (fast: the walk counted them, as pool_pack_flag says)
+				if (fast && !PKNOCK(8)) eq0 += eqw & 63u, eq1 += (eqw >> 6) & 63u, eq2 += (eqw >> 12) & 63u, eq3 += (eqw >> 18) & 63u;
 				for (uint64_t sl = PKNOCK(9) ? 0ull : __ballot(ord && !fast); sl; sl &= sl - 1) {
 					const uint32_t l = (uint32_t)__builtin_ctzll(sl);
 					const uint32_t q0 = uni((uint32_t)__shfl((int)pos, (int)l)) + 1, ln = uni((uint32_t)__shfl((int)len, (int)l));

@@ -185,8 +185,12 @@ static_assert(ANDI_RESTITCH_ROUNDS < 8, "restitch_count[]: rounds 0 .. ROUNDS at
 #define ANDI_ROUTE_LEFT 0x20u /* ... which handed it back */
 #define ANDI_ROUTE_SOFT 0x10u /* (k_pair_estimate to k_pair_route) the lane scan is better at it, if such pairs are more than a few */
 #define ANDI_ROUTE_GUESS 0x04u /* (k_pair_estimate to k_pair_route, small calls) marked for the wavefront kernel although the sampling cannot judge the pair: not where the call has pairs with unrelated stretches */
-#define ANDI_ROUTE_L2 0x08u   /* a pair handed back: in the second lane layout */
-#define ANDI_ROUTE_POOLCAND 0x08u /* (k_pair_estimate to k_pair_route) mean sampled match in [ScanArgs.pool_match, 4096): a pair that suits k_pool_cold (coop_pool.h) */
+/* ONE BIT, TWO MEANINGS, kept apart in time (the class byte has no bit to spare): ANDI_ROUTE_POOLCAND is written by k_pair_estimate and
+ * read AND CLEARED for every pair by k_pair_route (scan_lane.hip: route_pair) before anything reads ANDI_ROUTE_L2, which only k_pair_leftover
+ * sets, behind pass A.  A reader of ANDI_ROUTE_L2 placed between k_pair_estimate and k_pair_route -- or a path that skips k_pair_route --
+ * would take pool candidates for handed-back pairs and drop them from the lane layout: do not add one. */
+#define ANDI_ROUTE_L2 0x08u   /* (from k_pair_leftover on) a pair handed back: in the second lane layout */
+#define ANDI_ROUTE_POOLCAND 0x08u /* (k_pair_estimate to k_pair_route ONLY) mean sampled match in [ScanArgs.pool_match, 4096): a pair that suits k_pool_cold (coop_pool.h) */
 #define ANDI_STRUCT_WAVES 4 /* restitch_count[this] during the layout of a routed call: wavefronts of pairs with unrelated stretches that are not merely far apart (k_pair_estimate) */
 #define ANDI_POOL_SEGS 6 /* restitch_count[this] after k_pair_route: segments of the wavefront kernel's pairs that suit k_pool_cold */
 #define ANDI_COOP_SEGS 7 /* ... of all its pairs */
