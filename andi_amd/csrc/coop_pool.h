@@ -338,12 +338,7 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 				else if (end - 1 - x0 < 32) live = (1u << (end - 1 - x0)) - 1u;
 				const uint32_t hmask = cur & A & ~B & live;
 				const uint32_t nh = (uint32_t)__builtin_popcount(hmask);
-				uint32_t hb = nh; // exclusive prefix sum over the lanes
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) {
-					const uint32_t o = (uint32_t)__shfl_up((int)hb, d);
-					if (lane >= (uint32_t)d) hb += o;
-				}
+				uint32_t hb = wave_scan_add(nh); // (inclusive; made exclusive below)
 				const uint32_t total = uni((uint32_t)__shfl((int)hb, 63));
 				hb -= nh;
 				if (total) {
@@ -433,11 +428,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 			seen = v != 0 && o + r < Wp;
 			return r;
 		};
-		auto generic_probe = [&](uint32_t pp) {
-			LWin w;
-			w.q0 = EMPTY, w.dg = NO_DIAG;
-			return lane_probe(c, pp, w);
-		};
+		auto generic_probe = [&](uint32_t pp) { return coop_generic_probe(c, pp); };
 		for (;;) {
 			const uint64_t idle = __ballot(hk == NOPOS);
 			if (idle && next_head < nheads) {
@@ -814,12 +805,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 				u[j] = rm && w < nwords ? (pick(mv, j) | pick(ev, j)) & rm : 0u; // (an anchor may end behind the window: no bits there)
 				if (u[j]) before = x0 + 31u - (uint32_t)__builtin_clz(u[j]) + 2u;
 			}
-			uint32_t scan = before;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t o = (uint32_t)__shfl_up((int)scan, d);
-				if (lane >= (uint32_t)d && o > scan) scan = o;
-			}
+			const uint32_t scan = wave_scan_max(before);
 			before = (uint32_t)__shfl_up((int)scan, 1);
 			if (lane == 0 || before < carry_before) before = carry_before;
 			uint32_t prev_top = (uint32_t)__shfl_up((int)(u[3] >> 31), 1);

@@ -110,10 +110,32 @@ __device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) {
 	(void)__hip_atomic_fetch_or((lds_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-	for (int d = 32; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+
+// inclusive prefix sums / prefix maxima over the 64 lanes in six DPP steps (shifts by 1, 2, 4, 8 inside the rows of 16 lanes, then
+// lane 15 of a row into the next row, lane 31 into the upper half; lanes without a source take 0: the identity of both for unsigned
+// values) -- six vector instructions where six __shfl_up were six LDS-crossbar round trips with their address arithmetic
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
 	return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+	uint32_t o;
+	o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false), v = o > v ? o : v;
+	o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false), v = o > v ? o : v;
+	o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false), v = o > v ? o : v;
+	o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false), v = o > v ? o : v;
+	o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false), v = o > v ? o : v;
+	o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false), v = o > v ? o : v;
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { // (all lanes active) the sum over the wavefront, wave-uniform
+	return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(v), 63);
 }
 
 __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
@@ -337,6 +359,18 @@ __device__ __forceinline__ bool coop_probe_codes(const PairCtx &c, uint32_t p, u
 	return true;
 }
 
+// lane_probe with a window of its own, for the walks' rare probes that nothing shorter answers (0.4 % of them: window edges,
+// separators, matches deeper than 16 symbols off the diagonal)
+#ifdef COOP_GENERIC_NOINLINE
+__device__ __attribute__((noinline)) Probe coop_generic_probe(const PairCtx &c, uint32_t pp) {
+#else
+__device__ __forceinline__ Probe coop_generic_probe(const PairCtx &c, uint32_t pp) {
+#endif
+	LWin w;
+	w.q0 = EMPTY, w.dg = NO_DIAG;
+	return lane_probe(c, pp, w);
+}
+
 template <int NCH>
 __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<NCH> &L, uint32_t wbase, bool clean, uint32_t p, uint32_t sd, Probe &r, bool &on_diag,
 												uint32_t &multi_x, uint32_t &multi_n, uint32_t &multi_q) {
@@ -553,12 +587,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		hmask[j] = cur & soon & ~before & live;
 		nh += (uint32_t)__builtin_popcount(hmask[j]);
 	}
-	uint32_t hbase = nh; // exclusive prefix sum over the lanes
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t o = (uint32_t)__shfl_up((int)hbase, d);
-		if (lane >= (uint32_t)d) hbase += o;
-	}
+	uint32_t hbase = wave_scan_add(nh); // (inclusive; made exclusive below)
 	const uint32_t nheads_all = uni((uint32_t)__shfl((int)hbase, 63));
 	hbase -= nh;
 	uint32_t dropped = NOPOS; // the first head beyond the list's capacity: nothing is decided from there on
@@ -596,11 +625,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			seen = v != 0 && o + r < W;
 			return r;
 		};
-		auto generic_probe = [&](uint32_t pp) { // lane_probe with a window of its own (rare: nothing to keep across the trips)
-			LWin w;
-			w.q0 = EMPTY, w.dg = NO_DIAG;
-			return lane_probe(c, pp, w);
-		};
+		auto generic_probe = [&](uint32_t pp) { return coop_generic_probe(c, pp); };
 		for (;;) {
 			const uint64_t idle = __ballot(hk == NOPOS);
 			if (idle && next_head < nheads) {
@@ -913,12 +938,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		if (u) before = x0 + 31u - (uint32_t)__builtin_clz(u) + 2u;
 	}
 	{
-		uint32_t scan = before;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t o = (uint32_t)__shfl_up((int)scan, d);
-			if (lane >= (uint32_t)d && o > scan) scan = o;
-		}
+		const uint32_t scan = wave_scan_max(before);
 		before = (uint32_t)__shfl_up((int)scan, 1);
 		if (lane == 0 || before < st.lastQ + 1u) before = st.lastQ + 1u; // (the anchor before e0 starts at lastQ: lastQ - 1 is the position before it)
 	}
