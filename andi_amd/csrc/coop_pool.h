@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t pool_next_bit(const PoolScratch *G, uint32_t
 		const uint64_t hit = __ballot(v != 0);
 		if (hit) {
 			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
-			const uint32_t vl = (uint32_t)__shfl((int)v, (int)l);
+			const uint32_t vl = lane_read(v, l);
 			return uni(wbase + 32 * (w0 + l) + (uint32_t)__builtin_ctz(vl));
 		}
 	}
@@ -119,7 +119,7 @@ __device__ __forceinline__ uint32_t pool_prev_bit(const PoolScratch *G, uint32_t
 		const uint64_t hit = __ballot(v != 0);
 		if (hit) {
 			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
-			const uint32_t vl = (uint32_t)__shfl((int)v, (int)l);
+			const uint32_t vl = lane_read(v, l);
 			return uni(wbase + 32 * (uint32_t)(w0 - (int32_t)l) + 31u - (uint32_t)__builtin_clz(vl));
 		}
 	}
@@ -308,7 +308,7 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 					const uint64_t any = __ballot(m != 0);
 					if (any) {
 						const uint32_t l = 63u - (uint32_t)__builtin_clzll(any);
-						const uint32_t ml = (uint32_t)__shfl((int)m, (int)l);
+						const uint32_t ml = lane_read(m, l);
 						last_mm = uni(wbase + 2048 * t + 32 * l + 31u - (uint32_t)__builtin_clz(ml));
 					}
 				}
@@ -339,7 +339,7 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 				const uint32_t hmask = cur & A & ~B & live;
 				const uint32_t nh = (uint32_t)__builtin_popcount(hmask);
 				uint32_t hb = wave_scan_add(nh); // (inclusive; made exclusive below)
-				const uint32_t total = uni((uint32_t)__shfl((int)hb, 63));
+				const uint32_t total = lane_read(hb, 63);
 				hb -= nh;
 				if (total) {
 					if (total > POOL_CHUNK_HEADS || nheads + total > G->hc) { // dropped: nothing is decided from this round's first head on
@@ -369,7 +369,7 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 							}
 							const uint64_t okm = __ballot(ok), bad = __ballot(valid && !ok);
 							if (bad) { // (sorted: the first of them is the lowest) too near the window's end: nothing is decided from there on
-								const uint32_t first = uni((uint32_t)__shfl((int)e, (int)__builtin_ctzll(bad)));
+								const uint32_t first = lane_read(e, __builtin_ctzll(bad));
 								if (first < f_cap) f_cap = first;
 								heads_on = false;
 							}
@@ -645,7 +645,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 		// is the next mismatch behind the landing -- looked up only where it matters: the next head, a mismatch itself, bounds it
 		const bool landed = (fl & W_STATUS) == W_OK, lucky = landed && (fl & W_LUCKY);
 		const uint32_t endk = landed && !lucky ? la + rs.hend : NOPOS;
-		uint32_t nxtpos = (uint32_t)__shfl_down((int)pos, 1);
+		uint32_t nxtpos = lane_above(pos);
 		if (lane == 63) nxtpos = k + 1 < nheads ? G->res[k + 1].pos : NOPOS;
 		const bool unusual = valid && (!landed || pos >= F || nxtpos < la || (lucky ? nxtpos >= F : (nxtpos < endk || endk >= F)));
 		bool onpath = false;
@@ -665,15 +665,15 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 			if (j > lo) {
 				const uint32_t last = (j < 64 ? j : 64u) - 1u;
 				const uint32_t lastv = nheads - base - 1u < last ? nheads - base - 1u : last;
-				cur = uni((uint32_t)__shfl((int)la, (int)lastv)); // (a lower bound, see above)
-				have_hop = 1, hop_ha = cur, hop_x = uni((uint32_t)__shfl((int)fl, (int)lastv)) & W_HADX;
+				cur = lane_read(la, lastv); // (a lower bound, see above)
+				have_hop = 1, hop_ha = cur, hop_x = lane_read(fl, lastv) & W_HADX;
 			}
 			if (j >= 64) {
 				kcur = base + 64;
 				break;
 			}
-			const uint32_t pj = uni((uint32_t)__shfl((int)pos, (int)j)), lj = uni((uint32_t)__shfl((int)la, (int)j)), fj = uni((uint32_t)__shfl((int)fl, (int)j));
-			uint32_t ej = uni((uint32_t)__shfl((int)endk, (int)j));
+			const uint32_t pj = lane_read(pos, j), lj = lane_read(la, j), fj = lane_read(fl, j);
+			uint32_t ej = lane_read(endk, j);
 			if (pj < F && (fj & W_STATUS) == W_OK && (fj & W_LUCKY)) ej = pool_next_bit(G, nwords, wbase, lj);
 			if (pj >= F) { // the chain reaches a position where the window's knowledge ends before this head
 				cur = F, done = true;
@@ -729,14 +729,14 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 				if (fast && !PKNOCK(8)) eq0 += eqw & 63u, eq1 += (eqw >> 6) & 63u, eq2 += (eqw >> 12) & 63u, eq3 += (eqw >> 18) & 63u;
 				for (uint64_t sl = PKNOCK(9) ? 0ull : __ballot(ord && !fast); sl; sl &= sl - 1) {
 					const uint32_t l = (uint32_t)__builtin_ctzll(sl);
-					const uint32_t q0 = uni((uint32_t)__shfl((int)pos, (int)l)) + 1, ln = uni((uint32_t)__shfl((int)len, (int)l));
+					const uint32_t q0 = lane_read(pos, l) + 1, ln = lane_read(len, l);
 					pool_count_equal_coop(c, q0, (uint32_t)((int64_t)q0 + dg), ln, eq0, eq1, eq2, eq3);
 				}
 				// (3) a walk that met anchors off the diagonal (rare): its stretch is counted nowhere -- the mismatches are taken back --, the anchor
 				// before the head only under the conditions of src/process.c:176-186
 				for (uint64_t hx = __ballot(onpath && (fl & W_HADX)); hx; hx &= hx - 1) {
 					const uint32_t l = (uint32_t)__builtin_ctzll(hx);
-					const uint32_t q0 = uni((uint32_t)__shfl((int)pos, (int)l)), ln = uni((uint32_t)__shfl((int)la, (int)l)) - q0;
+					const uint32_t q0 = lane_read(pos, l), ln = lane_read(la, l) - q0;
 					pool_uncount_coop(c, hist, q0, (uint32_t)((int64_t)q0 + dg), ln);
 				}
 				if (onpath && (fl & W_HADX)) {
@@ -806,9 +806,9 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 				if (u[j]) before = x0 + 31u - (uint32_t)__builtin_clz(u[j]) + 2u;
 			}
 			const uint32_t scan = wave_scan_max(before);
-			before = (uint32_t)__shfl_up((int)scan, 1);
+			before = lane_below(scan);
 			if (lane == 0 || before < carry_before) before = carry_before;
-			uint32_t prev_top = (uint32_t)__shfl_up((int)(u[3] >> 31), 1);
+			uint32_t prev_top = lane_below((u[3] >> 31));
 			if (lane == 0) prev_top = carry_top;
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
@@ -825,9 +825,9 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 				prev_top = uu >> 31;
 			}
 			{
-				const uint32_t top = uni((uint32_t)__shfl((int)scan, 63));
+				const uint32_t top = lane_read(scan, 63);
 				if (top > carry_before) carry_before = top;
-				carry_top = uni((uint32_t)__shfl((int)(u[3] >> 31), 63));
+				carry_top = lane_read((u[3] >> 31), 63);
 			}
 		}
 		ch.quarter += wave_sum(q_acc) - wave_sum(sub_q), ch.rest += wave_sum(r_acc) - wave_sum(sub_r);
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(64, POOL_OCC) void k_pool_cold(ScanArgs a) {
 		wave_sync();
 		uint32_t nx = 0;
 		if (__lane_id() == 0) nx = atomicAdd(a.pool_ticket, 1u);
-		item = gridDim.x + uni((uint32_t)__shfl((int)nx, 0));
+		item = gridDim.x + lane_read(nx, 0);
 	}
 }
 

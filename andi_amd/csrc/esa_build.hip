@@ -518,7 +518,7 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 #pragma unroll
 	for (int u = 0; u < PT_GAPS; ++u) {
 		const uint32_t word = u * (PT_BLOCK / 64) + wave;
-		const uint32_t before = (uint32_t)__shfl((int)owners_before, (int)word);
+		const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)owners_before, __builtin_amdgcn_readfirstlane((int)word)); // (word is wave-uniform: v_readlane, not a trip through the LDS crossbar)
 		if (counts[u] == 0) continue;
 		const uint32_t i = threadIdx.x + u * PT_BLOCK, off = firsts[u] - base;
 		s_owner[before + (uint32_t)__builtin_popcountll(s_some[word] & ((1ull << lane) - 1ull))] = (uint16_t)i;

@@ -134,6 +134,18 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
 	return v;
 }
 
+// Lane l's value for a wave-uniform l: v_readlane; the value of the lane below / above (lane 0 / 63: its own): one DPP move.
+// (__shfl and its kin are ds_bpermute: a trip through the LDS crossbar each.)
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t l) {
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uni(l));
+}
+__device__ __forceinline__ uint32_t lane_below(uint32_t v) {
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false); // wave_shr:1
+}
+__device__ __forceinline__ uint32_t lane_above(uint32_t v) {
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false); // wave_shl:1
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { // (all lanes active) the sum over the wavefront, wave-uniform
 	return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(v), 63);
 }
@@ -190,7 +202,7 @@ __device__ __forceinline__ uint32_t coop_lcp(const PairCtx &c, uint32_t p, uint3
 		const uint64_t hit = __ballot(f < WNT);
 		if (hit) {
 			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
-			const uint32_t fl = (uint32_t)__shfl((int)f, (int)l);
+			const uint32_t fl = lane_read(f, l);
 			const uint32_t len = uni(pe + base + WNT * l + fl - p);
 			return len < maxlen ? len : maxlen;
 		}
@@ -262,7 +274,7 @@ __device__ __forceinline__ uint32_t coop_next_mismatch(const CoopLds<NCH> &L, ui
 		const uint64_t hit = __ballot(v != 0);
 		if (hit) {
 			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
-			const uint32_t vl = (uint32_t)__shfl((int)v, (int)l);
+			const uint32_t vl = lane_read(v, l);
 			return uni(wbase + 32 * (w0 + l) + (uint32_t)__builtin_ctz(vl));
 		}
 	}
@@ -282,7 +294,7 @@ __device__ __forceinline__ uint32_t coop_prev_mismatch(const CoopLds<NCH> &L, ui
 		const uint64_t hit = __ballot(v != 0);
 		if (hit) {
 			const uint32_t l = (uint32_t)__builtin_ctzll(hit);
-			const uint32_t vl = (uint32_t)__shfl((int)v, (int)l);
+			const uint32_t vl = lane_read(v, l);
 			return uni(wbase + 32 * (uint32_t)(w0 - (int32_t)l) + 31u - (uint32_t)__builtin_clz(vl));
 		}
 	}
@@ -361,11 +373,9 @@ __device__ __forceinline__ bool coop_probe_codes(const PairCtx &c, uint32_t p, u
 
 // lane_probe with a window of its own, for the walks' rare probes that nothing shorter answers (0.4 % of them: window edges,
 // separators, matches deeper than 16 symbols off the diagonal)
-#ifdef COOP_GENERIC_NOINLINE
-__device__ __attribute__((noinline)) Probe coop_generic_probe(const PairCtx &c, uint32_t pp) {
-#else
+// (as a real call -- noinline -- the walks' loop shrinks from 4400 to 1500 instructions, but the call's register convention costs more
+// than the code's size: k_coop_cold 4.12 -> 4.32 ms, k_pool_cold 4.37 -> 5.07; profiles/r07_pool/readlane.txt)
 __device__ __forceinline__ Probe coop_generic_probe(const PairCtx &c, uint32_t pp) {
-#endif
 	LWin w;
 	w.q0 = EMPTY, w.dg = NO_DIAG;
 	return lane_probe(c, pp, w);
@@ -588,7 +598,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		nh += (uint32_t)__builtin_popcount(hmask[j]);
 	}
 	uint32_t hbase = wave_scan_add(nh); // (inclusive; made exclusive below)
-	const uint32_t nheads_all = uni((uint32_t)__shfl((int)hbase, 63));
+	const uint32_t nheads_all = lane_read(hbase, 63);
 	hbase -= nh;
 	uint32_t dropped = NOPOS; // the first head beyond the list's capacity: nothing is decided from there on
 #pragma unroll
@@ -792,7 +802,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			}
 		}
 		const bool hop_ok = endk != NOPOS;
-		uint32_t nxtpos = (uint32_t)__shfl_down((int)pos, 1);
+		uint32_t nxtpos = lane_above(pos);
 		if (lane == 63) nxtpos = k + 1 < nheads ? wbase + L.hpos[k + 1] : NOPOS;
 		const bool unusual = valid && (!hop_ok || pos >= F || nxtpos < endk || endk >= F);
 		bool onpath = false;
@@ -811,13 +821,13 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			if (j > lo) {
 				const uint32_t last = (j < 64 ? j : 64u) - 1u;
 				const uint32_t lastv = nheads - base - 1u < last ? nheads - base - 1u : last;
-				hop = base + lastv, cur = uni((uint32_t)__shfl((int)endk, (int)lastv));
+				hop = base + lastv, cur = lane_read(endk, lastv);
 			}
 			if (j >= 64) {
 				kcur = base + 64;
 				break;
 			}
-			const uint32_t pj = uni((uint32_t)__shfl((int)pos, (int)j)), ej = uni((uint32_t)__shfl((int)endk, (int)j));
+			const uint32_t pj = lane_read(pos, j), ej = lane_read(endk, j);
 			if (pj >= F) { // the chain reaches a position where the window's knowledge ends before this head
 				cur = F, done = true;
 			} else if (ej == NOPOS) { // its walk did not land (or where the anchor ends is not in the window): the chain stops at the head
@@ -939,7 +949,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	}
 	{
 		const uint32_t scan = wave_scan_max(before);
-		before = (uint32_t)__shfl_up((int)scan, 1);
+		before = lane_below(scan);
 		if (lane == 0 || before < st.lastQ + 1u) before = st.lastQ + 1u; // (the anchor before e0 starts at lastQ: lastQ - 1 is the position before it)
 	}
 	uint32_t prev_top = 0; // the last position of the word before is in no anchor (what lies before e0 is the anchor)
