@@ -202,6 +202,30 @@ __device__ __forceinline__ Planes ld_subject_planes(const PairCtx &c, int64_t s)
 	r.b0 = __builtin_amdgcn_alignbit(n0, a0, sh), r.b1 = __builtin_amdgcn_alignbit(n1, a1, sh), r.b2 = __builtin_amdgcn_alignbit(n2, a2, sh);
 	return r;
 }
+// The same two fetches as the words come from memory -- no use of a loaded value, so that the loads of round t + 1 stay in flight
+// while round t is worked on (ld_subject_planes shifts its words at once: the wait for them then stands right behind the loads,
+// and sweep S paid the stream's whole latency every round; round 6) -- and what turns them into planes.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+struct RawPlanes { // (whole registers tuples as the loads deliver them: taken apart only where they are used -- a struct of nine words was
+	u32x3_t q;     // copied word by word at the loop's head, with the wait for the loads in front of the copies)
+	u32x4_t a;     // subject block: planes 0, 1, 2 and plane 0 of the next block
+	u32x2_t n;     // planes 1, 2 of the next block
+};
+__device__ __forceinline__ void ld_raw_planes(const PairCtx &c, uint32_t x0, int64_t s, RawPlanes &r) {
+	r.q = *(const __attribute__((address_space(1))) u32x3_t *)(c.Qp + 3 * (x0 >> 5));
+	r.a = (u32x4_t)(~0u), r.n = (u32x2_t)(~0u); // (at and beyond the text's end: NUL, all ones)
+	if (s < (int64_t)c.E.n) {
+		const g_u32p p = c.E.P + 3 * (int32_t)(s >> 5); // (block >= -1: a block of padding lies in front)
+		r.a = *(const __attribute__((address_space(1))) u32x4_t *)p;
+		r.n = *(const __attribute__((address_space(1))) u32x2_t *)(p + 4);
+	}
+}
+__device__ __forceinline__ void planes_of(const RawPlanes &r, uint32_t sh, Planes &q, Planes &s) {
+	q.b0 = r.q.x, q.b1 = r.q.y, q.b2 = r.q.z;
+	s.b0 = __builtin_amdgcn_alignbit(r.a.w, r.a.x, sh), s.b1 = __builtin_amdgcn_alignbit(r.n.x, r.a.y, sh), s.b2 = __builtin_amdgcn_alignbit(r.n.y, r.a.z, sh);
+}
 // the substitutions among the positions `mm` (query symbol != subject symbol, both nucleotides) by kind, into twelve counters:
 // kind k = 3 * (query nucleotide) + (rank of the subject's among the three others) -- no loop over the mismatches, no LDS
 struct SubstAcc {
@@ -277,16 +301,19 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 		SubstAcc acc; // every mismatch a single-position gap (model_count of one position, src/model.c:309-337): sweep R takes back what is not
 #pragma unroll
 		for (int k = 0; k < 12; ++k) acc.n[k] = 0;
-		auto fetch = [&](uint32_t t, Planes &q_, Planes &s_) {
+		// (a lane's subject offset x0 + dg keeps its low five bits from round to round: rounds are 2048 positions apart)
+		const uint32_t sh = (uint32_t)((int64_t)(wbase + WNT * lane) + dg) & 31u;
+		RawPlanes raw;
+		raw.q = (u32x3_t)(0u), raw.a = (u32x4_t)(0u), raw.n = (u32x2_t)(0u);
+		auto fetch = [&](uint32_t t) {
 			const uint32_t x0 = wbase + 2048 * t + WNT * lane;
-			if (t < nchunks && x0 < c.qlen) q_ = ld_query_planes(c, x0), s_ = ld_subject_planes(c, (int64_t)x0 + dg);
+			if (t < nchunks && x0 < c.qlen) ld_raw_planes(c, x0, (int64_t)x0 + dg, raw);
 		};
-		fetch(0, qv, sv);
+		fetch(0);
 		for (uint32_t t = 0; t <= nchunks; ++t) {
 			if (t < nchunks) {
-				Planes qn, sn;
-				qn.b0 = qn.b1 = qn.b2 = sn.b0 = sn.b1 = sn.b2 = 0;
-				fetch(t + 1, qn, sn); // (in flight while this round is worked on)
+				planes_of(raw, sh, qv, sv);
+				fetch(t + 1); // (in flight while this round is worked on)
 				const uint32_t x0 = wbase + 2048 * t + WNT * lane;
 				uint32_t m = ~0u, mc = 0; // positions at and beyond the query's end: lcp() stops there; mc: the mismatches that are counted
 				uint2 codes = make_uint2(0, 0); // (the query's planes b0, b1: what the heads' records are cut from)
@@ -312,7 +339,6 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 						last_mm = uni(wbase + 2048 * t + 32 * l + 31u - (uint32_t)__builtin_clz(ml));
 					}
 				}
-				qv = qn, sv = sn;
 			}
 			wave_sync();
 			if (t >= 1 && heads_on && !PKNOCK(1)) { // the heads of round T: its words and their neighbours are in the ring
@@ -780,6 +806,18 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 		uint32_t carry_before = st.lastQ + 1u; // (the last position in no anchor before the round's words) + 2: the anchor before e0 starts at lastQ
 		uint32_t carry_top = 0;
 		const uint32_t span = (cur < wend ? cur : wend) - wbase; // (behind the window no bit is set)
+		// (the words of round w0 + 256 are fetched while round w0 is counted -- two 8-byte loads past this CU's cache per lane and round:
+		// the stretches were or-ed in at the device's level)
+		typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+		auto load_gapbits = [&](uint32_t w0) {
+			u64x2_t v = (u64x2_t)(0ull);
+			if (32 * w0 < span && w0 + 4 * lane < nwords) {
+				const unsigned long long *ep = (const unsigned long long *)&G->POOL_GAPBITS[w0 + 4 * lane];
+				v.x = __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v.y = __hip_atomic_load(ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			return v;
+		};
+		u64x2_t ev_next = load_gapbits(0);
 		for (uint32_t w0 = 0; 32 * w0 < span && !PKNOCK(3); w0 += 256) {
 			uint32_t u[4], before = 0;
 #ifdef POOL_SEPARATE_EBITS
@@ -787,12 +825,8 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 #else
 			const uint4 mv = make_uint4(0, 0, 0, 0); // (the bits with the stretches in them: ev, read past this CU's cache)
 #endif
-			uint4 ev = make_uint4(0, 0, 0, 0);
-			if (w0 + 4 * lane < nwords) {
-				const uint32_t *ep = &G->POOL_GAPBITS[w0 + 4 * lane];
-				ev.x = __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ev.y = __hip_atomic_load(ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				ev.z = __hip_atomic_load(ep + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ev.w = __hip_atomic_load(ep + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
+			const uint4 ev = make_uint4((uint32_t)ev_next.x, (uint32_t)(ev_next.x >> 32), (uint32_t)ev_next.y, (uint32_t)(ev_next.y >> 32));
+			ev_next = load_gapbits(w0 + 256);
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				const uint32_t w = w0 + 4 * lane + j, x0 = wbase + 32 * w;

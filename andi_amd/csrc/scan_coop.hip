@@ -551,14 +551,33 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	TICK(tph);
 	// ---- the bits: position x of the window against subject position x + dg; the query's symbols as 2-bit codes
 	uint32_t dirty = 0; // a query symbol of the window that is no nucleotide ('!' of joined contigs): the walks then read the query itself
+	// (-DCOOP_STREAM_PIPELINE: the loads of chunk ck + 1 issued before chunk ck is worked on -- the wait for a chunk's loads stands right
+	// behind them otherwise, four memory latencies per window.  Measured no gain, same box: 4.10 against 4.08 ms, three more spilled
+	// registers; profiles/r07_pool/coop_stream_pipeline_ab.txt.  k_pool_cold's sweep S, where the stream is most of the work, keeps its pipeline.)
+#ifdef COOP_STREAM_PIPELINE
+	auto fetch_chunk = [&](int ck, uint4 &q_, uint4 &s_) {
+		const uint32_t x0 = wbase + 2048 * (uint32_t)ck + WNT * lane;
+		if (x0 < c.qlen) q_ = ld_query(c, x0), s_ = ld_subject_guarded(c, (int64_t)x0 + dg);
+	};
+	uint4 qv = make_uint4(0, 0, 0, 0), sv = make_uint4(0, 0, 0, 0);
+	fetch_chunk(0, qv, sv);
+#pragma unroll
+#else
 #pragma unroll 2
+#endif
 	for (int ck = 0; ck < NCH; ++ck) {
+#ifdef COOP_STREAM_PIPELINE
+		uint4 qn = make_uint4(0, 0, 0, 0), sn = make_uint4(0, 0, 0, 0);
+		if (ck + 1 < NCH) fetch_chunk(ck + 1, qn, sn);
+#endif
 		const uint32_t x0 = wbase + 2048 * ck + WNT * lane;
 		uint32_t m = ~0u; // positions at and beyond the query's end: lcp() stops there
 		uint2 codes = make_uint2(0, 0);
 		if (x0 < c.qlen) {
-			const uint4 qv = ld_query(c, x0);
-			m = squeeze32(neq32(qv, ld_subject_guarded(c, (int64_t)x0 + dg)));
+#ifndef COOP_STREAM_PIPELINE
+			const uint4 qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
+#endif
+			m = squeeze32(neq32(qv, sv));
 			codes = make_uint2(squeeze_codes(qv.x) | (squeeze_codes(qv.y) << 16), squeeze_codes(qv.z) | (squeeze_codes(qv.w) << 16));
 			if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0);
 			dirty |= (qv.x | qv.y | qv.z | qv.w) & 0x44444444u; // bit 2 of a symbol: no nucleotide (the padding behind the query's end too: its last window's walks read the query itself)
@@ -567,6 +586,9 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		if (x0 + WNT <= e0) m = 0;
 		L.mbits[64 * ck + lane] = m;
 		*(uint2 *)&L.q2[2 * (64 * ck + lane)] = codes;
+#ifdef COOP_STREAM_PIPELINE
+		qv = qn, sv = sn;
+#endif
 	}
 	const bool clean = !__any(dirty != 0);
 	if (lane < 4) L.q2[128 * NCH + lane] = 0;
