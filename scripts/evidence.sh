@@ -6,7 +6,7 @@
 # usage: scripts/evidence.sh <tag>          (then copy gpurun_out/<tag>_* into profiles/)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
-tag=${1:-r06}
+tag=${1:-r07}
 mkdir -p gpurun_out
 timeout 1800 python3 -m pytest tests -q -m gpu 2>&1 | tail -3 > gpurun_out/${tag}_pytest.txt
 shapes=("headline" "c4shape --genomes 3085 --subjects 8 --length 2100000 --dlo 0.001 --dhi 0.015" "tree --set tree" "realistic --set realistic")
