@@ -489,7 +489,13 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 					const uint32_t r = run_ahead(p, seen);
 					have = coop_probe_multi<false>(c, p, sd, mx, mn, mq, r, seen, pr, long_diag); // (the sorter's records -- k_coop_cold's first try -- cost this kernel 12 more spilled registers: C4 shape 24.7 -> 28.9 ms)
 				}
+#ifdef POOL_NO_GENERIC
+				// (experiment: a probe that needs lane_probe ends the window at its head -- W_BREAK, always a legal outcome: the chain goes
+				// on in mode G there -- so that this loop, the kernel's widest in registers, does not carry lane_probe's)
+				if (!have) res = W_BREAK, ra = p, long_diag = false;
+#else
 				if (!have) pr = generic_probe(p), long_diag = false;
+#endif
 				have = true, parked = false;
 #ifdef ANDI_COOP_STATS
 				atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
@@ -500,7 +506,11 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 						res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
 						ra = p;
 					} else {
+#ifdef POOL_NO_GENERIC
+						res = W_BREAK, ra = p;
+#else
 						pr = generic_probe(p);
+#endif
 					}
 				}
 			} else {
