@@ -27,20 +27,22 @@ constexpr uint32_t POOL_CHUNK_HEADS = 128;      // heads of one round of 2048 po
 struct __attribute__((aligned(16))) PoolRec { // what a head's walk reads
 	uint32_t q2[4];   // the query's symbols at positions pos + 1 ... pos + 64, bit-sliced: [0], [1] = bit 0 of the 64 symbols, [2], [3] = bit 1
 	uint32_t bits[2]; // the mismatch bits of those positions
-	uint32_t pos, pad;
+	uint32_t pos, dirty; // dirty: one of those 64 query symbols is no nucleotide ('!' of joined contigs): the walk's probes from the record go the long way
 };
 struct __attribute__((aligned(16))) PoolRes { // what it found
 	uint32_t pos, ha, hend, flag; // the head; landing position; length of the anchor landed on (W_LUCKY: not known); pool_pack_flag(W_* flags, equal symbols of the stretch)
 };
-// The flag word of a result: bits 0-4 the W_* status bits, 5-7 the anchors met off the diagonal (W_NX_SHIFT), 8-31 the equal
-// symbols of an ordinary stretch of at most POOL_EQ_MAX positions by nucleotide, six bits each (the walk has the head's record in
-// registers when it ends; until round 6 sweep R fetched every record a second time for them: 32 bytes per head)
-constexpr uint32_t POOL_EQ_MAX = 63;
-__device__ __forceinline__ uint32_t pool_pack_flag(uint32_t res, uint32_t eq) {
-	return (res & 0x1fu) | (((res >> W_NX_SHIFT) & 7u) << 5) | (eq << 8);
+// The flag word of a result: bits 0-4 the W_* status bits, 5-6 the anchors met off the diagonal (W_NX_SHIFT; at most COOP_MAX_X = 3),
+// bit 7: bits 8-31 hold the equal symbols of the walk's stretch by nucleotide, six bits each -- an ordinary stretch of at most
+// POOL_EQ_MAX positions inside a record without separators (the walk has the head's record in registers when it ends; until
+// round 6 sweep R fetched every record a second time for them: 32 bytes per head)
+constexpr uint32_t POOL_EQ_MAX = 63, POOL_EQ_VALID = 0x80u;
+static_assert(COOP_MAX_X <= 3, "two bits of the packed flag");
+__device__ __forceinline__ uint32_t pool_pack_flag(uint32_t res, uint32_t eq, bool eq_valid) {
+	return (res & 0x1fu) | (((res >> W_NX_SHIFT) & 3u) << 5) | (eq_valid ? POOL_EQ_VALID : 0u) | (eq << 8);
 }
 __device__ __forceinline__ uint32_t pool_flag_of(uint32_t w) {
-	return (w & 0x1fu) | (((w >> 5) & 7u) << W_NX_SHIFT);
+	return (w & 0x1fu) | (((w >> 5) & 3u) << W_NX_SHIFT);
 }
 struct PoolScratch { // a window's scratch in global memory, one per resident wavefront
 	uint32_t *bits;  // [64 maxchunks + 64] bit (x - wbase): query symbol x != subject symbol x + dg
@@ -74,6 +76,7 @@ __device__ __forceinline__ PoolScratch pool_scratch_at(void *base, size_t idx, u
 struct PoolLds {
 	uint32_t mring[256];          // sweep S: the bits of the last four rounds (word w at w & 255)
 	uint32_t qring[512];          // and the query's 2-bit codes (two words per word of bits)
+	uint32_t dring[256];          // ... and which of its symbols are no nucleotides (joined contigs' '!'): for the heads' records
 	uint16_t hl[POOL_CHUNK_HEADS]; // the heads of a round, offsets into it
 	uint32_t pl[64], pp[64]; // mode G: the block of probes
 	uint32_t hist[16];
@@ -317,19 +320,22 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 				const uint32_t x0 = wbase + 2048 * t + WNT * lane;
 				uint32_t m = ~0u, mc = 0; // positions at and beyond the query's end: lcp() stops there; mc: the mismatches that are counted
 				uint2 codes = make_uint2(0, 0); // (the query's planes b0, b1: what the heads' records are cut from)
+				uint32_t dirty_w = 0;           // the word's query symbols that are no nucleotides
 				if (x0 < c.qlen) {
 					m = (qv.b0 ^ sv.b0) | (qv.b1 ^ sv.b1) | (qv.b2 ^ sv.b2);
 					codes = make_uint2(qv.b0, qv.b1);
 					mc = m & ~(qv.b2 | sv.b2); // both nucleotides (src/model.c:318-320)
 					uint32_t inq = ~0u;
 					if (c.qlen - x0 < WNT) inq = ~(~0u << (c.qlen - x0)), m |= ~inq, mc &= inq;
-					dirty |= qv.b2 & inq;
+					dirty_w = qv.b2 & inq;
+					dirty |= dirty_w;
 				}
 				if (x0 <= e0 && e0 - x0 < WNT) m &= ~0u << (e0 - x0), mc &= ~0u << (e0 - x0); // (what lies before the anchor is none of the window's business)
 				if (x0 + WNT <= e0) m = 0, mc = 0;
 				G->bits[64 * t + lane] = m;
 				L.mring[(64 * t + lane) & 255u] = m;
 				*(uint2 *)&L.qring[(2 * (64 * t + lane)) & 511u] = codes;
+				L.dring[(64 * t + lane) & 255u] = dirty_w;
 				if (!PKNOCK(0)) subst_count(acc, mc, qv, sv);
 				{
 					const uint64_t any = __ballot(m != 0);
@@ -390,7 +396,8 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 								rc.q2[0] = __builtin_amdgcn_alignbit(c2, c0, sh), rc.q2[1] = __builtin_amdgcn_alignbit(c4, c2, sh);
 								rc.q2[2] = __builtin_amdgcn_alignbit(c3, c1, sh), rc.q2[3] = __builtin_amdgcn_alignbit(c5, c3, sh);
 								rc.bits[0] = __builtin_amdgcn_alignbit(r1, r0, sh), rc.bits[1] = __builtin_amdgcn_alignbit(r2, r1, sh);
-								rc.pos = e, rc.pad = 0;
+								rc.pos = e;
+								rc.dirty = L.dring[wq & 255u] | L.dring[(wq + 1) & 255u] | L.dring[(wq + 2) & 255u]; // (a separator in the three words the record is cut from: a superset of its 64 positions' own is enough)
 								G->rec[rbase + i] = rc;
 							}
 							const uint64_t okm = __ballot(ok), bad = __ballot(valid && !ok);
@@ -436,6 +443,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 		uint32_t hk = NOPOS, e = 0, p = 0, Xq = 0, Xs = 0, Xl = 0, nX = 0, next_head = 0;
 		uint32_t mx = 0, mn = 0, mq = 0;
 		uint32_t cq0 = 0, cq1 = 0, cq2 = 0, cq3 = 0, cb0 = 0, cb1 = 0; // the head's record
+		bool hclean = true;                                            // ... holds no separator (a window without one: every record)
 		bool parked = false;
 		// equal symbols from pp on along the diagonal as far as 32 bits show; seen: a mismatch of the window ends them
 		auto run_ahead = [&](uint32_t pp, bool &seen) {
@@ -463,6 +471,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 					const PoolRec rc = G->rec[my];
 					hk = my, e = rc.pos, p = e + 1, Xl = 0, nX = 0, parked = false;
 					cq0 = rc.q2[0], cq1 = rc.q2[1], cq2 = rc.q2[2], cq3 = rc.q2[3], cb0 = rc.bits[0], cb1 = rc.bits[1];
+					hclean = clean || rc.dirty == 0;
 				}
 				next_head += (uint32_t)__builtin_popcountll(idle);
 			}
@@ -489,13 +498,10 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 					const uint32_t r = run_ahead(p, seen);
 					have = coop_probe_multi<false>(c, p, sd, mx, mn, mq, r, seen, pr, long_diag); // (the sorter's records -- k_coop_cold's first try -- cost this kernel 12 more spilled registers: C4 shape 24.7 -> 28.9 ms)
 				}
-#ifdef POOL_NO_GENERIC
-				// (experiment: a probe that needs lane_probe ends the window at its head -- W_BREAK, always a legal outcome: the chain goes
-				// on in mode G there -- so that this loop, the kernel's widest in registers, does not carry lane_probe's)
-				if (!have) res = W_BREAK, ra = p, long_diag = false;
-#else
+				// (measured: without lane_probe in this loop -- such a probe ending the window at its head instead -- the kernel fits 64 registers
+				// with 19 spilled, but eight wavefronts per SIMD are no faster than six at equal work, and the windows cut short cost
+				// sweep S five times over: profiles/r07_pool/no_generic_probe_occupancy.txt)
 				if (!have) pr = generic_probe(p), long_diag = false;
-#endif
 				have = true, parked = false;
 #ifdef ANDI_COOP_STATS
 				atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
@@ -506,11 +512,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 						res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
 						ra = p;
 					} else {
-#ifdef POOL_NO_GENERIC
-						res = W_BREAK, ra = p;
-#else
 						pr = generic_probe(p);
-#endif
 					}
 				}
 			} else {
@@ -539,19 +541,25 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 					bool on_diag = false;
 					mn = 0;
 					have = false;
-					if (clean && p + 32 <= c.qlen && o + 32 <= Wp) {
+					// (joined contigs -- a window with separators: round 5 sent EVERY probe of such a window to lane_probe, and a set of
+					// 100-contig assemblies scanned at half the speed of the same genomes whole; now only a record / a fetch that holds one)
+					if (p + 32 <= c.qlen && o + 32 <= Wp) {
 						const uint32_t oc = p - (e + 1);
-						uint32_t lo, hi;
+						uint32_t lo = 0, hi = 0;
+						bool codes_ok;
 						if (oc <= 36) {
 							// the record holds the symbols bit-sliced: bit 0 and bit 1 of the 32 from p on, interleaved to 2-bit codes
 							const uint32_t pa = (uint32_t)((((uint64_t)cq1 << 32) | cq0) >> oc), pb = (uint32_t)((((uint64_t)cq3 << 32) | cq2) >> oc);
 							lo = spread16(pa) | (spread16(pb) << 1), hi = spread16(pa >> 16) | (spread16(pb >> 16) << 1);
+							codes_ok = hclean;
 						} else {
 							const uint4 qv = ld_query(c, p & ~1u); // 32 symbols from an even position on
 							const uint32_t s0 = squeeze_codes(qv.x) | (squeeze_codes(qv.y) << 16), s1 = squeeze_codes(qv.z) | (squeeze_codes(qv.w) << 16);
 							lo = __builtin_amdgcn_alignbit(s1, s0, 2 * (p & 1u)), hi = s1 >> (2 * (p & 1u)); // (31 symbols are enough: K + 16 <= 29)
+							codes_ok = clean || ((qv.x | qv.y | qv.z | qv.w) & 0x44444444u) == 0;
 						}
-						have = coop_probe_codes(c, p, sd, lo, hi, pr, on_diag, mx, mn, mq);
+						if (codes_ok) have = coop_probe_codes(c, p, sd, lo, hi, pr, on_diag, mx, mn, mq);
+						else WHY(CS_WHY_PRE);
 					} else {
 						WHY(CS_WHY_PRE);
 					}
@@ -590,9 +598,11 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 				if ((res & W_LUCKY) && (ra + sd < c.border) != (e + sd <= c.border)) res = W_BREAK;
 				// the equal symbols of the stretch (e, ra) by nucleotide, for sweep R: from the record, if the stretch lies inside it
 				uint32_t eq = 0;
+				bool eq_valid = false;
 				{
 					const uint32_t len = ra - e - 1;
-					if ((res & W_STATUS) == W_OK && !(res & W_HADX) && clean && len - 1u < POOL_EQ_MAX) {
+					if ((res & W_STATUS) == W_OK && !(res & W_HADX) && hclean && len - 1u < POOL_EQ_MAX) {
+						eq_valid = true;
 						uint32_t eqlo = ~cb0, eqhi = ~cb1; // the equal positions among the len <= 63 behind the head
 						if (len < 32) eqlo &= (1u << len) - 1u, eqhi = 0;
 						else eqhi &= (1u << (len - 32)) - 1u;
@@ -604,7 +614,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 					}
 				}
 				PoolRes rs;
-				rs.pos = e, rs.ha = ra, rs.hend = rlen, rs.flag = pool_pack_flag(res, eq);
+				rs.pos = e, rs.ha = ra, rs.hend = rlen, rs.flag = pool_pack_flag(res, eq, eq_valid);
 				G->res[hk] = rs;
 				hk = NOPOS;
 			}
@@ -677,6 +687,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 		rs.pos = NOPOS, rs.ha = 0, rs.hend = 0, rs.flag = 0;
 		if (valid) rs = G->res[k];
 		const uint32_t pos = rs.pos, fl = pool_flag_of(rs.flag), la = rs.ha, eqw = rs.flag >> 8; // (eqw: the stretch's equal symbols, from the walk)
+		const bool eq_valid = (rs.flag & POOL_EQ_VALID) != 0;
 		// Where the anchor the walk landed on ends is the chain's next stand.  A probe's anchor: the result says; a lucky anchor's end
 		// is the next mismatch behind the landing -- looked up only where it matters: the next head, a mismatch itself, bounds it
 		const bool landed = (fl & W_STATUS) == W_OK, lucky = landed && (fl & W_LUCKY);
@@ -761,7 +772,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 				// longer than a record (one head in thirty) with all lanes, one after the other -- a lane's own loop over their text
 				// was run by every round of 64 heads
 				const uint32_t len = la - pos - 1;
-				const bool ord = onpath && !(fl & W_HADX) && len != 0, fast = ord && clean && len <= POOL_EQ_MAX; // (fast: the walk counted them, as pool_pack_flag says)
+				const bool ord = onpath && !(fl & W_HADX) && len != 0, fast = ord && eq_valid; // (fast: the walk counted them, as pool_pack_flag says)
 				if (fast && !PKNOCK(8)) eq0 += eqw & 63u, eq1 += (eqw >> 6) & 63u, eq2 += (eqw >> 12) & 63u, eq3 += (eqw >> 18) & 63u;
 				for (uint64_t sl = PKNOCK(9) ? 0ull : __ballot(ord && !fast); sl; sl &= sl - 1) {
 					const uint32_t l = (uint32_t)__builtin_ctzll(sl);
@@ -930,18 +941,35 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, cons
 	CSTAT(CS_SEGMENTS, 1);
 	TICK(tall);
 	uint32_t same[4] = {0, 0, 0, 0}; // equal pairs the windows found in gaps, by nucleotide
+	// How long the next window should be (rounds of 2048 positions): sweep S streams a window to its end before anything is known
+	// about it, so a window that ends early -- the chain leaves its diagonal: an indel, the separator of a joined contig -- has
+	// streamed the rest for nothing.  A window the chain went through doubles the next one; one it did not go through sets the next to
+	// what it covered (as a power of two, four rounds at least).  Round 5 always began again at the longest window: genomes of 100
+	// contigs each (a diagonal every 10 000 positions) scanned 17 times slower than the same genomes whole -- 384 against 20 ms for the
+	// C4 shape -- and now 2.2 times (profiles/r07_pool/join_ab.txt).  The hint outlives the windows' loop: mode G takes over at every
+	// break, and the windows behind it begin where the last ones left off.
+	uint32_t hint_chunks = a.pool_first;
 	// windows one after the other while the chain stays canonical on the diagonal and moves; false: the pair was handed back
 	auto windows = [&]() {
 		// (behind an anchor of thousands of symbols the next mismatch is far: genomes 1e-5 apart -- a window finds one or two, and nothing is
 		// decided behind the last: short windows first)
-		uint32_t chunks = st.lastLen >= 4096 ? 4u : a.pool_first;
+		uint32_t chunks = st.lastLen >= 4096 ? 4u : hint_chunks;
 		bool through = false;
 		for (;;) {
 			if (!(st.p < end && st.lastQ + st.lastLen < c.qlen)) break;
+			const uint32_t from = st.lastQ + st.lastLen;
 			pool_stream(a, c, ch, L, G, end, chunks, pw);
-			if (!pool_resolve(a, c, ch, L, G, end, pw, through, same)) break;
+			const bool moved = pool_resolve(a, c, ch, L, G, end, pw, through, same);
+			if (moved && through) {
+				chunks = 2 * chunks < G->maxchunks ? 2 * chunks : G->maxchunks;
+			} else {
+				const uint32_t covered = moved ? st.p - from : 0u;
+				chunks = 4;
+				while (chunks < G->maxchunks && 2048u * chunks < covered) chunks *= 2;
+			}
+			hint_chunks = chunks;
+			if (!moved) break;
 			if (given_up()) return false;
-			chunks = !through ? a.pool_first : 2 * chunks < G->maxchunks ? 2 * chunks : G->maxchunks;
 		}
 		return true;
 	};

@@ -53,6 +53,8 @@ def parse():
                          "both strands, indels, inversions, unrelated islands (andi_amd/synth.py: realistic_set); tree: "
                          "substitutions along a random tree, pairwise distances 4.4e-4 ... 2.6e-2 (tree_set)")
     ap.add_argument("--model", choices=("raw", "jc", "kimura"), default="jc", help="the estimator's model (andi -m): what the counts are made for")
+    ap.add_argument("--contigs", type=int, default=0, help="every genome cut into that many contigs joined by '!' (andi --join, src/sequence.c:78-125: "
+                                                           "what multi-contig assemblies like BASELINE's Maela set look like to the scan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (structured genomes, tree-structured set)")
     ap.add_argument("--seam-child", default="", help=argparse.SUPPRESS)  # internal: the multi-GPU seam in a process of its own
@@ -343,6 +345,8 @@ def main():
     p_value = 0.025
     t_gen = time.time()
     seqs = make_set(args.set, G, args.length, args.dlo, args.dhi, args.seed)
+    if args.contigs > 1:  # the same genomes as joined contigs: separators in subjects and queries
+        seqs = [synth.join_contigs(sq, args.contigs, seed=args.seed + 7 * k) for k, sq in enumerate(seqs)]
     t_gen = time.time() - t_gen
 
     S = args.subjects if 0 < args.subjects <= G else G  # subject rows of the job
@@ -455,7 +459,7 @@ def main():
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload_name(args.set, G, S, args.length, args.dlo, args.dhi, args.seed, world, model),
+            "config": {"workload": workload_name(args.set, G, S, args.length, args.dlo, args.dhi, args.seed, world, model) + (", every genome as %d contigs joined by '!' (--join)" % args.contigs if args.contigs > 1 else ""),
                        "genomes": G, "subjects": S, "length": args.length, "model": MODEL_NAMES[model], "pairs": pairs_total,
                        "segment": args.segment or ("auto (pass A routed per pair: by wavefronts on segments of 32768 ... 524288 symbols (shorter in small calls), by lanes on segments chosen per pair, 2048 ... 16384)" if tm["routed_calls"] else "auto (chosen per pair from its sampled match lengths: 2048 ... 16384)")},
             "roofline": {"bound": "hbm", "kernel": scan_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -591,7 +595,7 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and world == 1 and not args.no_extra and args.set == "star" and not args.subjects:
+    if rank == 0 and world == 1 and not args.no_extra and args.set == "star" and not args.subjects and not args.contigs:
         out.setdefault("extra", {}).update({
             "realistic": secondary("realistic", args, model, p_value),
             "tree_structured": secondary("tree", args, model, p_value),
