@@ -178,6 +178,7 @@ struct andi_hip_queries {
 	int32_t *h_foreign = nullptr; // pinned: set if the pool holds bytes outside the alphabet
 	uint64_t *d_off = nullptr;
 	uint32_t *d_len = nullptr;
+	uint32_t *d_sep = nullptr;    // contig separators of every sequence (k_sep_counts: for the routing of the scan)
 	std::vector<uint64_t> off;
 	std::vector<uint32_t> len;
 	size_t nq = 0;
@@ -999,6 +1000,17 @@ size_t andi_hip_esa_bytes(const andi_hip_esa *e) {
 }
 
 // ------------------------------------------------------------------ queries
+// the contig separators of every staged sequence (d_off, d_len and the byte pool are queued on the stream): one pass over the pool
+static hipError_t queries_count_separators(andi_hip_ctx *ctx, andi_hip_queries *q) {
+	hipError_t err = dmalloc(&q->d_sep, q->nq);
+	if (err != hipSuccess) return err;
+	uint32_t longest = 0;
+	for (uint32_t l : q->len) longest = std::max(longest, l);
+	err = hipMemsetAsync(q->d_sep, 0, q->nq * sizeof(uint32_t), ctx->stream);
+	if (err == hipSuccess) err = andi_launch_sep_counts(q->pool, q->d_off, q->d_len, (uint32_t)q->nq, longest, q->d_sep, ctx->stream);
+	return err;
+}
+
 int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n,
 						   andi_hip_queries **out) {
 	if (!ctx || !seqs || !out || n == 0 || n >= (size_t)UINT32_MAX) {
@@ -1048,6 +1060,7 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 	if (err == hipSuccess)
 		err = andi_launch_pack_symbols(q->pool, pool_bytes, q->nib, nullptr, d_foreign, ctx->stream);
 	if (err == hipSuccess) err = andi_launch_pack_planes(q->nib, pool_bytes, q->planes, ctx->stream);
+	if (err == hipSuccess) err = queries_count_separators(ctx, q);
 	if (err == hipSuccess)
 		err = hipMemcpyAsync(q->h_foreign, d_foreign, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
 	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
@@ -1065,7 +1078,7 @@ void andi_hip_queries_free(andi_hip_ctx *ctx, andi_hip_queries *q) {
 	if (!q) return;
 	if (ctx) (void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize();
-	void *bufs[] = {q->pool, q->nib, q->planes, q->d_off, q->d_len, q->d_qseg_start, q->d_seg2query, q->c_qseg_start, q->c_seg2query};
+	void *bufs[] = {q->pool, q->nib, q->planes, q->d_off, q->d_len, q->d_sep, q->d_qseg_start, q->d_seg2query, q->c_qseg_start, q->c_seg2query};
 	for (void *b : bufs) (void)andi_arena::dev_free(b, false);
 	host_pool::word_put(q->h_foreign);
 	delete q;
@@ -1213,6 +1226,7 @@ static int queries_stage_packed(andi_hip_ctx *ctx, const PackedQueries &P, andi_
 	if (err == hipSuccess) err = andi_launch_pack_planes(q->nib, P.pool_bytes, q->planes, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(q->d_off, q->off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess) err = hipMemcpyAsync(q->d_len, q->len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+	if (err == hipSuccess) err = queries_count_separators(ctx, q);
 	if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
 	if (err != hipSuccess) {
 		andi_hip_queries_free(ctx, q);
@@ -1457,7 +1471,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	a.subjects = (const EsaDev *)ctx->desc_dev;
 	a.self = (const int64_t *)((const EsaDev *)ctx->desc_dev + nsub);
 	a.nsub = (uint32_t)nsub;
-	a.qpool = q->pool, a.qnib = q->nib, a.qplanes = q->planes, a.qoff = q->d_off, a.qlen = q->d_len, a.nq = (uint32_t)q->nq;
+	a.qpool = q->pool, a.qnib = q->nib, a.qplanes = q->planes, a.qoff = q->d_off, a.qlen = q->d_len, a.qsep = q->d_sep, a.nq = (uint32_t)q->nq;
 	a.qseg_start = q->d_qseg_start, a.seg2query = q->d_seg2query;
 	a.total_segs = q->total_segs, a.seg = segment;
 	char *p = (char *)ctx->scratch;

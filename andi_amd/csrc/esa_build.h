@@ -60,3 +60,6 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, int single_ext, hipStr
 hipError_t andi_launch_rs_from_query(uint8_t *RS, const uint8_t *q, uint32_t len, hipStream_t st);
 hipError_t andi_launch_gc_counts(const uint8_t *pool, const uint64_t *d_off, const uint32_t *d_len, uint32_t nq, uint32_t longest,
 								 unsigned long long *d_counts, hipStream_t st);
+// contig separators ('!') per sequence of a pool (counts zeroed by the caller)
+hipError_t andi_launch_sep_counts(const uint8_t *pool, const uint64_t *d_off, const uint32_t *d_len, uint32_t nq, uint32_t longest,
+								  uint32_t *d_counts, hipStream_t st);

@@ -734,6 +734,42 @@ __global__ __launch_bounds__(256) void k_gc_counts(const uint8_t *__restrict__ p
 	if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(&counts[qi], (unsigned long long)cnt);
 }
 
+// contig separators ('!', joined contigs: src/sequence.c:78-125) of every sequence of the pool: every one is a place where the diagonal
+// of a pair breaks -- the routing of the scan wants to know how often (scan_lane.hip: k_pair_estimate)
+__global__ __launch_bounds__(256) void k_sep_counts(const uint8_t *__restrict__ pool, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+													 uint32_t *__restrict__ counts) {
+	const uint32_t qi = blockIdx.y, L = len[qi];
+	const uint64_t c0 = (uint64_t)blockIdx.x * GC_CHUNK;
+	if (c0 >= L) return;
+	const uint8_t *s = pool + off[qi];
+	const uint64_t c1 = c0 + GC_CHUNK < L ? c0 + GC_CHUNK : L;
+	uint32_t cnt = 0;
+	for (uint64_t p = c0 + 16ull * threadIdx.x; p < c1; p += 16ull * 256) {
+		const uint4 v = *(const uint4 *)(s + p);
+		const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			// bytes below 'A' (0x41) inside the sequence are separators; a zero-byte test on (w & 0xc0c0c0c0) would count NULs too, but
+			// the sequence holds none before its end: positions at and beyond c1 are masked
+#pragma unroll
+			for (int b = 0; b < 4; ++b) cnt += (p + 4 * j + b < c1) && (((ws[j] >> (8 * b)) & 0xffu) == (uint32_t)'!');
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+	if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(&counts[qi], cnt);
+}
+
+hipError_t andi_launch_sep_counts(const uint8_t *pool, const uint64_t *d_off, const uint32_t *d_len, uint32_t nq, uint32_t longest,
+								  uint32_t *d_counts, hipStream_t st) {
+	if (!nq || !longest) return hipSuccess;
+	for (uint32_t q0 = 0; q0 < nq; q0 += 65535u) {
+		const uint32_t cnt = nq - q0 < 65535u ? nq - q0 : 65535u;
+		k_sep_counts<<<dim3((longest + GC_CHUNK - 1) / GC_CHUNK, cnt), 256, 0, st>>>(pool, d_off + q0, d_len + q0, d_counts + q0);
+		CHECK_LAUNCH();
+	}
+	return hipSuccess;
+}
+
 hipError_t andi_launch_rs_from_query(uint8_t *RS, const uint8_t *q, uint32_t len, hipStream_t st) {
 	const uint64_t words = (2 * (uint64_t)len + 1 + 3) / 4;
 	k_rs_from_query<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(RS, q, len);

@@ -40,6 +40,7 @@ struct ScanArgs {
 	const uint32_t *qplanes; // the pool bit-sliced (andi_dev.h: EsaDev.P): sequence q starts at block qoff[q] / 32
 	const uint64_t *qoff; // [nq]
 	const uint32_t *qlen; // [nq]
+	const uint32_t *qsep; // [nq] contig separators ('!') of every query, or null (k_sep_counts; the routing keeps pairs whose diagonals break often away from the wavefront kernels)
 	uint32_t nq;
 	// segmentation of the queries into work items
 	const uint32_t *qseg_start; // [nq+1]

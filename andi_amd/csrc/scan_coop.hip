@@ -81,7 +81,6 @@ struct CoopLds {
 		uint32_t ebits[64 * NCH];   // once they are done: the stretches behind the heads the chain came by, [head, landing): counted as gaps -- except
 	};
 	uint32_t kpos[COOP_KCAP];     // those that start at one of these positions (the walk met anchors off the diagonal): counted nowhere
-	uint32_t dwords[2 * NCH];     // bit w: the window's word w (positions 32 w ...) holds a query symbol that is no nucleotide ('!' of joined contigs)
 	uint32_t nhadx;               // walks of the window that ended that way (at most COOP_KCAP: the others give up)
 	union {
 		struct {
@@ -387,17 +386,12 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 												uint32_t &multi_x, uint32_t &multi_n, uint32_t &multi_q) {
 	on_diag = false, multi_n = 0;
 	const uint32_t o = p - wbase;
-	if (!(o + 32 <= 2048 * NCH && p + 32 <= c.qlen)) {
+	// (a window with a separator -- joined contigs: every probe of it goes the long way.  Per-word flags in LDS were built and measured
+	// in round 6: 1 % faster on genomes of 100 contigs, 1.7 % slower on whole ones -- profiles/r07_pool/join_ab.txt; k_pool_cold, whose
+	// windows are sixteen times as long, keeps a flag per head's record)
+	if (!(clean && o + 32 <= 2048 * NCH && p + 32 <= c.qlen)) {
 		WHY(CS_WHY_PRE);
 		return false;
-	}
-	if (!clean) { // (joined contigs: the window holds separators -- the 32 symbols from p on lie in two of its words: both without one?  Round 5
-		// sent EVERY probe of such a window to lane_probe: a set of 100-contig assemblies scanned at half the speed of the same genomes whole)
-		const uint32_t w = o >> 5, w2 = (o & 31u) ? w + 1 : w, d0 = L.dwords[w >> 5], d1 = L.dwords[w2 >> 5];
-		if (((d0 >> (w & 31u)) | (d1 >> (w2 & 31u))) & 1u) {
-			WHY(CS_WHY_PRE);
-			return false;
-		}
 	}
 	const uint32_t j = o >> 4, sh = 2 * (o & 15u);
 	const uint32_t w0 = L.q2[j], w1 = L.q2[j + 1], w2 = L.q2[j + 2];
@@ -582,7 +576,6 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		const uint32_t x0 = wbase + 2048 * ck + WNT * lane;
 		uint32_t m = ~0u; // positions at and beyond the query's end: lcp() stops there
 		uint2 codes = make_uint2(0, 0);
-		uint32_t dirty_w = 0; // this lane's word of the chunk holds a symbol that is no nucleotide
 		if (x0 < c.qlen) {
 #ifndef COOP_STREAM_PIPELINE
 			const uint4 qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
@@ -590,17 +583,12 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			m = squeeze32(neq32(qv, sv));
 			codes = make_uint2(squeeze_codes(qv.x) | (squeeze_codes(qv.y) << 16), squeeze_codes(qv.z) | (squeeze_codes(qv.w) << 16));
 			if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0);
-			dirty_w = (qv.x | qv.y | qv.z | qv.w) & 0x44444444u; // bit 2 of a symbol: no nucleotide (the padding behind the query's end too: its last window's walks read the query itself)
-			dirty |= dirty_w;
+			dirty |= (qv.x | qv.y | qv.z | qv.w) & 0x44444444u; // bit 2 of a symbol: no nucleotide (the padding behind the query's end too: its last window's walks read the query itself)
 		}
 		if (x0 <= e0 && e0 - x0 < WNT) m &= ~0u << (e0 - x0); // (what lies before the anchor is none of the window's business)
 		if (x0 + WNT <= e0) m = 0;
 		L.mbits[64 * ck + lane] = m;
 		*(uint2 *)&L.q2[2 * (64 * ck + lane)] = codes;
-		{ // (which words of the chunk hold a separator: two words of LDS per chunk, read only by the probes of a window that has one)
-			const uint64_t dm = __ballot(dirty_w != 0);
-			if (lane == 0) L.dwords[2 * ck] = (uint32_t)dm, L.dwords[2 * ck + 1] = (uint32_t)(dm >> 32);
-		}
 #ifdef COOP_STREAM_PIPELINE
 		qv = qn, sv = sn;
 #endif

@@ -80,7 +80,17 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 	const bool quad_cand = (sum >> 6) >= a.quad_min_match && (sum >> 6) < ANDI_ISLAND_MEAN_MAX && a.quad_min_match != 0;
 	// routed calls: would the pair suit pass A by wavefronts?  (one whole segment of that kernel's at least)
 	// (one whole segment of that kernel's at least, or a query of a few windows: with many short queries a wavefront's chain is a query)
-	const bool coop_cand = a.route && (sum >> 6) < 512u && c.qlen >= (a.route_seg < ANDI_ROUTE_MIN_QLEN ? a.route_seg : ANDI_ROUTE_MIN_QLEN); // (matches of 512 symbols and more on average: k_lane_quad's, always)
+	// Joined contigs: every separator of the query or of the subject ends the pair's diagonal (the genomes' contigs are cut at different
+	// places), and a wavefront kernel pays a window for every end.  C4 shape of genomes of 100 / 20 contigs, per call: k_pool_cold 117 / 48 ms,
+	// k_coop_cold 87 / 37, the lane scan 54 / 44 (whole genomes: 20 by k_pool_cold); bench set of 100-contig genomes (an end every 24 500
+	// positions): lanes 8.2, k_coop_cold 9.5 ms.  So by the mean distance between the ends: below 32768 positions the lane scan, below
+	// 131072 -- a window of k_pool_cold -- no candidate of that kernel (profiles/r07_pool/join_routing.txt).
+	uint32_t break_dist = ~0u;
+	if (a.qsep && a.self[sub] >= 0) {
+		const uint32_t ends = a.qsep[qidx] + a.qsep[(uint32_t)a.self[sub]];
+		if (ends) break_dist = c.qlen / ends;
+	}
+	const bool coop_cand = a.route && (sum >> 6) < 512u && c.qlen >= (a.route_seg < ANDI_ROUTE_MIN_QLEN ? a.route_seg : ANDI_ROUTE_MIN_QLEN) && break_dist >= 32768u; // (matches of 512 symbols and more on average: k_lane_quad's, always)
 	if (coop_cand) { // (wave-uniform)
 		// Unrelated stretches are contiguous: where a sample sees less than a threshold's worth of matching symbols, four
 		// more are taken, 128 symbols apart.  Five short ones in a row come about by chance at the fifth power of the rate of
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 		const bool quad = (sum >> 6) >= a.quad_min_match && !(islands && (sum >> 6) < ANDI_ISLAND_MEAN_MAX);
 		a.pair_class[pair] = (uint8_t)(cls | (quad ? 0x80u : 0u) | (coop_cand && !islands ? ANDI_ROUTE_COOP : 0u) | (soft ? ANDI_ROUTE_SOFT : 0u) |
 										 (coop_cand && islands ? ANDI_ROUTE_LEFT : 0u) | (coop_cand && guess ? ANDI_ROUTE_GUESS : 0u) |
-										 (a.route && (sum >> 6) >= a.pool_match && (sum >> 6) < 4096u ? ANDI_ROUTE_POOLCAND : 0u));
+										 (a.route && (sum >> 6) >= a.pool_match && (sum >> 6) < 4096u && break_dist >= 131072u ? ANDI_ROUTE_POOLCAND : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
 		// (scan.h: sub_order; not in calls of thousands of pairs -- a few subjects with thousands of queries each, alike: their costs stay
 		// zero and the order is the subjects' own; 24 680 additions to eight words took 0.07 ms)
