@@ -351,3 +351,26 @@ def test_routed_calls_choose_one_wavefront_kernel():
     assert t["pool_calls"] == 0 and (got == lane).all(), t
     forced, t = _rows(close, {"ANDI_POOL_MATCH": "0", "ANDI_QUAD_MATCH": "-1"})  # (... and keeps them from k_lane_quad: the wavefront kernel's)
     assert (forced == lane).all(), t
+
+
+def test_joined_contigs_are_routed_by_the_distance_between_their_ends():
+    """andi --join (src/sequence.c:78-125): every genome a set of contigs joined by '!', cut at different places in every genome, so each
+    separator of the query or the subject ends the pair's diagonal.  A large call routes such pairs by the mean distance between the
+    ends (k_pair_estimate, from the separators counted per sequence on the device): many contigs -- the lane scan; few -- the wavefront
+    kernels.  Same counts every way, rows against the oracle."""
+    os.environ.pop("ANDI_COOP", None)
+    base = synth.base_codes(3_000_000, 61)
+    whole = [synth.to_bytes(synth.mutate_codes(base, d, 70 + k)) for k, d in enumerate((0.001, 0.004, 0.008, 0.012, 0.003, 0.006, 0.01))]
+    many = [synth.join_contigs(s, 150, seed=5 + k) for k, s in enumerate(whole)]   # an end every 10 000 positions
+    few = [synth.join_contigs(s, 8, seed=9 + k) for k, s in enumerate(whole)]      # ... every 190 000
+    for seqs, expect_wavefronts in ((many, False), (few, True)):
+        got, t = _rows(seqs, {})
+        assert t["routed_calls"] == 1 and t["fixups"] == 0, t
+        assert (t["coop_query_nt"] > 0) == expect_wavefronts and (expect_wavefronts or t["lane_query_nt"] > 0), t
+        lane, _ = _rows(seqs, {"ANDI_COOP": "0"})
+        assert (got == lane).all()
+        for i in (0, 3):
+            O = orc.OracleEsa(seqs[i])
+            want = orc.scan_row(O, seqs, i, orc.M_JC, threads=os.cpu_count() or 1)
+            O.close()
+            assert (got[i] == want).all(), i
