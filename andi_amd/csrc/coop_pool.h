@@ -297,6 +297,8 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 	TICK(tph);
 	// ---- sweep S
 	uint32_t nheads = 0, f_cap = NOPOS, last_mm = e0, dirty = 0;
+	uint32_t ring_dirty = 0xfu; // which of the ring's four rounds of L.dring may hold a separator's bit (a window begins with whatever the last one left)
+	bool win_dirty = false;     // the window has shown a separator so far (wave-uniform)
 	bool heads_on = true;
 	{
 		Planes qv, sv;
@@ -335,7 +337,12 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 				G->bits[64 * t + lane] = m;
 				L.mring[(64 * t + lane) & 255u] = m;
 				*(uint2 *)&L.qring[(2 * (64 * t + lane)) & 511u] = codes;
-				L.dring[(64 * t + lane) & 255u] = dirty_w;
+				{ // (the separators' ring is written only where it holds or held one: whole genomes never touch it)
+					const bool any_now = __any(dirty_w != 0);
+					if (any_now || ((ring_dirty >> (t & 3u)) & 1u)) L.dring[(64 * t + lane) & 255u] = dirty_w;
+					ring_dirty = (ring_dirty & ~(1u << (t & 3u))) | (any_now ? 1u << (t & 3u) : 0u);
+					win_dirty = win_dirty || any_now;
+				}
 				if (!PKNOCK(0)) subst_count(acc, mc, qv, sv);
 				{
 					const uint64_t any = __ballot(m != 0);
@@ -397,7 +404,7 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 								rc.q2[2] = __builtin_amdgcn_alignbit(c3, c1, sh), rc.q2[3] = __builtin_amdgcn_alignbit(c5, c3, sh);
 								rc.bits[0] = __builtin_amdgcn_alignbit(r1, r0, sh), rc.bits[1] = __builtin_amdgcn_alignbit(r2, r1, sh);
 								rc.pos = e;
-								rc.dirty = L.dring[wq & 255u] | L.dring[(wq + 1) & 255u] | L.dring[(wq + 2) & 255u]; // (a separator in the three words the record is cut from: a superset of its 64 positions' own is enough)
+								rc.dirty = win_dirty ? L.dring[wq & 255u] | L.dring[(wq + 1) & 255u] | L.dring[(wq + 2) & 255u] : 0u; // (a separator in the three words the record is cut from: a superset of its 64 positions' own is enough)
 								G->rec[rbase + i] = rc;
 							}
 							const uint64_t okm = __ballot(ok), bad = __ballot(valid && !ok);
@@ -960,6 +967,11 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, cons
 			const uint32_t from = st.lastQ + st.lastLen;
 			pool_stream(a, c, ch, L, G, end, chunks, pw);
 			const bool moved = pool_resolve(a, c, ch, L, G, end, pw, through, same);
+#ifdef POOL_FIXED_WINDOWS /* (A/B: round 5's policy) */
+			if (!through) {
+				chunks = a.pool_first;
+			} else
+#endif
 			if (moved && through) {
 				chunks = 2 * chunks < G->maxchunks ? 2 * chunks : G->maxchunks;
 			} else {
