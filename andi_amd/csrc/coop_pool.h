@@ -955,7 +955,10 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, cons
 	// contigs each (a diagonal every 10 000 positions) scanned 17 times slower than the same genomes whole -- 384 against 20 ms for the
 	// C4 shape -- and now 2.2 times (profiles/r07_pool/join_ab.txt).  The hint outlives the windows' loop: mode G takes over at every
 	// break, and the windows behind it begin where the last ones left off.
-	uint32_t hint_chunks = a.pool_first;
+	// (the persistent wavefronts begin their segments with windows of different lengths -- 64, 24, 40, 56 rounds by their number -- so that
+	// the six of a SIMD do not all stream, or all walk, at the same time: C4 shape 20.36 -> 20.08 ms; the bench set forced onto this kernel
+	// 4.30 -> 4.36: profiles/r07_pool/stagger_ab.txt)
+	uint32_t hint_chunks = a.pool_first == 64u ? (blockIdx.x & 3u) == 0 ? 64u : (blockIdx.x & 3u) == 1 ? 24u : (blockIdx.x & 3u) == 2 ? 40u : 56u : a.pool_first;
 	// windows one after the other while the chain stays canonical on the diagonal and moves; false: the pair was handed back
 	auto windows = [&]() {
 		// (behind an anchor of thousands of symbols the next mismatch is far: genomes 1e-5 apart -- a window finds one or two, and nothing is
