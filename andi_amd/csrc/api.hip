@@ -1048,9 +1048,52 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 	chk(dmalloc(&q->d_off, n));
 	chk(dmalloc(&q->d_len, n));
 	if (err == hipSuccess) err = hipMemsetAsync(q->pool, 0, pool_bytes, ctx->stream);
-	for (size_t i = 0; i < n && err == hipSuccess; ++i)
-		err = hipMemcpyAsync(q->pool + q->off[i], seqs[i].seq, seqs[i].len, hipMemcpyHostToDevice,
-							 ctx->stream);
+	if (err == hipSuccess && q->total_nt >= ((uint64_t)1 << 31)) {
+		// Gigabytes of sequences in pageable memory (BASELINE's config 3: 6.5 GB): one hipMemcpyAsync per sequence went through the
+		// runtime's staging at 10-13 GB/s (0.5-0.6 of the 10.5 s of the 3085 x 3085 matrix, before anything else can begin: now 0.35 s).  Four
+		// host threads instead, each copying its share chunk by chunk into one of its two pinned buffers while the other's
+		// transfer runs on a stream of its own.
+		err = hipStreamSynchronize(ctx->stream); // (the pool's zeroes first: the copies run on other streams)
+		constexpr size_t CHUNK = (size_t)8 << 20;
+		const int nt = 4;
+		std::atomic<size_t> next_seq{0};
+		std::atomic<int> bad{0};
+		auto work = [&]() {
+			(void)hipSetDevice(ctx->device);
+			hipStream_t st = nullptr;
+			void *pin = nullptr;
+			hipEvent_t ev[2] = {nullptr, nullptr};
+			bool ok = host_pool::stream_get(&st, ctx->device, 0) == hipSuccess && host_pool::pinned_get(&pin, 2 * CHUNK) == hipSuccess &&
+					  hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+			size_t k = 0; // chunks this thread has sent
+			while (ok && !bad.load()) {
+				const size_t i = next_seq.fetch_add(1);
+				if (i >= n) break;
+				for (size_t o = 0; o < seqs[i].len && ok; o += CHUNK, ++k) {
+					const size_t len = std::min(CHUNK, seqs[i].len - o);
+					char *buf = (char *)pin + (k & 1) * CHUNK;
+					if (k >= 2) ok = hipEventSynchronize(ev[k & 1]) == hipSuccess; // (the transfer that last read this buffer)
+					memcpy(buf, seqs[i].seq + o, len);
+					ok = ok && hipMemcpyAsync(q->pool + q->off[i] + o, buf, len, hipMemcpyHostToDevice, st) == hipSuccess && hipEventRecord(ev[k & 1], st) == hipSuccess;
+				}
+			}
+			if (st) ok = hipStreamSynchronize(st) == hipSuccess && ok;
+			if (!ok) bad.store(1);
+			for (hipEvent_t e : ev)
+				if (e) (void)hipEventDestroy(e);
+			if (pin) host_pool::pinned_put(pin, 2 * CHUNK);
+			if (st) host_pool::stream_put(st, ctx->device, 0);
+		};
+		std::vector<std::thread> ts;
+		for (int t = 1; t < nt; ++t) ts.emplace_back(work);
+		work();
+		for (auto &t : ts) t.join();
+		if (bad.load() && err == hipSuccess) err = hipErrorUnknown;
+	} else {
+		for (size_t i = 0; i < n && err == hipSuccess; ++i)
+			err = hipMemcpyAsync(q->pool + q->off[i], seqs[i].seq, seqs[i].len, hipMemcpyHostToDevice,
+								 ctx->stream);
+	}
 	if (err == hipSuccess)
 		err = hipMemcpyAsync(q->d_off, q->off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
 	if (err == hipSuccess)
