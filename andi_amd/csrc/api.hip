@@ -1048,7 +1048,10 @@ int andi_hip_queries_stage(andi_hip_ctx *ctx, const andi_hip_seq *seqs, size_t n
 	chk(dmalloc(&q->d_off, n));
 	chk(dmalloc(&q->d_len, n));
 	if (err == hipSuccess) err = hipMemsetAsync(q->pool, 0, pool_bytes, ctx->stream);
-	if (err == hipSuccess && q->total_nt >= ((uint64_t)1 << 31)) {
+	uint64_t threaded_from = (uint64_t)1 << 31;
+	if (const char *um = andi_knob(KNOB_UPLOAD_MIN_MB)) // (tests: the threaded path on small sets)
+		if (atoi(um) >= 0) threaded_from = (uint64_t)atoi(um) << 20;
+	if (err == hipSuccess && q->total_nt >= threaded_from) {
 		// Gigabytes of sequences in pageable memory (BASELINE's config 3: 6.5 GB): one hipMemcpyAsync per sequence went through the
 		// runtime's staging at 10-13 GB/s (0.5-0.6 of the 10.5 s of the 3085 x 3085 matrix, before anything else can begin: now 0.35 s).  Four
 		// host threads instead, each copying its share chunk by chunk into one of its two pinned buffers while the other's

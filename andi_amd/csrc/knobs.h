@@ -12,7 +12,7 @@
 #define ANDI_KNOB_LIST_HOOKS(X)                                                                                            \
 	X(COOP_GIVEUP) X(COOP_SEG) X(COOP_STATS) X(DEBUG_STITCH) X(DEEP_K) X(FORCE_ADAPTIVE) X(KNOCK) X(LANE_OCC) X(LANE_STATS)      \
 	X(NO_RESTITCH) X(NO_SIDE_STREAM) X(NO_SORTED_RECORDS) X(POOL_FIRST) X(POOL_MATCH) X(QUAD_BLOCKS4) X(QUERIES_BYTES) X(QUERIES_PACKED)       \
-	X(QUAD_MATCH) X(QUAD_UNLISTED) X(ROUTE_SMALL) X(ROUTE_SOFT) X(ROUTE_TINY) X(SEG0) X(SORT_WIDTH) X(SEG_FACTOR) X(SINGLE_EXT) X(UNIFORM_SEGMENTS)
+	X(QUAD_MATCH) X(QUAD_UNLISTED) X(ROUTE_SMALL) X(ROUTE_SOFT) X(ROUTE_TINY) X(SEG0) X(SORT_WIDTH) X(SEG_FACTOR) X(SINGLE_EXT) X(UNIFORM_SEGMENTS) X(UPLOAD_MIN_MB)
 #define ANDI_KNOB_LIST(X) ANDI_KNOB_LIST_SHIPPED(X) ANDI_KNOB_LIST_HOOKS(X)
 
 enum AndiKnob {

@@ -2,6 +2,8 @@
 opts.devices; src/dist_hack.h:46-47 is the loop that is being tiled).  A box with one GPU can still run every
 piece of it: several driver threads and contexts on device 0 (rows go to the host matrix directly), and the
 RCCL gather forced for one device (communicator, grouped exchange, the copy of the gathered matrix)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -141,3 +143,23 @@ def test_chunks_outlive_the_contexts_and_trim_gives_them_back():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _TRIM_SCRIPT], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "trim ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_large_sets_are_uploaded_by_threads(orc, knob):
+    """Sets of 2 GiB and more are staged by four host threads through pinned buffers (api.hip: andi_hip_queries_stage).  The test hook
+    ANDI_UPLOAD_MIN_MB lowers the limit so that the path runs here: sequences longer than a chunk (8 MiB), shorter ones, an odd count;
+    the one-call seam's matrix equals the oracle's rows and the matrix staged the ordinary way."""
+    import andi_amd
+    from andi_amd import synth
+    base = synth.base_codes(9_000_000, 77)
+    seqs = [synth.to_bytes(synth.mutate_codes(base, 0.004 * (k + 1), 80 + k))[: 9_000_000 - 1_234_567 * k] for k in range(5)]
+    seqs += [synth.to_bytes(synth.mutate_codes(base[:70_001], 0.01, 90)), synth.join_contigs(synth.to_bytes(base[:300_000]), 4)]
+    plain = andi_amd.dist_matrix(seqs, model=andi_amd.M_JC)
+    knob("ANDI_UPLOAD_MIN_MB", "1")
+    threaded = andi_amd.dist_matrix(seqs, model=andi_amd.M_JC)
+    assert (threaded == plain).all()
+    for i in (1, 5, 6):
+        O = orc.OracleEsa(seqs[i])
+        want = orc.scan_row(O, seqs, i, orc.M_JC, threads=os.cpu_count() or 1)
+        O.close()
+        assert (threaded[i] == want).all(), i
