@@ -354,18 +354,15 @@ static State &state() {
 	static State *s = new State;
 	return *s;
 }
-#define mu state().mu
-#define streams state().streams
-#define pinned state().pinned
 constexpr size_t PINNED_KEEP = (size_t)256 << 20; // bytes of pinned buffers kept at most
 
 static hipError_t stream_get(hipStream_t *out, int device, int prio) {
 	{
-		std::lock_guard<std::mutex> lk(mu);
-		for (size_t i = 0; i < streams.size(); ++i)
-			if (streams[i].device == device && streams[i].prio == prio) {
-				*out = streams[i].s;
-				streams.erase(streams.begin() + (long)i);
+		std::lock_guard<std::mutex> lk(state().mu);
+		for (size_t i = 0; i < state().streams.size(); ++i)
+			if (state().streams[i].device == device && state().streams[i].prio == prio) {
+				*out = state().streams[i].s;
+				state().streams.erase(state().streams.begin() + (long)i);
 				return hipSuccess;
 			}
 	}
@@ -373,18 +370,18 @@ static hipError_t stream_get(hipStream_t *out, int device, int prio) {
 }
 static void stream_put(hipStream_t s, int device, int prio) { // (idle: the caller has synchronised it)
 	if (!s) return;
-	std::lock_guard<std::mutex> lk(mu);
-	streams.push_back({device, prio, s});
+	std::lock_guard<std::mutex> lk(state().mu);
+	state().streams.push_back({device, prio, s});
 }
 static hipError_t pinned_get(void **out, size_t bytes) {
 	{
-		std::lock_guard<std::mutex> lk(mu);
-		size_t best = pinned.size();
-		for (size_t i = 0; i < pinned.size(); ++i)
-			if (pinned[i].bytes >= bytes && pinned[i].bytes <= 2 * bytes + 4096 && (best == pinned.size() || pinned[i].bytes < pinned[best].bytes)) best = i;
-		if (best != pinned.size()) {
-			*out = pinned[best].p;
-			pinned.erase(pinned.begin() + (long)best);
+		std::lock_guard<std::mutex> lk(state().mu);
+		size_t best = state().pinned.size();
+		for (size_t i = 0; i < state().pinned.size(); ++i)
+			if (state().pinned[i].bytes >= bytes && state().pinned[i].bytes <= 2 * bytes + 4096 && (best == state().pinned.size() || state().pinned[i].bytes < state().pinned[best].bytes)) best = i;
+		if (best != state().pinned.size()) {
+			*out = state().pinned[best].p;
+			state().pinned.erase(state().pinned.begin() + (long)best);
 			return hipSuccess;
 		}
 	}
@@ -393,11 +390,11 @@ static hipError_t pinned_get(void **out, size_t bytes) {
 static void pinned_put(void *p, size_t bytes) {
 	if (!p) return;
 	{
-		std::lock_guard<std::mutex> lk(mu);
+		std::lock_guard<std::mutex> lk(state().mu);
 		size_t held = 0;
-		for (const IdlePinned &b : pinned) held += b.bytes;
+		for (const IdlePinned &b : state().pinned) held += b.bytes;
 		if (held + bytes <= PINNED_KEEP) {
-			pinned.push_back({p, bytes});
+			state().pinned.push_back({p, bytes});
 			return;
 		}
 	}
@@ -405,7 +402,7 @@ static void pinned_put(void *p, size_t bytes) {
 }
 constexpr size_t WORD_BYTES = 256, SLAB_BYTES = 65536;
 static void *word_get() { // 256 zeroed bytes of pinned host memory (device-visible: unified addressing), 256-byte aligned
-	std::lock_guard<std::mutex> lk(mu);
+	std::lock_guard<std::mutex> lk(state().mu);
 	State &S = state();
 	if (S.free_words.empty()) {
 		char *slab = nullptr;
@@ -424,7 +421,7 @@ static void *word_get() { // 256 zeroed bytes of pinned host memory (device-visi
 }
 static void word_put(void *p) {
 	if (!p) return;
-	std::lock_guard<std::mutex> lk(mu);
+	std::lock_guard<std::mutex> lk(state().mu);
 	state().free_words.push_back(p);
 	--state().words_out;
 }
@@ -433,7 +430,7 @@ static void word_put(void *p) {
 // call: 0.8 GB of hipMalloc + hipFree per call and device otherwise); andi_hip_trim returns it
 static void *scratch_get(int device, size_t bytes) {
 	{
-		std::lock_guard<std::mutex> lk(mu);
+		std::lock_guard<std::mutex> lk(state().mu);
 		auto &v = state().scratch;
 		for (size_t i = 0; i < v.size(); ++i)
 			if (v[i].device == device && v[i].bytes == bytes) {
@@ -452,7 +449,7 @@ static void *scratch_get(int device, size_t bytes) {
 static void scratch_put(int device, void *p, size_t bytes) { // (idle: the caller has waited for the kernels that used it)
 	if (!p) return;
 	{
-		std::lock_guard<std::mutex> lk(mu);
+		std::lock_guard<std::mutex> lk(state().mu);
 		auto &v = state().scratch;
 		bool have = false;
 		for (const IdleScratch &x : v) have = have || x.device == device;
@@ -464,16 +461,16 @@ static void scratch_put(int device, void *p, size_t bytes) { // (idle: the calle
 	(void)hipFree(p);
 }
 static bool any() {
-	std::lock_guard<std::mutex> lk(mu);
-	return !streams.empty() || !pinned.empty() || !state().scratch.empty() || !state().slabs.empty();
+	std::lock_guard<std::mutex> lk(state().mu);
+	return !state().streams.empty() || !state().pinned.empty() || !state().scratch.empty() || !state().slabs.empty();
 }
 static size_t trim() { // (the caller restores the current device); returns the device bytes given back
 	std::vector<IdleStream> st;
 	std::vector<IdlePinned> pb;
 	std::vector<IdleScratch> sc;
 	{
-		std::lock_guard<std::mutex> lk(mu);
-		st.swap(streams), pb.swap(pinned), sc.swap(state().scratch);
+		std::lock_guard<std::mutex> lk(state().mu);
+		st.swap(state().streams), pb.swap(state().pinned), sc.swap(state().scratch);
 		if (state().words_out == 0) { // (slabs with blocks still out stay)
 			for (char *slab : state().slabs) pb.push_back({slab, SLAB_BYTES});
 			state().slabs.clear(), state().free_words.clear();
@@ -487,9 +484,6 @@ static size_t trim() { // (the caller restores the current device); returns the 
 		if (hipSetDevice(x.device) == hipSuccess && hipFree(x.p) == hipSuccess) freed += x.bytes;
 	return freed;
 }
-#undef mu
-#undef streams
-#undef pinned
 } // namespace host_pool
 
 size_t andi_hip_trim(void) {
