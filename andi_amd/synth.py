@@ -122,7 +122,7 @@ def join_contigs(seq: bytes, n_contigs, seed=7):
     """Cut a genome into contigs and join them with '!' (dsa_join,
     src/sequence.c:78-125)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    cuts = sorted(int(c) for c in rng.choice(np.arange(1, len(seq)), size=n_contigs - 1, replace=False))
+    cuts = sorted(1 + int(c) for c in rng.choice(len(seq) - 1, size=n_contigs - 1, replace=False))  # (O(contigs), not O(length))
     parts, last = [], 0
     for c in cuts + [len(seq)]:
         parts.append(seq[last:c])

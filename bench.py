@@ -170,7 +170,7 @@ def workload_name(kind, G, S, length, dlo, dhi, seed, world, model=1):
         MODEL_NAMES[model], seed, "all" if S == G else "the first %d subject" % S, world)
 
 
-def secondary(kind, args, model, p_value, G=29, L=None, S=None, dlo=None, dhi=None, seam=False):
+def secondary(kind, args, model, p_value, G=29, L=None, S=None, dlo=None, dhi=None, seam=False, contigs=0):
     """The same step on another set (one GPU, after the headline's timed region): structured genomes, the tree-structured
     variant, and a call of BASELINE's config 3 (S subject rows of the 3085-genome set: the shape the north_star's target
     is stated on) -- reported beside, never instead of, the star headline."""
@@ -181,6 +181,9 @@ def secondary(kind, args, model, p_value, G=29, L=None, S=None, dlo=None, dhi=No
     dlo = args.dlo if dlo is None else dlo
     dhi = args.dhi if dhi is None else dhi
     seqs = make_set(kind, G, L, dlo, dhi, args.seed)
+    if contigs > 1:  # andi --join: every genome a set of contigs, cut at places of its own
+        from andi_amd import synth
+        seqs = [synth.join_contigs(sq, contigs, seed=args.seed + 7 * k) for k, sq in enumerate(seqs)]
     ctx = andi_amd.Context(0)
     ctx.expect_queries(G - 1)
     Q = andi_amd.Queries(ctx, seqs)
@@ -203,7 +206,7 @@ def secondary(kind, args, model, p_value, G=29, L=None, S=None, dlo=None, dhi=No
     tm = ctx.timings()
     scan_ms = tm["scan_ms"] / max(int(tm["scan_launches"]), 1)
     alg = 2.0 * tm["scan_query_nt"] / max(int(tm["scan_launches"]), 1)
-    out = {"workload": workload_name(kind, G, S, L, dlo, dhi, args.seed, 1, model),
+    out = {"workload": workload_name(kind, G, S, L, dlo, dhi, args.seed, 1, model) + (", every genome as %d contigs joined by '!' (--join)" % contigs if contigs > 1 else ""),
            "pairs_per_s": S * (G - 1) / (el / steps), "ms_per_step": 1e3 * el / steps,
            "roofline_frac": alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if scan_ms > 0 else None,
            "pass_a_kernel": pass_a_of(tm)[0], "pass_a_query_nt_fraction": pass_a_of(tm)[1],
@@ -600,6 +603,8 @@ def main():
             "realistic": secondary("realistic", args, model, p_value),
             "tree_structured": secondary("tree", args, model, p_value),
             "c4_shape": secondary("star", args, model, p_value, G=3085, L=2_100_000, S=8, dlo=0.001, dhi=0.015),
+            # ... and as what the Maela assemblies are: multi-contig drafts under --join (40 contigs per genome, cut at places of their own)
+            "c4_shape_joined": secondary("star", args, model, p_value, G=3085, L=2_100_000, S=8, dlo=0.001, dhi=0.015, contigs=40),
             # BASELINE's configs[2] at full size on one GPU: the step, and the whole job once through the one-call seam
             "c3": secondary("fast", args, MODELS["kimura"], p_value, G=109, L=5_100_000, dlo=1e-4, dhi=5e-3, seam=True)})
     if rank == 0:
