@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 	// places), and a wavefront kernel pays a window for every end.  C4 shape of genomes of 100 / 20 contigs, per call: k_pool_cold 117 / 48 ms,
 	// k_coop_cold 87 / 37, the lane scan 54 / 44 (whole genomes: 20 by k_pool_cold); bench set of 100-contig genomes (an end every 24 500
 	// positions): lanes 8.2, k_coop_cold 9.5 ms.  So by the mean distance between the ends: below 32768 positions the lane scan, below
-	// 131072 -- a window of k_pool_cold -- no candidate of that kernel (profiles/r07_pool/join_routing.txt).
+	// 262144 -- two windows of k_pool_cold -- no candidate of that kernel (C4 shape of 8-contig genomes, an end every 131 000 positions:
+	// k_pool_cold 33.7, k_coop_cold 30.0 ms; profiles/r07_pool/join_routing.txt, join_sweep.txt).
 	uint32_t break_dist = ~0u;
 	if (a.qsep && a.self[sub] >= 0) {
 		const uint32_t ends = a.qsep[qidx] + a.qsep[(uint32_t)a.self[sub]];
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 		const bool quad = (sum >> 6) >= a.quad_min_match && !(islands && (sum >> 6) < ANDI_ISLAND_MEAN_MAX);
 		a.pair_class[pair] = (uint8_t)(cls | (quad ? 0x80u : 0u) | (coop_cand && !islands ? ANDI_ROUTE_COOP : 0u) | (soft ? ANDI_ROUTE_SOFT : 0u) |
 										 (coop_cand && islands ? ANDI_ROUTE_LEFT : 0u) | (coop_cand && guess ? ANDI_ROUTE_GUESS : 0u) |
-										 (a.route && (sum >> 6) >= a.pool_match && (sum >> 6) < 4096u && break_dist >= 131072u ? ANDI_ROUTE_POOLCAND : 0u));
+										 (a.route && (sum >> 6) >= a.pool_match && (sum >> 6) < 4096u && break_dist >= 262144u ? ANDI_ROUTE_POOLCAND : 0u));
 		a.pair_waves[pair] = (nseg + 63) / 64;
 		// (scan.h: sub_order; not in calls of thousands of pairs -- a few subjects with thousands of queries each, alike: their costs stay
 		// zero and the order is the subjects' own; 24 680 additions to eight words took 0.07 ms)

@@ -362,7 +362,7 @@ def test_joined_contigs_are_routed_by_the_distance_between_their_ends():
     base = synth.base_codes(3_000_000, 61)
     whole = [synth.to_bytes(synth.mutate_codes(base, d, 70 + k)) for k, d in enumerate((0.001, 0.004, 0.008, 0.012, 0.003, 0.006, 0.01))]
     many = [synth.join_contigs(s, 150, seed=5 + k) for k, s in enumerate(whole)]   # an end every 10 000 positions
-    few = [synth.join_contigs(s, 8, seed=9 + k) for k, s in enumerate(whole)]      # ... every 190 000
+    few = [synth.join_contigs(s, 4, seed=9 + k) for k, s in enumerate(whole)]      # ... every 430 000
     for seqs, expect_wavefronts in ((many, False), (few, True)):
         got, t = _rows(seqs, {})
         assert t["routed_calls"] == 1 and t["fixups"] == 0, t
