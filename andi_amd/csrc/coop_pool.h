@@ -425,6 +425,7 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 	}
 	if (PKNOCK(2)) nheads = 0;
 	ch.blk_base = NOPOS;
+	ch.stuck = 0;
 	CSTAT(CS_WINDOWS, 1);
 	CSTAT(CS_HEADS, nheads);
 	pw.e0 = e0, pw.nchunks = nchunks, pw.nheads = nheads, pw.last_mm = last_mm, pw.f_cap = f_cap, pw.clean = __any(dirty != 0) ? 0u : 1u;
@@ -733,6 +734,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 				cur = F, done = true;
 			} else if (ej == NOPOS) { // its walk did not land (or where the anchor ends is not in the window): the chain stops at the head
 				cur = pj, done = true;
+				if ((fj & W_STATUS) == W_BREAK) ch.stuck = 1; // (scan_coop.hip: Chain.stuck)
 			} else { // hopped; the chain stands where the anchor ends
 				if (lane == j) onpath = true;
 				cur = ej;
@@ -941,7 +943,7 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, cons
 	PoolWin pw;
 	if (lane < 16) L.hist[lane] = 0;
 	ch.st = seg_in_q == 0 ? initial_state() : cold_state(start, n);
-	ch.quarter = ch.rest = ch.anchors = ch.marked = 0, ch.blk_base = NOPOS;
+	ch.quarter = ch.rest = ch.anchors = ch.marked = 0, ch.blk_base = NOPOS, ch.stuck = 0;
 	ChainState &st = ch.st;
 	wave_sync();
 
@@ -985,6 +987,7 @@ __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, cons
 			hint_chunks = chunks;
 			if (!moved) break;
 			if (given_up()) return false;
+			if (ch.stuck) break; // (the chain stands at a head whose walk gave up: mode G's step, not another window at the same place)
 		}
 		return true;
 	};

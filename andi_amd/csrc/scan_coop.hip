@@ -183,6 +183,8 @@ struct Chain { // the chain of the wavefront: everything wave-uniform
 	uint32_t anchors;
 	uint32_t marked; // the mark behind the 2nd anchor has been written
 	uint32_t blk_base; // the block of probes in LDS answers positions blk_base ... blk_base + 63 (NOPOS: none)
+	uint32_t stuck;    // the last window ended at a head whose walk gave up (W_BREAK: the chain leaves the diagonal there): the next step is mode G's --
+					   // a window opened at that head again would stream, walk all its heads and not move (one such window per contig end, round 6)
 };
 
 // lcp(Q + p, S + s, maxlen) (src/process.c:59-65) with all lanes: 2048 symbols per round trip
@@ -598,6 +600,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	if (lane == 0) L.nhadx = 0;
 	if (lane < 4) L.mbits[64 * NCH + lane] = 0;
 	ch.blk_base = NOPOS; // (mode G's block of probes lies where the heads are about to be listed)
+	ch.stuck = 0;
 	wave_sync();
 
 	TOCK(tph, PH_STREAM);
@@ -857,6 +860,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 				cur = F, done = true;
 			} else if (ej == NOPOS) { // its walk did not land (or where the anchor ends is not in the window): the chain stops at the head
 				cur = pj, done = true;
+				if ((lane_read(fl, j) & W_STATUS) == W_BREAK) ch.stuck = 1;
 			} else { // hopped; the chain stands where the anchor ends
 				if (lane == j) onpath = true;
 				hop = base + j, cur = ej;
@@ -1091,7 +1095,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 	if (lane < 16) L.hist[lane] = 0;
 	Chain ch;
 	ch.st = seg_in_q == 0 ? initial_state() : cold_state(start, n);
-	ch.quarter = ch.rest = ch.anchors = ch.marked = 0, ch.blk_base = NOPOS;
+	ch.quarter = ch.rest = ch.anchors = ch.marked = 0, ch.blk_base = NOPOS, ch.stuck = 0;
 	ChainState &st = ch.st;
 	wave_sync();
 
@@ -1147,6 +1151,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 		if (found && lucky)
 			while (st.p < end && st.lastQ + st.lastLen < c.qlen && coop_window<NCH, EXACT>(a, c, ch, L, end)) {
 				if (given_up()) return;
+				if (ch.stuck) break; // (the chain stands at a head whose walk gave up: mode G's step)
 			}
 	}
 
