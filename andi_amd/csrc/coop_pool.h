@@ -21,7 +21,10 @@
 // The states and counts are those of the sequential loop (src/process.c:141-214), as coop_window's: tests/test_coop_gpu.py
 // runs both against the oracle and against each other.  LogDet / ANI (EXACT) stay with coop_window.
 
-constexpr uint32_t POOL_MW = 131072;            // positions of a window at most (a multiple of 2048)
+#ifndef POOL_MW_POS
+#define POOL_MW_POS 131072
+#endif
+constexpr uint32_t POOL_MW = POOL_MW_POS;       // positions of a window at most (a multiple of 2048)
 constexpr uint32_t POOL_CHUNK_HEADS = 128;      // heads of one round of 2048 positions (more: as above)
 
 struct __attribute__((aligned(16))) PoolRec { // what a head's walk reads

@@ -32,7 +32,9 @@
 
 namespace {
 
-#define COOP_HCAP (NCH <= 2 ? 64u : 24u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
+// (LDS bounds the window at eight wavefronts per SIMD: 5120 bytes each.  Five chunks with 20 heads per chunk are 5068 bytes; fewer heads per
+// chunk cost more than the longer window gains -- 16 per chunk: + 4 %, 20: + 1 %, 32: - 0.5 %; profiles/r07_coop/README.md)
+#define COOP_HCAP (NCH <= 2 ? 64u : NCH == 5 ? 20u * NCH : 24u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
 constexpr int COOP_WAVES = 1; // wavefronts per block: single wavefronts find a place on a CU the moment one leaves (bench set 5.39 -> 5.24 ms against blocks of two, 5.61 with four); seven per SIMD (72 registers): 4.94
 constexpr uint32_t COOP_KCAP = 32; // stretches of a window that are counted nowhere (more: the window ends before the next one)
 // (routed calls hand a pair back when one of its segments needs more generic steps than ScanArgs.route_giveup -- 1024: long stretches without homology that the sampling missed (clean sets: <= 45 steps; an island of 20 kbp: some 1500).  Grinding through them instead -- the limit at 16384 -- took the structured set's pass A from 9.4 to 28 ms for 9 of its 812 pairs, and its passes B/C from 6.9 to 15 ms: their true chains cross the islands on long segments, one lane each)
@@ -76,10 +78,14 @@ enum : uint32_t { W_OK = 1, W_OPEN = 2, W_EXIT = 3, W_BREAK = 4, W_STATUS = 7u, 
 template <int NCH>
 struct CoopLds {
 	uint32_t mbits[64 * NCH + 4]; // mismatch bits of the window, bit (x - wbase); the words behind it stay 0: nothing known there
+#ifdef COOP_QGLOBAL
+	uint32_t ebits[64 * NCH]; // (the walks read the query's symbols from global memory: no 2-bit copy of the window in LDS, longer windows)
+#else
 	union {
 		uint32_t q2[128 * NCH + 4]; // the window's query symbols as 2-bit codes, 16 per word, symbol k of a word at bits 2k, 2k + 1: for the walks;
 		uint32_t ebits[64 * NCH];   // once they are done: the stretches behind the heads the chain came by, [head, landing): counted as gaps -- except
 	};
+#endif
 	uint32_t kpos[COOP_KCAP];     // those that start at one of these positions (the walk met anchors off the diagonal): counted nowhere
 	uint32_t nhadx;               // walks of the window that ended that way (at most COOP_KCAP: the others give up)
 	union {
@@ -395,9 +401,16 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 		WHY(CS_WHY_PRE);
 		return false;
 	}
+#ifdef COOP_QGLOBAL
+	const uint4 qv = ld_query(c, p & ~1u); // 32 symbols from p (31 if p is odd): the K-mer and the 16 behind it are K + 16 <= 29
+	const uint32_t sh = 4 * (p & 1u);
+	const uint32_t n0 = __builtin_amdgcn_alignbit(qv.y, qv.x, sh), n1 = __builtin_amdgcn_alignbit(qv.z, qv.y, sh), n2 = __builtin_amdgcn_alignbit(qv.w, qv.z, sh), n3 = qv.w >> sh;
+	return coop_probe_codes(c, p, sd, squeeze_codes(n0) | (squeeze_codes(n1) << 16), squeeze_codes(n2) | (squeeze_codes(n3) << 16), r, on_diag, multi_x, multi_n, multi_q);
+#else
 	const uint32_t j = o >> 4, sh = 2 * (o & 15u);
 	const uint32_t w0 = L.q2[j], w1 = L.q2[j + 1], w2 = L.q2[j + 2];
 	return coop_probe_codes(c, p, sd, __builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh), r, on_diag, multi_x, multi_n, multi_q);
+#endif
 }
 
 // The probe of a parked lane whose K-mer occurs n <= 4 times (at SA[x ...]): the longest match is the best of the
@@ -583,20 +596,28 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			const uint4 qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
 #endif
 			m = squeeze32(neq32(qv, sv));
+#ifndef COOP_QGLOBAL
 			codes = make_uint2(squeeze_codes(qv.x) | (squeeze_codes(qv.y) << 16), squeeze_codes(qv.z) | (squeeze_codes(qv.w) << 16));
+#endif
 			if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0);
 			dirty |= (qv.x | qv.y | qv.z | qv.w) & 0x44444444u; // bit 2 of a symbol: no nucleotide (the padding behind the query's end too: its last window's walks read the query itself)
 		}
 		if (x0 <= e0 && e0 - x0 < WNT) m &= ~0u << (e0 - x0); // (what lies before the anchor is none of the window's business)
 		if (x0 + WNT <= e0) m = 0;
 		L.mbits[64 * ck + lane] = m;
+#ifndef COOP_QGLOBAL
 		*(uint2 *)&L.q2[2 * (64 * ck + lane)] = codes;
+#else
+		(void)codes;
+#endif
 #ifdef COOP_STREAM_PIPELINE
 		qv = qn, sv = sn;
 #endif
 	}
 	const bool clean = !__any(dirty != 0);
+#ifndef COOP_QGLOBAL
 	if (lane < 4) L.q2[128 * NCH + lane] = 0;
+#endif
 	if (lane == 0) L.nhadx = 0;
 	if (lane < 4) L.mbits[64 * NCH + lane] = 0;
 	ch.blk_base = NOPOS; // (mode G's block of probes lies where the heads are about to be listed)
@@ -674,7 +695,8 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			const uint64_t busy = __ballot(hk != NOPOS), waiting = __ballot(hk != NOPOS && parked);
 			if (!busy) break;
 			// the parked lanes' turn?
-			const bool service = waiting && ((uint32_t)__builtin_popcountll(waiting) >= COOP_PARK || waiting == busy);
+			// (... or no head is left to take: served only when nothing else was left, a parked lane's remaining steps ran alone behind all the others)
+			const bool service = waiting && ((uint32_t)__builtin_popcountll(waiting) >= COOP_PARK || waiting == busy || next_head >= nheads);
 #ifdef ANDI_COOP_STATS
 			if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
 				const uint32_t nb = (uint32_t)__builtin_popcountll(service ? waiting : busy & ~waiting); // lanes at work in this trip
@@ -724,6 +746,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 					  : (near && run_ok) ? (W_OK | W_LUCKY)
 					  : (near && !seen && left < thr) ? W_OPEN : 0u;
 				ra = p;
+				if (inwin && !res && o + 32 > W) res = Xl ? W_BREAK : W_OPEN; // (a probe in the window's last 32 symbols would be lane_probe's, by one lane: the chain stops at this head instead, the next window opens there)
 				if (inwin && Xl) { // lucky_anchor on the diagonal of the anchor off the window's: compare (rare)
 					const uint32_t adv = p - Xq;
 					if (Xs + adv < n && adv - Xl <= thr) {
@@ -1067,7 +1090,7 @@ template <int NCH, bool EXACT>
 #ifndef COOP_OCC
 #define COOP_OCC 8
 #endif
-__global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_coop_cold(ScanArgs a) {
+__global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 5 ? COOP_OCC : 4) void k_coop_cold(ScanArgs a) {
 	__shared__ CoopLds<NCH> s_lds[COOP_WAVES];
 	CoopLds<NCH> &L = s_lds[threadIdx.x >> 6];
 	const uint32_t lane = __lane_id();
@@ -1180,15 +1203,15 @@ __global__ __launch_bounds__(64 * COOP_WAVES, NCH <= 4 ? COOP_OCC : 4) void k_co
 
 } // namespace
 
-// ANDI_COOP=0: never; 2, 4, 8: pass A with one wavefront per chain for every pair, windows of 2048 n symbols, whatever
+// ANDI_COOP=0: never; 2, 4, 5, 8: pass A with one wavefront per chain for every pair, windows of 2048 n symbols, whatever
 // the call (any other value: 4, with a warning); unset (< 0): large calls are routed per pair (scan.h)
 int andi_coop_enabled(void) {
 	const char *e = andi_knob(KNOB_COOP);
 	if (!e) return -4;
 	const int v = atoi(e);
-	if (v == 0 || v == 2 || v == 4 || v == 8) return v;
+	if (v == 0 || v == 2 || v == 4 || v == 5 || v == 8) return v;
 	static bool warned = false;
-	if (!warned) fprintf(stderr, "andi-hip: ANDI_COOP=%s: windows of 2, 4 or 8 chunks of 2048 symbols; taking 4\n", e), warned = true;
+	if (!warned) fprintf(stderr, "andi-hip: ANDI_COOP=%s: windows of 2, 4, 5 or 8 chunks of 2048 symbols; taking 4\n", e), warned = true;
 	return 4;
 }
 
@@ -1237,7 +1260,10 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 		if (e != hipSuccess) return e;
 		k_pool_cold<<<(uint32_t)(items < a.pool_waves ? items : a.pool_waves), 64, 0, st>>>(b);
 	} else
-	switch (nch < 0 ? -nch : nch) {
+	// windows of five chunks where the segments are long enough to fill them (round 6: 4.10 -> 3.87 ms on the bench set against four -- a
+	// window's walks take as many trips as its longest, whatever the number of heads); short segments of small calls keep four
+	switch (nch < 0 ? (a.seg >= 32768 ? 5 : 4) : nch) {
+		case 5: a.exact_equal ? k_coop_cold<5, true><<<grid, 64 * COOP_WAVES, 0, st>>>(a) : k_coop_cold<5, false><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 		case 2: a.exact_equal ? k_coop_cold<2, true><<<grid, 64 * COOP_WAVES, 0, st>>>(a) : k_coop_cold<2, false><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 		case 8: a.exact_equal ? k_coop_cold<8, true><<<grid, 64 * COOP_WAVES, 0, st>>>(a) : k_coop_cold<8, false><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;
 		default: a.exact_equal ? k_coop_cold<4, true><<<grid, 64 * COOP_WAVES, 0, st>>>(a) : k_coop_cold<4, false><<<grid, 64 * COOP_WAVES, 0, st>>>(a); break;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Calls of the size at which pass A is routed per pair (scan.h: ScanArgs.route): random sets of 8-12 genomes of
 3-5 Mbp (star, tree, structured, close, mixed), every model the kernel takes, through andi_hip_scan_rows --
-the call as it comes (routed), the lane scan (ANDI_COOP=0) and the wavefront kernel forced (ANDI_COOP=4) must agree
+the call as it comes (routed), the lane scan (ANDI_COOP=0) and the wavefront kernel forced (ANDI_COOP=4 or 5) must agree
 bit for bit, and one sampled subject row must equal the oracle's.  scripts/fuzz_large.py [seconds] [seed]"""
 import os
 import sys
@@ -80,7 +80,7 @@ def main():
         model = int(rng.choice([0, 1, 1, 2, 3, 4]))
         lane, t0 = rows(seqs, model, {"ANDI_COOP": "0"})
         got, t1 = rows(seqs, model, {})
-        forced, t2 = rows(seqs, model, {"ANDI_COOP": "4"}) if kind in ("star", "tree", "joined", "strands") else (lane, t0)
+        forced, t2 = rows(seqs, model, {"ANDI_COOP": str(rng.choice([4, 5]))}) if kind in ("star", "tree", "joined", "strands") else (lane, t0)
         # ... and with every routed pair taken for one that suits k_pool_cold (coop_pool.h): that kernel where the call is large enough for
         # the host to look at the layout, whatever the pairs are like
         pooled, t3 = rows(seqs, model, {"ANDI_POOL_MATCH": "0", "ANDI_ROUTE_SMALL": "20"}) if model < 3 else (lane, t0)

@@ -56,7 +56,7 @@ def main():
             segment = int(rng.choice([0, 0, 0, 0, 64, 100, 300, 700, 2048, 5000, 40000]))  # 0: the engine's choice -- pass A routed per pair from 2^18 symbols
             env = {}
             if rng.random() < 0.3:
-                env["ANDI_COOP"] = str(rng.choice([2, 4, 8]))
+                env["ANDI_COOP"] = str(rng.choice([2, 4, 5, 8]))
             else:
                 if rng.random() < 0.6:  # no call is tiny: calls of this size are routed per pair (else: the wavefront kernel for every pair)
                     env["ANDI_ROUTE_TINY"] = "1"

@@ -22,7 +22,7 @@ def _revcomp(b: bytes) -> bytes:
     return bytes(b[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")))
 
 
-@pytest.mark.parametrize("coop", [2, 4, 8])
+@pytest.mark.parametrize("coop", [2, 4, 5, 8])
 def test_divergence_ladder(coop):
     base = synth.base_codes(300000, 5)
     seqs = [synth.to_bytes(synth.mutate_codes(base, d, 10 + k)) for k, d in enumerate((0.0, 0.0005, 0.005, 0.02, 0.05, 0.15))]
@@ -39,6 +39,7 @@ def test_structured_genomes_equal_lane_scan_and_oracle():
     assert (lane == want).all()
     for segment in (0, 8192, 700):
         assert (_matrix(seqs, andi_amd.M_KIMURA, 4, segment) == want).all(), "segment %d" % segment
+    assert (_matrix(seqs, andi_amd.M_KIMURA, 5, 0) == want).all() and (_matrix(seqs, andi_amd.M_KIMURA, 5, 12000) == want).all()
 
 
 def test_strands_contigs_edges():
@@ -49,7 +50,7 @@ def test_strands_contigs_edges():
             synth.join_contigs(synth.to_bytes(synth.mutate_codes(base, 0.01, 4)), 9),  # '!' separators
             s, synth.unrelated(90000, 77), s[:700]]  # identical, unrelated, short
     want = orc.dist_matrix(seqs, model=orc.M_RAW, threads=4)
-    for coop in (2, 4):
+    for coop in (2, 4, 5):
         for segment in (0, 2048, 300):
             got = _matrix(seqs, andi_amd.M_RAW, coop, segment)
             assert (got == want).all(), "window of %d chunks, segment %d: pairs %s" % (
@@ -66,7 +67,7 @@ def test_logdet_and_ani_count_every_anchor(model):
     seqs.append(_revcomp(seqs[2]))
     seqs.append(synth.join_contigs(seqs[1], 6))
     want = orc.dist_matrix(seqs, model=model, threads=4)
-    for coop in (2, 4):
+    for coop in (2, 5):
         for segment in (0, 3000):
             got = _matrix(seqs, model, coop, segment)
             assert (got == want).all(), (coop, segment, np.argwhere((got != want).any(axis=2))[:6].tolist())
@@ -81,6 +82,7 @@ def test_headline_pair_full_length():
     seqs, _ = synth.genome_set(3, 4_900_000, 0.0004, 0.03, seed=1729)
     lane = _matrix(seqs, andi_amd.M_JC, 0)
     assert (_matrix(seqs, andi_amd.M_JC, 4) == lane).all()
+    assert (_matrix(seqs, andi_amd.M_JC, 5) == lane).all()
 
 
 def _rows(seqs, env):
