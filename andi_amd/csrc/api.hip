@@ -305,7 +305,7 @@ EsaBuildArgs build_args(const andi_hip_esa *e) {
 	a.deep = e->deep, a.flags = e->flags, a.deepK = e->deepK;
 	a.rec = e->rec_valid ? e->rec : nullptr;
 	a.rec2 = e->rec_valid ? e->rec2 : nullptr;
-	a.N0 = e->N0, a.N1 = e->N1;
+	a.N0 = e->N0, a.N1 = e->N1, a.P = e->P;
 	a.min_scratch = e->min_scratch;
 	a.n = e->n;
 	return a;
@@ -919,7 +919,7 @@ int andi_hip_esa_build_index_batch(andi_hip_ctx *ctx, andi_hip_esa *const *esas,
 			ctx->err = "andi_hip_esa_build_index_batch: null subject";
 			return 1;
 		}
-		items[k].S = e->S, items[k].SA = e->SA, items[k].deep = e->deep, items[k].N0 = e->N0, items[k].N1 = e->N1;
+		items[k].S = e->S, items[k].SA = e->SA, items[k].deep = e->deep, items[k].N0 = e->N0, items[k].N1 = e->N1, items[k].P = e->P;
 		items[k].flags = e->flags, items[k].n = e->n, items[k].deepK = e->deepK;
 		items[k].rec = e->rec_valid ? e->rec : nullptr;
 		items[k].rec2 = e->rec_valid ? e->rec2 : nullptr;
@@ -1594,11 +1594,6 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 		}
 		if (!ctx->pool_scratch) return;
 		x.pool_ticket = (uint32_t *)ctx->pool_scratch, x.pool_scratch = (char *)ctx->pool_scratch + 4096, x.pool_waves = ctx->pool_waves, x.pool_bytes = ctx->pool_bytes;
-		// that kernel streams the texts bit-sliced: the subjects' planes are made from their 4-bit symbols in front of its launch (only
-		// there -- a call that takes k_coop_cold does not pay the 0.06 ms: andi_launch_coop_cold)
-		size_t max_n = 0;
-		for (size_t k = 0; k < nsub; ++k) max_n = std::max(max_n, (size_t)subjects[k]->n);
-		x.pool_max_n = max_n;
 	};
 	a.route = routed ? ANDI_LAYOUT_LANES : 0, a.route_seg = coop_seg, a.route_nt = ctx->d_route;
 	uint32_t longest_q = 0;

@@ -21,6 +21,7 @@ struct EsaBuildArgs {
 	int4 *tab;          // 4^10    (out)
 	uint2 *deep;        // 4^deepK (out)
 	uint8_t *N0, *N1;   // 4-bit symbols of the text, two alignments (out; see andi_dev.h)
+	uint32_t *P;        // the text bit-sliced (out; EsaDev.P): what the wavefront kernels stream
 	int32_t *flags;     // 4 ints  (out)
 	const uint32_t *rec; // the suffixes' records in suffix-array order if the device sorter made them (sa_device.hip), else null
 	const uint16_t *rec2; // ... and the symbols behind their first deepK (the short extended form of DEEP_SINGLE), or null
@@ -35,6 +36,7 @@ struct AndiIndexBatchItem {
 	const int32_t *SA;
 	uint2 *deep;
 	uint8_t *N0, *N1;
+	uint32_t *P; // as EsaBuildArgs.P
 	int32_t *flags;
 	const uint32_t *rec; // as EsaBuildArgs.rec
 	const uint16_t *rec2;
@@ -51,6 +53,7 @@ int andi_index_single_ext(size_t queries, bool sorted_on_device);
 hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, hipStream_t st);
 // (scan_lane.hip) packed symbols of the items' texts, `bytes` source bytes each at most (shorter texts stop at their own end)
 hipError_t andi_launch_pack_symbols_batch(const AndiIndexBatchItem *d_items, uint32_t count, size_t bytes, hipStream_t st);
+hipError_t andi_launch_pack_planes_batch(const AndiIndexBatchItem *d_items, uint32_t count, size_t max_n, hipStream_t st); // N0 -> P of every item
 // reference arrays LCP, CLD, FVC, tab (esa_init_LCP/_CLD/_FVC/_cache)
 hipError_t andi_launch_esa_build(const EsaBuildArgs &a, hipStream_t st);
 // scan index: deep, side, flags from S and SA alone

@@ -619,6 +619,9 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, int single_ext, hipStr
 	// symbols for the lane scan: the text, its NUL and 64 bytes of the zero padding behind it
 	e = andi_launch_pack_symbols(a.S, (size_t)n + 1 + 64, a.N0, a.N1, a.flags + 1, st);
 	if (e != hipSuccess) return e;
+	// ... and bit-sliced, for the wavefront kernels' streams (round 6: once per subject here, not in front of every launch of theirs)
+	if (a.P) e = andi_launch_pack_planes(a.N0, (size_t)n + 1 + 64, a.P, st);
+	if (e != hipSuccess) return e;
 	k_probe_table<<<(unsigned)(((int64_t)n + 1 + PT_TILE - 1) / PT_TILE), PT_BLOCK, 0, st>>>(a.N0, a.SA, a.rec, a.rec2, a.deep, a.flags, n,
 																				  a.deepK, single_ext);
 	CHECK_LAUNCH();
@@ -628,6 +631,8 @@ hipError_t andi_launch_index_build(const EsaBuildArgs &a, int single_ext, hipStr
 hipError_t andi_launch_index_build_batch(const AndiIndexBatchItem *d_items, uint32_t count, int32_t max_n, hipStream_t st) {
 	if (count == 0) return hipSuccess;
 	hipError_t e = andi_launch_pack_symbols_batch(d_items, count, (size_t)max_n + 1 + 64, st);
+	if (e != hipSuccess) return e;
+	e = andi_launch_pack_planes_batch(d_items, count, (size_t)max_n, st);
 	if (e != hipSuccess) return e;
 	const dim3 grid((unsigned)(((int64_t)max_n + 1 + PT_TILE - 1) / PT_TILE), count);
 	k_probe_table_batch<<<grid, PT_BLOCK, 0, st>>>(d_items);

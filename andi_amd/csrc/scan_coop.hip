@@ -78,14 +78,10 @@ enum : uint32_t { W_OK = 1, W_OPEN = 2, W_EXIT = 3, W_BREAK = 4, W_STATUS = 7u, 
 template <int NCH>
 struct CoopLds {
 	uint32_t mbits[64 * NCH + 4]; // mismatch bits of the window, bit (x - wbase); the words behind it stay 0: nothing known there
-#ifdef COOP_QGLOBAL
-	uint32_t ebits[64 * NCH]; // (the walks read the query's symbols from global memory: no 2-bit copy of the window in LDS, longer windows)
-#else
 	union {
 		uint32_t q2[128 * NCH + 4]; // the window's query symbols as 2-bit codes, 16 per word, symbol k of a word at bits 2k, 2k + 1: for the walks;
 		uint32_t ebits[64 * NCH];   // once they are done: the stretches behind the heads the chain came by, [head, landing): counted as gaps -- except
 	};
-#endif
 	uint32_t kpos[COOP_KCAP];     // those that start at one of these positions (the walk met anchors off the diagonal): counted nowhere
 	uint32_t nhadx;               // walks of the window that ended that way (at most COOP_KCAP: the others give up)
 	union {
@@ -401,16 +397,9 @@ __device__ __forceinline__ bool coop_probe_fast(const PairCtx &c, const CoopLds<
 		WHY(CS_WHY_PRE);
 		return false;
 	}
-#ifdef COOP_QGLOBAL
-	const uint4 qv = ld_query(c, p & ~1u); // 32 symbols from p (31 if p is odd): the K-mer and the 16 behind it are K + 16 <= 29
-	const uint32_t sh = 4 * (p & 1u);
-	const uint32_t n0 = __builtin_amdgcn_alignbit(qv.y, qv.x, sh), n1 = __builtin_amdgcn_alignbit(qv.z, qv.y, sh), n2 = __builtin_amdgcn_alignbit(qv.w, qv.z, sh), n3 = qv.w >> sh;
-	return coop_probe_codes(c, p, sd, squeeze_codes(n0) | (squeeze_codes(n1) << 16), squeeze_codes(n2) | (squeeze_codes(n3) << 16), r, on_diag, multi_x, multi_n, multi_q);
-#else
 	const uint32_t j = o >> 4, sh = 2 * (o & 15u);
 	const uint32_t w0 = L.q2[j], w1 = L.q2[j + 1], w2 = L.q2[j + 2];
 	return coop_probe_codes(c, p, sd, __builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh), r, on_diag, multi_x, multi_n, multi_q);
-#endif
 }
 
 // The probe of a parked lane whose K-mer occurs n <= 4 times (at SA[x ...]): the longest match is the best of the
@@ -553,6 +542,26 @@ __device__ __forceinline__ void coop_account(const PairCtx &c, Chain &ch, LDS &L
 	}
 }
 
+#include "coop_pool.h" // (mode P, and what mode W takes from it: the texts bit-sliced, the substitutions counted without a loop)
+
+// The twelve counters of all lanes into the 4 x 4 counts in LDS (cell = subject nucleotide << 2 | query nucleotide, src/model.c:309-337), added or
+// taken back.  A window of mode W has at most 32 NCH <= 256 mismatches per lane and kind: two counters to a register, six sums over the lanes;
+// the sums go to lanes 0 ... 11, which add them to their cells in ONE instruction (subst_flush's conditional add per counter by lane 0 cost as
+// much as its scans; every lane adding its own counters to the twelve cells -- 64 adds to one address each -- took the kernel from 3.7 to 4.3 ms).
+__device__ __forceinline__ void subst_flush_pairs(const SubstAcc &acc, lds_u32 *hist, bool add) {
+	const uint32_t lane = __lane_id();
+	uint32_t w = 0; // lane k < 6: the sums of counters k (low half) and k + 6 (high half)
+#pragma unroll
+	for (int k = 0; k < 6; ++k) {
+		const uint32_t sum = wave_sum(acc.n[k] | (acc.n[k + 6] << 16));
+		w = lane == (uint32_t)k ? sum : w;
+	}
+	const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x116, 0xf, 0xf, false); // row_shr:6: lane k + 6 sees lane k's
+	const uint32_t v = lane < 6 ? w & 0xffffu : up >> 16;
+	const uint32_t qn = lane / 3, r = lane - 3 * qn, sn = r + (r >= qn ? 1u : 0u);
+	if (lane < 12 && v) lds_add(&hist[(sn << 2) | qn], add ? v : 0u - v);
+}
+
 // ------------------------------------------------------------------ mode W
 // The chain stands at a canonical state of diagonal dg: st.p = e0 + 1 behind the anchor [lastQ, e0), e0 a mismatch
 // of the diagonal.  Returns true if the chain moved; st is a genuine loop-top state either way.
@@ -569,6 +578,63 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	TICK(tph);
 	// ---- the bits: position x of the window against subject position x + dg; the query's symbols as 2-bit codes
 	uint32_t dirty = 0; // a query symbol of the window that is no nucleotide ('!' of joined contigs): the walks then read the query itself
+	lds_u32 *hist = (lds_u32 *)L.hist;
+	// RAW / JC / Kimura (round 6): the texts are streamed BIT-SLICED (EsaDev.P, ScanArgs.qplanes: three words per 32 symbols), as k_pool_cold's
+	// sweep S does -- the mismatch bits are three instructions per word, and every mismatch of the window is counted as a single-position gap
+	// at once, by kind, without a loop (subst_count): what the chain turns out not to reach, and the stretches that are counted nowhere, are
+	// taken back below.  Until then the counting pass fetched both texts a second time for every word with a mismatch and every stretch's lane
+	// walked its text symbol by symbol: 22 % of the kernel (profiles/r07_coop/README.md).  LogDet / ANI keep the 4-bit stream.
+	// the mismatches of [from, end of the window) out of the counts again
+	auto take_back = [&](uint32_t from) {
+		if constexpr (!EXACT) {
+			if ((from - wbase) / 2048u >= (uint32_t)NCH) return;
+			SubstAcc acc;
+#pragma unroll
+			for (int k = 0; k < 12; ++k) acc.n[k] = 0;
+			for (uint32_t t = (from - wbase) / 2048u; t < (uint32_t)NCH; ++t) {
+				const uint32_t x0 = wbase + 2048 * t + WNT * lane;
+				if (x0 >= c.qlen || x0 + WNT <= from) continue;
+				const Planes qv = ld_query_planes(c, x0), sv = ld_subject_planes(c, (int64_t)x0 + dg);
+				uint32_t mc = ((qv.b0 ^ sv.b0) | (qv.b1 ^ sv.b1) | (qv.b2 ^ sv.b2)) & ~(qv.b2 | sv.b2);
+				if (c.qlen - x0 < WNT) mc &= ~(~0u << (c.qlen - x0));
+				if (from > x0) mc &= ~0u << (from - x0);
+				subst_count(acc, mc, qv, sv);
+			}
+			subst_flush_pairs(acc, hist, false);
+		}
+	};
+	if constexpr (!EXACT) {
+		SubstAcc acc;
+#pragma unroll
+		for (int k = 0; k < 12; ++k) acc.n[k] = 0;
+		const uint32_t sh = (uint32_t)((int64_t)(wbase + WNT * lane) + dg) & 31u; // (a lane's subject offset keeps its low five bits from chunk to chunk)
+#pragma unroll 2
+		for (int ck = 0; ck < NCH; ++ck) {
+			const uint32_t x0 = wbase + 2048 * ck + WNT * lane;
+			uint32_t m = ~0u, mc = 0; // positions at and beyond the query's end: lcp() stops there; mc: the mismatches that are counted
+			uint2 codes = make_uint2(0, 0);
+			if (x0 < c.qlen) {
+				RawPlanes raw;
+				ld_raw_planes(c, x0, (int64_t)x0 + dg, raw);
+				Planes qv, sv;
+				planes_of(raw, sh, qv, sv);
+				m = (qv.b0 ^ sv.b0) | (qv.b1 ^ sv.b1) | (qv.b2 ^ sv.b2);
+				mc = m & ~(qv.b2 | sv.b2); // both nucleotides (src/model.c:318-320)
+				codes = make_uint2(spread16(qv.b0) | (spread16(qv.b1) << 1), spread16(qv.b0 >> 16) | (spread16(qv.b1 >> 16) << 1));
+				uint32_t inq = ~0u;
+				if (c.qlen - x0 < WNT) inq = ~(~0u << (c.qlen - x0)), m |= ~inq, mc &= inq;
+				dirty |= qv.b2 & inq;
+				if (x0 <= e0 && e0 - x0 < WNT) mc &= ~0u << (e0 - x0);
+				if (x0 + WNT <= e0) mc = 0;
+				subst_count(acc, mc, qv, sv);
+			}
+			if (x0 <= e0 && e0 - x0 < WNT) m &= ~0u << (e0 - x0); // (what lies before the anchor is none of the window's business)
+			if (x0 + WNT <= e0) m = 0;
+			L.mbits[64 * ck + lane] = m;
+			*(uint2 *)&L.q2[2 * (64 * ck + lane)] = codes;
+		}
+		subst_flush_pairs(acc, hist, true);
+	} else {
 	// (-DCOOP_STREAM_PIPELINE: the loads of chunk ck + 1 issued before chunk ck is worked on -- the wait for a chunk's loads stands right
 	// behind them otherwise, four memory latencies per window.  Measured no gain, same box: 4.10 against 4.08 ms, three more spilled
 	// registers; profiles/r07_pool/coop_stream_pipeline_ab.txt.  k_pool_cold's sweep S, where the stream is most of the work, keeps its pipeline.)
@@ -596,28 +662,21 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			const uint4 qv = ld_query(c, x0), sv = ld_subject_guarded(c, (int64_t)x0 + dg);
 #endif
 			m = squeeze32(neq32(qv, sv));
-#ifndef COOP_QGLOBAL
 			codes = make_uint2(squeeze_codes(qv.x) | (squeeze_codes(qv.y) << 16), squeeze_codes(qv.z) | (squeeze_codes(qv.w) << 16));
-#endif
 			if (c.qlen - x0 < WNT) m |= ~0u << (c.qlen - x0);
 			dirty |= (qv.x | qv.y | qv.z | qv.w) & 0x44444444u; // bit 2 of a symbol: no nucleotide (the padding behind the query's end too: its last window's walks read the query itself)
 		}
 		if (x0 <= e0 && e0 - x0 < WNT) m &= ~0u << (e0 - x0); // (what lies before the anchor is none of the window's business)
 		if (x0 + WNT <= e0) m = 0;
 		L.mbits[64 * ck + lane] = m;
-#ifndef COOP_QGLOBAL
 		*(uint2 *)&L.q2[2 * (64 * ck + lane)] = codes;
-#else
-		(void)codes;
-#endif
 #ifdef COOP_STREAM_PIPELINE
 		qv = qn, sv = sn;
 #endif
 	}
+	}
 	const bool clean = !__any(dirty != 0);
-#ifndef COOP_QGLOBAL
 	if (lane < 4) L.q2[128 * NCH + lane] = 0;
-#endif
 	if (lane == 0) L.nhadx = 0;
 	if (lane < 4) L.mbits[64 * NCH + lane] = 0;
 	ch.blk_base = NOPOS; // (mode G's block of probes lies where the heads are about to be listed)
@@ -817,13 +876,15 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	wave_sync();
 
 	TOCK(tph, PH_WALKS);
-	for (uint32_t jw = 0; jw < (uint32_t)NCH; ++jw) L.ebits[NCH * lane + jw] = 0; // (the walks are done with the query codes that lay there)
+	if constexpr (EXACT)
+		for (uint32_t jw = 0; jw < (uint32_t)NCH; ++jw) L.ebits[NCH * lane + jw] = 0; // (the walks are done with the query codes that lay there)
 	// ---- the chain hops from head to head; between them every mismatch is followed by a lucky anchor.
 	// Nearly every head is on the chain's path and is followed by the next one: the lanes work out, head by head,
 	// where its walk's anchor ends and whether anything is unusual about it (the next head lies inside the walk's
 	// span; the walk did not land; a position at which the window's knowledge ends comes first); the chain is then
 	// followed from one unusual head to the next with ballots -- a few trips per window, not one per head.
 	uint32_t F = coop_prev_mismatch(L, wbase, wbase + W); // behind the last mismatch nothing is known
+	const uint32_t last_mm = F;
 	if (f_cap < F) F = f_cap;
 	{
 		const int64_t b = (int64_t)c.border - dg; // '#': the next anchor lies on the other strand, no right anchor (src/process.c:162)
@@ -833,7 +894,11 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			if (fe != NOPOS && fe < F) F = fe;
 		}
 	}
-	if (e0 >= F) return false;
+	if (e0 >= F) {
+		take_back(e0);
+		wave_sync();
+		return false;
+	}
 	uint32_t cur = e0, kcur = 0, hop = NOPOS; // hop: the last head the chain hopped from
 	bool done = false;
 	for (uint32_t base = 0; base < nheads && !done; base += 64) {
@@ -908,7 +973,24 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 #endif
 	}
 	if (!done) cur = F; // past the last head: lucky anchors up to where the window's knowledge ends
-	if (cur == e0) return false;
+	if (cur == e0) {
+		take_back(e0);
+		wave_sync();
+		return false;
+	}
+	// What the chain did not reach is taken back.  As a rule it stands at the window's LAST mismatch (cur: the next window's e0): that one
+	// mismatch, by one lane -- its query symbol from the codes in LDS (still there), the subject's by one load; anything else: take_back, below
+	bool taken_back = false;
+	if constexpr (!EXACT) {
+		if (cur == last_mm && cur < c.qlen && clean) {
+			if (lane == 0) {
+				const uint32_t o = cur - wbase, qn = (L.q2[o >> 4] >> (2 * (o & 15u))) & 3u;
+				const uint32_t sn = ld_subject_guarded(c, (int64_t)cur + dg).x & 15u;
+				if (!(sn & 4u)) lds_add(&hist[((sn & 3u) << 2) | qn], 0u - 1u); // (counted only if both are nucleotides)
+			}
+			taken_back = true;
+		}
+	}
 	CSTAT(CS_MOVED, 1);
 	CSTAT(CS_COVERED, cur - e0);
 	wave_sync();
@@ -951,6 +1033,8 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			extra_anchors += (uni(L.hflag[kk]) >> W_NX_SHIFT) & 7u;
 			if (lane == 0) L.kpos[kn] = pk;
 			++kn;
+			if constexpr (!EXACT) // (the stretch is counted nowhere: its mismatches were, with all the window's)
+				pool_uncount_coop(c, hist, pk, (uint32_t)((int64_t)pk + dg), wbase + uni(L.ha[kk]) - pk);
 		}
 	}
 	wave_sync();
@@ -958,6 +1042,56 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	TOCK(tph, PH_HOPS);
 	// ---- the stretches behind the heads the chain came by: gap positions (ebits), unless listed in kpos (counted nowhere);
 	// their symbols are counted here, by the lane of the head (model_count, src/model.c:309-337)
+	if constexpr (!EXACT) {
+		// the mismatches were counted with all the window's: what is left of a stretch (head, landing) are its EQUAL symbols, by nucleotide -- from
+		// the window's bits and the query's codes, both still in LDS (the codes lie where the stretches' bits are about to be written); a window
+		// with a separator ('!' = '!' is no pair of nucleotides) reads the texts instead
+		uint32_t eq0 = 0, eq1 = 0, eq2 = 0, eq3 = 0;
+		for (uint32_t b = 0; b < nheads; b += 64) {
+			const uint32_t i = b + lane;
+			const uint32_t fl = i < nheads ? L.hflag[i] : 0u;
+			const bool ord = (fl & W_ONPATH) && !(fl & W_HADX);
+			const uint32_t o0 = ord ? L.hpos[i] + 1u : 0u, o1 = ord ? L.ha[i] : 0u; // [o0, o1): behind the head's own mismatch
+			if (clean) {
+				for (uint32_t wd = o0 >> 5; 32 * wd < o1; ++wd) {
+					uint32_t rm = ~0u;
+					if (wd == (o0 >> 5)) rm &= ~0u << (o0 & 31u);
+					if (32 * wd + 32 > o1) rm &= (1u << (o1 & 31u)) - 1u;
+					const uint32_t eq = ~L.mbits[wd] & rm, c0 = L.q2[2 * wd], c1 = L.q2[2 * wd + 1];
+					const uint32_t lo = spread16(eq), hi = spread16(eq >> 16); // (a position's bit where its code's low bit lies)
+					eq0 += (uint32_t)__builtin_popcount(lo & ~c0 & ~(c0 >> 1)) + (uint32_t)__builtin_popcount(hi & ~c1 & ~(c1 >> 1));
+					eq1 += (uint32_t)__builtin_popcount(lo & c0 & ~(c0 >> 1)) + (uint32_t)__builtin_popcount(hi & c1 & ~(c1 >> 1));
+					eq2 += (uint32_t)__builtin_popcount(lo & ~c0 & (c0 >> 1)) + (uint32_t)__builtin_popcount(hi & ~c1 & (c1 >> 1));
+					eq3 += (uint32_t)__builtin_popcount(lo & c0 & (c0 >> 1)) + (uint32_t)__builtin_popcount(hi & c1 & (c1 >> 1));
+				}
+			} else {
+				for (uint64_t sl = __ballot(ord && o1 > o0); sl; sl &= sl - 1) {
+					const uint32_t l = (uint32_t)__builtin_ctzll(sl);
+					const uint32_t q0 = wbase + lane_read(o0, l), ln = lane_read(o1, l) - lane_read(o0, l);
+					pool_count_equal_coop(c, q0, (uint32_t)((int64_t)q0 + dg), ln, eq0, eq1, eq2, eq3);
+				}
+			}
+		}
+		{
+			const uint32_t v0 = wave_sum(eq0 | (eq2 << 16)), v1 = wave_sum(eq1 | (eq3 << 16)); // (a lane's stretches hold fewer than 1024 symbols: two sums to a register)
+			if (lane == 0) lds_add(&hist[0], v0 & 0xffffu), lds_add(&hist[5], v1 & 0xffffu), lds_add(&hist[10], v0 >> 16), lds_add(&hist[15], v1 >> 16);
+		}
+		wave_sync();
+		for (uint32_t jw = 0; jw < (uint32_t)NCH; ++jw) L.ebits[NCH * lane + jw] = 0; // (the query's codes that lay there are done with)
+		wave_sync();
+		for (uint32_t b = 0; b < nheads; b += 64) {
+			const uint32_t i = b + lane;
+			const uint32_t fl = i < nheads ? L.hflag[i] : 0u;
+			if (!(fl & W_ONPATH)) continue;
+			const uint32_t o0 = L.hpos[i], o1 = L.ha[i]; // [o0, o1)
+			for (uint32_t wd = o0 >> 5; 32 * wd < o1; ++wd) {
+				uint32_t m = ~0u;
+				if (wd == (o0 >> 5)) m &= ~0u << (o0 & 31u);
+				if (32 * wd + 32 > o1) m &= (1u << (o1 & 31u)) - 1u;
+				lds_or(&L.ebits[wd], m);
+			}
+		}
+	} else
 	{
 		Tally tl;
 		tl.hist = (lds_u32 *)L.hist, tl.hs = 1, tl.quarter = tl.rest = 0;
@@ -1023,6 +1157,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	auto fetch = [&](uint32_t jw, uint4 &qv, uint4 &sv) { // the symbols of a word that has single mismatches (or, LogDet / ANI, anchors) to count
 		const uint32_t w = NCH * lane + jw, x0 = wbase + 32 * w;
 		qv = sv = make_uint4(0, 0, 0, 0);
+		if constexpr (!EXACT) return; // (every mismatch was counted when the window was streamed)
 		if (jw >= (uint32_t)NCH) return;
 		const bool singles = (L.mbits[w] & ~L.ebits[w] & in_range(x0)) != 0;
 		if (singles || (EXACT && anchor_range(x0))) qv = ld_query(c, x0);
@@ -1059,7 +1194,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		}
 		if (u) before = x0 + 31u - (uint32_t)__builtin_clz(u) + 2u;
 		prev_top = u >> 31;
-		for (uint32_t singles = m & ~eb; singles; singles &= singles - 1) { // mismatches in no head's stretch: single-position gaps
+		for (uint32_t singles = EXACT ? m & ~eb : 0u; singles; singles &= singles - 1) { // mismatches in no head's stretch: single-position gaps
 			const uint32_t b = (uint32_t)__builtin_ctz(singles), sh = 4 * (b & 7u);
 			const uint32_t qn = (pick(qv, b >> 3) >> sh) & 15u, sn = (pick(sv, b >> 3) >> sh) & 15u;
 			if (!((qn | sn) & 4u)) lds_add((lds_u32 *)&L.hist[((sn & 3u) << 2) | (qn & 3u)], 1u);
@@ -1079,11 +1214,11 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		(void)nodes;
 		CSTAT(CS_NODES, nodes);
 	}
+	if (!taken_back) take_back(cur); // (the mismatches the chain did not reach)
 	st.p = cur + 1, st.lastS = (uint32_t)((int64_t)aQ + dg), st.lastQ = aQ, st.lastLen = cur - aQ, st.lwra = lw;
 	return true;
 }
 
-#include "coop_pool.h"
 
 // ------------------------------------------------------------------ the kernel
 template <int NCH, bool EXACT>
@@ -1247,9 +1382,9 @@ hipError_t andi_launch_coop_cold(const ScanArgs &a, hipStream_t st) { // one seg
 	const int nch = andi_coop_enabled();
 	// The windows' walks pooled through global memory (k_pool_cold: persistent wavefronts take the segments in order): segments long enough
 	// to fill its windows; in a routed call where the pairs with long sampled matches hold most of the segments (ScanArgs.pool_use)
+	// (both kernels stream the texts bit-sliced -- LogDet / ANI: the 4-bit symbols --: the subjects' planes are made with their scan indexes,
+	// esa_build.hip: andi_launch_index_build)
 	if (andi_coop_will_pool(a)) {
-		hipError_t pe = andi_launch_pack_planes_subjects(a.subjects, a.nsub, a.pool_max_n, st); // (the texts bit-sliced: coop_pool.h)
-		if (pe != hipSuccess) return pe;
 		const uint64_t items = (uint64_t)a.total_segs * a.nsub;
 		ScanArgs b = a;
 		b.pool_first = 64;

@@ -1184,6 +1184,16 @@ __global__ __launch_bounds__(256) void k_pack_planes_subjects(const EsaDev *__re
 	planes[3 * j] = o[0], planes[3 * j + 1] = o[1], planes[3 * j + 2] = o[2];
 }
 
+__global__ __launch_bounds__(256) void k_pack_planes_batch(const AndiIndexBatchItem *__restrict__ items) {
+	const AndiIndexBatchItem it = items[blockIdx.y];
+	if (!it.P || !it.N0) return;
+	const int64_t blocks = ((int64_t)it.n + 1 + 64 + 31) / 32, j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= blocks) return;
+	uint32_t o[3];
+	planes_of(((const uint4 *)it.N0)[j], o);
+	it.P[3 * j] = o[0], it.P[3 * j + 1] = o[1], it.P[3 * j + 2] = o[2];
+}
+
 __global__ __launch_bounds__(256) void k_pack_symbols_batch(const AndiIndexBatchItem *__restrict__ items) {
 	const AndiIndexBatchItem it = items[blockIdx.y];
 	pack_symbols_block(it.S, ((int64_t)it.n + 1 + 64 + 15) / 16, (uint2 *)it.N0, (uint2 *)it.N1, it.flags + 1);
@@ -1228,6 +1238,14 @@ hipError_t andi_launch_pack_planes(const uint8_t *N0, size_t symbols, uint32_t *
 	const int64_t blocks = (int64_t)((symbols + 31) / 32);
 	if (blocks == 0) return hipSuccess;
 	k_pack_planes<<<(unsigned)((blocks + 255) / 256), 256, 0, st>>>((const uint4 *)N0, blocks, planes);
+	CHECK_LAUNCH();
+	return hipSuccess;
+}
+
+hipError_t andi_launch_pack_planes_batch(const AndiIndexBatchItem *d_items, uint32_t count, size_t max_n, hipStream_t st) {
+	const int64_t blocks = (int64_t)((max_n + 1 + 64 + 31) / 32);
+	if (blocks == 0 || count == 0) return hipSuccess;
+	k_pack_planes_batch<<<dim3((unsigned)((blocks + 255) / 256), count), 256, 0, st>>>(d_items);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
