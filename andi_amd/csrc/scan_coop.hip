@@ -1047,6 +1047,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		// the window's bits and the query's codes, both still in LDS (the codes lie where the stretches' bits are about to be written); a window
 		// with a separator ('!' = '!' is no pair of nucleotides) reads the texts instead
 		uint32_t eq0 = 0, eq1 = 0, eq2 = 0, eq3 = 0;
+		uint32_t tt = 0, t0 = 0, t1 = 0, t01 = 0; // equal symbols in all: whose code has bit 0, bit 1, both
 		for (uint32_t b = 0; b < nheads; b += 64) {
 			const uint32_t i = b + lane;
 			const uint32_t fl = i < nheads ? L.hflag[i] : 0u;
@@ -1059,10 +1060,11 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 					if (32 * wd + 32 > o1) rm &= (1u << (o1 & 31u)) - 1u;
 					const uint32_t eq = ~L.mbits[wd] & rm, c0 = L.q2[2 * wd], c1 = L.q2[2 * wd + 1];
 					const uint32_t lo = spread16(eq), hi = spread16(eq >> 16); // (a position's bit where its code's low bit lies)
-					eq0 += (uint32_t)__builtin_popcount(lo & ~c0 & ~(c0 >> 1)) + (uint32_t)__builtin_popcount(hi & ~c1 & ~(c1 >> 1));
-					eq1 += (uint32_t)__builtin_popcount(lo & c0 & ~(c0 >> 1)) + (uint32_t)__builtin_popcount(hi & c1 & ~(c1 >> 1));
-					eq2 += (uint32_t)__builtin_popcount(lo & ~c0 & (c0 >> 1)) + (uint32_t)__builtin_popcount(hi & ~c1 & (c1 >> 1));
-					eq3 += (uint32_t)__builtin_popcount(lo & c0 & (c0 >> 1)) + (uint32_t)__builtin_popcount(hi & c1 & (c1 >> 1));
+					const uint32_t l0 = lo & c0, l1 = lo & (c0 >> 1), h0 = hi & c1, h1 = hi & (c1 >> 1);
+					tt += (uint32_t)__builtin_popcount(eq);
+					t0 += (uint32_t)__builtin_popcount(l0) + (uint32_t)__builtin_popcount(h0);
+					t1 += (uint32_t)__builtin_popcount(l1) + (uint32_t)__builtin_popcount(h1);
+					t01 += (uint32_t)__builtin_popcount(l0 & l1) + (uint32_t)__builtin_popcount(h0 & h1);
 				}
 			} else {
 				for (uint64_t sl = __ballot(ord && o1 > o0); sl; sl &= sl - 1) {
@@ -1072,6 +1074,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 				}
 			}
 		}
+		eq0 += tt - t0 - t1 + t01, eq1 += t0 - t01, eq2 += t1 - t01, eq3 += t01; // (A: neither bit, C: bit 0 alone, G: bit 1 alone, T: both)
 		{
 			const uint32_t v0 = wave_sum(eq0 | (eq2 << 16)), v1 = wave_sum(eq1 | (eq3 << 16)); // (a lane's stretches hold fewer than 1024 symbols: two sums to a register)
 			if (lane == 0) lds_add(&hist[0], v0 & 0xffffu), lds_add(&hist[5], v1 & 0xffffu), lds_add(&hist[10], v0 >> 16), lds_add(&hist[15], v1 >> 16);
