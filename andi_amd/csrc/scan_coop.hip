@@ -32,11 +32,12 @@
 
 namespace {
 
-// (LDS bounds the window at eight wavefronts per SIMD: 5120 bytes each.  Five chunks with 20 heads per chunk are 5068 bytes; fewer heads per
-// chunk cost more than the longer window gains -- 16 per chunk: + 4 %, 20: + 1 %, 32: - 0.5 %; profiles/r07_coop/README.md)
-#define COOP_HCAP (NCH <= 2 ? 64u : NCH == 5 ? 20u * NCH : 24u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
+// (LDS bounds the window at eight wavefronts per SIMD: 5120 bytes each.  Five chunks with 112 heads are 5108 bytes; fewer heads per chunk
+// cost more than the longer window gains -- at four chunks 16 per chunk: + 4 %, 20: + 1 %, 32: - 0.5 %; at five 100 heads drop 6 % of
+// them (a dropped head ends its window), 112 with the list of stretches counted nowhere at 12 instead of 32: - 2 %; profiles/r07_coop/README.md)
+#define COOP_HCAP (NCH <= 2 ? 64u : NCH == 5 ? 112u : 24u * NCH) /* heads of a window that are walked (more: the window ends at the first one dropped) */
 constexpr int COOP_WAVES = 1; // wavefronts per block: single wavefronts find a place on a CU the moment one leaves (bench set 5.39 -> 5.24 ms against blocks of two, 5.61 with four); seven per SIMD (72 registers): 4.94
-constexpr uint32_t COOP_KCAP = 32; // stretches of a window that are counted nowhere (more: the window ends before the next one)
+constexpr uint32_t COOP_KCAP = 12; // stretches of a window that are counted nowhere (more: the window ends before the next one)
 // (routed calls hand a pair back when one of its segments needs more generic steps than ScanArgs.route_giveup -- 1024: long stretches without homology that the sampling missed (clean sets: <= 45 steps; an island of 20 kbp: some 1500).  Grinding through them instead -- the limit at 16384 -- took the structured set's pass A from 9.4 to 28 ms for 9 of its 812 pairs, and its passes B/C from 6.9 to 15 ms: their true chains cross the islands on long segments, one lane each)
 constexpr uint32_t COOP_TRIAL_LCP = 16;  // routed calls: a match followed through more rounds of 2048 symbols than this is longer than its segment
 constexpr uint32_t COOP_PARK = 16; // parked lanes (their probe needs lane_probe) that are served together
