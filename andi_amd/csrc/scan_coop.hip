@@ -745,53 +745,100 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 			return r;
 		};
 		auto generic_probe = [&](uint32_t pp) { return coop_generic_probe(c, pp); };
-		for (;;) {
-			const uint64_t idle = __ballot(hk == NOPOS);
-			if (idle && next_head < nheads) {
-				const uint32_t my = next_head + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-				if (hk == NOPOS && my < nheads) hk = my, e = wbase + L.hpos[my], p = e + 1, Xl = 0, nX = 0, parked = false;
-				next_head += (uint32_t)__builtin_popcountll(idle);
-			}
-			const uint64_t busy = __ballot(hk != NOPOS), waiting = __ballot(hk != NOPOS && parked);
-			if (!busy) break;
-			// the parked lanes' turn?
-			// (... or no head is left to take: served only when nothing else was left, a parked lane's remaining steps ran alone behind all the others)
-			const bool service = waiting && ((uint32_t)__builtin_popcountll(waiting) >= COOP_PARK || waiting == busy || next_head >= nheads);
-#ifdef ANDI_COOP_STATS
-			if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
-				const uint32_t nb = (uint32_t)__builtin_popcountll(service ? waiting : busy & ~waiting); // lanes at work in this trip
-				atomicAdd(&g_coop_trip_lanes[service ? 1 : 0][nb ? 32 - __builtin_clz(nb) : 0], 1ull);
-				atomicAdd(&g_coop_stats[service ? CS_SERVICE : CS_TRIPS], 1ull);
-				atomicAdd(&g_coop_stats[service ? CS_SERVICE_LANES : CS_LANE_STEPS], (unsigned long long)__builtin_popcountll(service ? waiting : busy & ~waiting));
-			}
-#endif
-			if (hk == NOPOS || parked != service) continue;
-			uint32_t res = 0, ra = 0, rlen = 0;
-			Probe pr;
-			pr.len = 0, pr.pos = 0, pr.unique = false;
-			bool have = false; // pr is the answer for p
-			if (service) {
-				bool long_diag = false;
-				if (mn) {
-					bool seen;
-					const uint32_t r = run_ahead(p, seen);
-					have = coop_probe_multi(c, p, sd, mx, mn, mq, r, seen, pr, long_diag);
-				}
-				if (!have) pr = generic_probe(p), long_diag = false;
-				have = true, parked = false;
-#ifdef ANDI_COOP_STATS
-				atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
-#endif
-				if (long_diag && pr.unique) { // the diagonal's occurrence is the longest, longer than the bits at hand show
-					if (wbase + W - p >= 32) {
+		// what a step's outcome does to its walk: on with the next position, or the head's result (res: how it ended, ra: where it landed, rlen: the
+		// length of the anchor it landed on)
+		auto settle = [&](uint32_t res, uint32_t ra, uint32_t rlen, const Probe &pr, bool have) {
+			if (!res && have) {
+				if (pr.unique && pr.len >= thr) {
+					if (pr.pos == p + sd) { // on the diagonal
+						// a right anchor of the anchor before the head only on the same strand (src/process.c:162)
 						const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
-						res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
-						ra = p;
+						if (!same_side || (Xl && Xl >= 2 * thr))
+							res = W_BREAK;
+						else
+							res = W_OK | (rlen == NOPOS ? W_LUCKY : 0u) | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT), ra = p, rlen = rlen == NOPOS ? 0u : pr.len;
 					} else {
-						pr = generic_probe(p); // (the window's end)
+						const uint32_t endS = Xs + Xl, endQ = Xq + Xl;
+						if (Xl && ((pr.pos > endS && p - endQ == pr.pos - endS && (pr.pos < c.border) == (Xs < c.border)) || Xl >= 2 * thr))
+							res = W_BREAK; // a right anchor off the diagonal (its gap is not in the window), or an anchor that is counted by itself
+						else if (++nX > COOP_MAX_X)
+							res = W_BREAK;
+						else
+							Xq = p, Xs = pr.pos, Xl = pr.len;
 					}
 				}
-			} else {
+				if (!res) p += pr.len + 1;
+			}
+			if (res) {
+				if ((res & W_LUCKY) && (ra + sd < c.border) != (e + sd <= c.border)) res = W_BREAK;
+				if ((res & W_STATUS) == W_OK && (res & W_HADX) && atomicAdd(&L.nhadx, 1u) >= COOP_KCAP) res = W_BREAK; // (the list of such stretches is full)
+				L.ha[hk] = (uint16_t)(ra - wbase), L.hend[hk] = rlen, L.hflag[hk] = (uint16_t)res;
+				hk = NOPOS;
+			}
+		};
+		// The parked lanes' turn -- coop_probe_multi, lane_probe: most of this loop's code -- stands in FRONT of the loop of the ordinary trips, not
+		// inside it (two loops, the inner one small): 3.52 -> 3.36 ms on the bench set.
+		bool due = false;
+		for (;;) {
+			if (due) {
+				due = false;
+				if (hk != NOPOS && parked) {
+					uint32_t res = 0, ra = 0, rlen = 0;
+					Probe pr;
+					pr.len = 0, pr.pos = 0, pr.unique = false;
+					bool have = false; // pr is the answer for p
+					bool long_diag = false;
+					if (mn) {
+						bool seen;
+						const uint32_t r = run_ahead(p, seen);
+						have = coop_probe_multi(c, p, sd, mx, mn, mq, r, seen, pr, long_diag);
+					}
+					if (!have) pr = generic_probe(p), long_diag = false;
+					have = true, parked = false;
+#ifdef ANDI_COOP_STATS
+					atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
+#endif
+					if (long_diag && pr.unique) { // the diagonal's occurrence is the longest, longer than the bits at hand show
+						if (wbase + W - p >= 32) {
+							const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
+							res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
+							ra = p;
+						} else {
+							pr = generic_probe(p); // (the window's end)
+						}
+					}
+					settle(res, ra, rlen, pr, have);
+				}
+			}
+			for (;;) {
+				const uint64_t idle = __ballot(hk == NOPOS);
+				if (idle && next_head < nheads) {
+					const uint32_t my = next_head + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+					if (hk == NOPOS && my < nheads) hk = my, e = wbase + L.hpos[my], p = e + 1, Xl = 0, nX = 0, parked = false;
+					next_head += (uint32_t)__builtin_popcountll(idle);
+				}
+				const uint64_t busy = __ballot(hk != NOPOS), waiting = __ballot(hk != NOPOS && parked);
+				if (!busy) break;
+				// the parked lanes' turn?
+				// (... or no head is left to take: served only when nothing else was left, a parked lane's remaining steps ran alone behind all the others)
+				const bool service = waiting && ((uint32_t)__builtin_popcountll(waiting) >= COOP_PARK || waiting == busy || next_head >= nheads);
+#ifdef ANDI_COOP_STATS
+				if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
+					const uint32_t nb = (uint32_t)__builtin_popcountll(service ? waiting : busy & ~waiting); // lanes at work in this trip
+					atomicAdd(&g_coop_trip_lanes[service ? 1 : 0][nb ? 32 - __builtin_clz(nb) : 0], 1ull);
+					atomicAdd(&g_coop_stats[service ? CS_SERVICE : CS_TRIPS], 1ull);
+					atomicAdd(&g_coop_stats[service ? CS_SERVICE_LANES : CS_LANE_STEPS], (unsigned long long)__builtin_popcountll(service ? waiting : busy & ~waiting));
+				}
+#endif
+				if (service) {
+					due = true;
+					break;
+				}
+				if (hk == NOPOS || parked) continue;
+				uint32_t res = 0, ra = 0, rlen = 0;
+				Probe pr;
+				pr.len = 0, pr.pos = 0, pr.unique = false;
+				bool have = false; // pr is the answer for p
 				// ---- a lane that is not parked: the step's conditions as values, few branches (a wavefront executes every
 				// branch some lane takes, and keeps the books of the execution mask for each: the nested form of this cost
 				// 230 vector and 260 scalar instructions per trip)
@@ -844,34 +891,9 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 					if (have) atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
 #endif
 				}
+				settle(res, ra, rlen, pr, have);
 			}
-			if (!res && have) {
-				if (pr.unique && pr.len >= thr) {
-					if (pr.pos == p + sd) { // on the diagonal
-						// a right anchor of the anchor before the head only on the same strand (src/process.c:162)
-						const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
-						if (!same_side || (Xl && Xl >= 2 * thr))
-							res = W_BREAK;
-						else
-							res = W_OK | (rlen == NOPOS ? W_LUCKY : 0u) | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT), ra = p, rlen = rlen == NOPOS ? 0u : pr.len;
-					} else {
-						const uint32_t endS = Xs + Xl, endQ = Xq + Xl;
-						if (Xl && ((pr.pos > endS && p - endQ == pr.pos - endS && (pr.pos < c.border) == (Xs < c.border)) || Xl >= 2 * thr))
-							res = W_BREAK; // a right anchor off the diagonal (its gap is not in the window), or an anchor that is counted by itself
-						else if (++nX > COOP_MAX_X)
-							res = W_BREAK;
-						else
-							Xq = p, Xs = pr.pos, Xl = pr.len;
-					}
-				}
-				if (!res) p += pr.len + 1;
-			}
-			if (res) {
-				if ((res & W_LUCKY) && (ra + sd < c.border) != (e + sd <= c.border)) res = W_BREAK;
-				if ((res & W_STATUS) == W_OK && (res & W_HADX) && atomicAdd(&L.nhadx, 1u) >= COOP_KCAP) res = W_BREAK; // (the list of such stretches is full)
-				L.ha[hk] = (uint16_t)(ra - wbase), L.hend[hk] = rlen, L.hflag[hk] = (uint16_t)res;
-				hk = NOPOS;
-			}
+			if (!due) break;
 		}
 	}
 	wave_sync();
