@@ -474,59 +474,120 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 			return r;
 		};
 		auto generic_probe = [&](uint32_t pp) { return coop_generic_probe(c, pp); };
-		for (;;) {
-			const uint64_t idle = __ballot(hk == NOPOS);
-			if (idle && next_head < nheads) {
-				const uint32_t my = next_head + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-				if (hk == NOPOS && my < nheads) {
-					const PoolRec rc = G->rec[my];
-					hk = my, e = rc.pos, p = e + 1, Xl = 0, nX = 0, parked = false;
-					cq0 = rc.q2[0], cq1 = rc.q2[1], cq2 = rc.q2[2], cq3 = rc.q2[3], cb0 = rc.bits[0], cb1 = rc.bits[1];
-					hclean = clean || rc.dirty == 0;
-				}
-				next_head += (uint32_t)__builtin_popcountll(idle);
-			}
-			const uint64_t busy = __ballot(hk != NOPOS), waiting = __ballot(hk != NOPOS && parked);
-			if (!busy) break;
-			const bool service = waiting && ((uint32_t)__builtin_popcountll(waiting) >= COOP_PARK || waiting == busy);
-#ifdef ANDI_COOP_STATS
-			if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
-				const uint32_t nb = (uint32_t)__builtin_popcountll(service ? waiting : busy & ~waiting);
-				atomicAdd(&g_coop_trip_lanes[service ? 1 : 0][nb ? 32 - __builtin_clz(nb) : 0], 1ull);
-				atomicAdd(&g_coop_stats[service ? CS_SERVICE : CS_TRIPS], 1ull);
-				atomicAdd(&g_coop_stats[service ? CS_SERVICE_LANES : CS_LANE_STEPS], (unsigned long long)__builtin_popcountll(service ? waiting : busy & ~waiting));
-			}
-#endif
-			if (hk == NOPOS || parked != service) continue;
-			uint32_t res = 0, ra = 0, rlen = 0;
-			Probe pr;
-			pr.len = 0, pr.pos = 0, pr.unique = false;
-			bool have = false;
-			if (service) {
-				bool long_diag = false;
-				if (mn) {
-					bool seen;
-					const uint32_t r = run_ahead(p, seen);
-					have = coop_probe_multi<false>(c, p, sd, mx, mn, mq, r, seen, pr, long_diag); // (the sorter's records -- k_coop_cold's first try -- cost this kernel 12 more spilled registers: C4 shape 24.7 -> 28.9 ms)
-				}
-				// (measured: without lane_probe in this loop -- such a probe ending the window at its head instead -- the kernel fits 64 registers
-				// with 19 spilled, but eight wavefronts per SIMD are no faster than six at equal work, and the windows cut short cost
-				// sweep S five times over: profiles/r07_pool/no_generic_probe_occupancy.txt)
-				if (!have) pr = generic_probe(p), long_diag = false;
-				have = true, parked = false;
-#ifdef ANDI_COOP_STATS
-				atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
-#endif
-				if (long_diag && pr.unique) {
-					if (wend - p >= 32) {
+		auto settle = [&](uint32_t res, uint32_t ra, uint32_t rlen, const Probe &pr, bool have) { // (as coop_window's)
+			if (!res && have) {
+				if (pr.unique && pr.len >= thr) {
+					if (pr.pos == p + sd) {
 						const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
-						res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
-						ra = p;
+						if (!same_side || (Xl && Xl >= 2 * thr))
+							res = W_BREAK;
+						else
+							res = W_OK | (rlen == NOPOS ? W_LUCKY : 0u) | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT), ra = p, rlen = rlen == NOPOS ? 0u : pr.len;
 					} else {
-						pr = generic_probe(p);
+						const uint32_t endS = Xs + Xl, endQ = Xq + Xl;
+						if (Xl && ((pr.pos > endS && p - endQ == pr.pos - endS && (pr.pos < c.border) == (Xs < c.border)) || Xl >= 2 * thr))
+							res = W_BREAK;
+						else if (++nX > COOP_MAX_X)
+							res = W_BREAK;
+						else
+							Xq = p, Xs = pr.pos, Xl = pr.len;
 					}
 				}
-			} else {
+				if (!res) p += pr.len + 1;
+			}
+			if (res) {
+				if ((res & W_LUCKY) && (ra + sd < c.border) != (e + sd <= c.border)) res = W_BREAK;
+				// the equal symbols of the stretch (e, ra) by nucleotide, for sweep R: from the record, if the stretch lies inside it
+				uint32_t eq = 0;
+				bool eq_valid = false;
+				{
+					const uint32_t len = ra - e - 1;
+					if ((res & W_STATUS) == W_OK && !(res & W_HADX) && hclean && len - 1u < POOL_EQ_MAX) {
+						eq_valid = true;
+						uint32_t eqlo = ~cb0, eqhi = ~cb1; // the equal positions among the len <= 63 behind the head
+						if (len < 32) eqlo &= (1u << len) - 1u, eqhi = 0;
+						else eqhi &= (1u << (len - 32)) - 1u;
+						const uint32_t n0 = (uint32_t)__builtin_popcount(eqlo & ~cq2 & ~cq0) + (uint32_t)__builtin_popcount(eqhi & ~cq3 & ~cq1);
+						const uint32_t n1 = (uint32_t)__builtin_popcount(eqlo & ~cq2 & cq0) + (uint32_t)__builtin_popcount(eqhi & ~cq3 & cq1);
+						const uint32_t n2 = (uint32_t)__builtin_popcount(eqlo & cq2 & ~cq0) + (uint32_t)__builtin_popcount(eqhi & cq3 & ~cq1);
+						const uint32_t n3 = (uint32_t)__builtin_popcount(eqlo & cq2 & cq0) + (uint32_t)__builtin_popcount(eqhi & cq3 & cq1);
+						eq = n0 | (n1 << 6) | (n2 << 12) | (n3 << 18);
+					}
+				}
+				PoolRes rs;
+				rs.pos = e, rs.ha = ra, rs.hend = rlen, rs.flag = pool_pack_flag(res, eq, eq_valid);
+				G->res[hk] = rs;
+				hk = NOPOS;
+			}
+		};
+		// (the parked lanes' turn in front of the loop of the ordinary trips, as in coop_window)
+		bool due = false;
+		for (;;) {
+			if (due) {
+				due = false;
+				if (hk != NOPOS && parked) {
+					uint32_t res = 0, ra = 0, rlen = 0;
+					Probe pr;
+					pr.len = 0, pr.pos = 0, pr.unique = false;
+					bool have = false;
+					bool long_diag = false;
+					if (mn) {
+						bool seen;
+						const uint32_t r = run_ahead(p, seen);
+						have = coop_probe_multi<false>(c, p, sd, mx, mn, mq, r, seen, pr, long_diag); // (the sorter's records -- k_coop_cold's first try -- cost this kernel 12 more spilled registers: C4 shape 24.7 -> 28.9 ms)
+					}
+					// (measured: without lane_probe in this loop -- such a probe ending the window at its head instead -- the kernel fits 64 registers
+					// with 19 spilled, but eight wavefronts per SIMD are no faster than six at equal work, and the windows cut short cost
+					// sweep S five times over: profiles/r07_pool/no_generic_probe_occupancy.txt)
+					if (!have) pr = generic_probe(p), long_diag = false;
+					have = true, parked = false;
+#ifdef ANDI_COOP_STATS
+					atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
+#endif
+					if (long_diag && pr.unique) {
+						if (wend - p >= 32) {
+							const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
+							res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
+							ra = p;
+						} else {
+							pr = generic_probe(p);
+						}
+					}
+					settle(res, ra, rlen, pr, have);
+				}
+			}
+			for (;;) {
+				const uint64_t idle = __ballot(hk == NOPOS);
+				if (idle && next_head < nheads) {
+					const uint32_t my = next_head + (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+					if (hk == NOPOS && my < nheads) {
+						const PoolRec rc = G->rec[my];
+						hk = my, e = rc.pos, p = e + 1, Xl = 0, nX = 0, parked = false;
+						cq0 = rc.q2[0], cq1 = rc.q2[1], cq2 = rc.q2[2], cq3 = rc.q2[3], cb0 = rc.bits[0], cb1 = rc.bits[1];
+						hclean = clean || rc.dirty == 0;
+					}
+					next_head += (uint32_t)__builtin_popcountll(idle);
+				}
+				const uint64_t busy = __ballot(hk != NOPOS), waiting = __ballot(hk != NOPOS && parked);
+				if (!busy) break;
+				const bool service = waiting && ((uint32_t)__builtin_popcountll(waiting) >= COOP_PARK || waiting == busy);
+#ifdef ANDI_COOP_STATS
+				if (lane == (uint32_t)__builtin_ctzll(__ballot(1))) {
+					const uint32_t nb = (uint32_t)__builtin_popcountll(service ? waiting : busy & ~waiting);
+					atomicAdd(&g_coop_trip_lanes[service ? 1 : 0][nb ? 32 - __builtin_clz(nb) : 0], 1ull);
+					atomicAdd(&g_coop_stats[service ? CS_SERVICE : CS_TRIPS], 1ull);
+					atomicAdd(&g_coop_stats[service ? CS_SERVICE_LANES : CS_LANE_STEPS], (unsigned long long)__builtin_popcountll(service ? waiting : busy & ~waiting));
+				}
+#endif
+				if (service) {
+					due = true;
+					break;
+				}
+				if (hk == NOPOS || parked) continue;
+				uint32_t res = 0, ra = 0, rlen = 0;
+				Probe pr;
+				pr.len = 0, pr.pos = 0, pr.unique = false;
+				bool have = false;
 				const uint32_t o = p - wbase;
 				const bool inwin = p < end && o < Wp;
 				bool seen;
@@ -584,51 +645,9 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 					if (have) atomicAdd(&g_coop_stats[CS_PROBES], 1ull);
 #endif
 				}
+				settle(res, ra, rlen, pr, have);
 			}
-			if (!res && have) {
-				if (pr.unique && pr.len >= thr) {
-					if (pr.pos == p + sd) {
-						const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
-						if (!same_side || (Xl && Xl >= 2 * thr))
-							res = W_BREAK;
-						else
-							res = W_OK | (rlen == NOPOS ? W_LUCKY : 0u) | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT), ra = p, rlen = rlen == NOPOS ? 0u : pr.len;
-					} else {
-						const uint32_t endS = Xs + Xl, endQ = Xq + Xl;
-						if (Xl && ((pr.pos > endS && p - endQ == pr.pos - endS && (pr.pos < c.border) == (Xs < c.border)) || Xl >= 2 * thr))
-							res = W_BREAK;
-						else if (++nX > COOP_MAX_X)
-							res = W_BREAK;
-						else
-							Xq = p, Xs = pr.pos, Xl = pr.len;
-					}
-				}
-				if (!res) p += pr.len + 1;
-			}
-			if (res) {
-				if ((res & W_LUCKY) && (ra + sd < c.border) != (e + sd <= c.border)) res = W_BREAK;
-				// the equal symbols of the stretch (e, ra) by nucleotide, for sweep R: from the record, if the stretch lies inside it
-				uint32_t eq = 0;
-				bool eq_valid = false;
-				{
-					const uint32_t len = ra - e - 1;
-					if ((res & W_STATUS) == W_OK && !(res & W_HADX) && hclean && len - 1u < POOL_EQ_MAX) {
-						eq_valid = true;
-						uint32_t eqlo = ~cb0, eqhi = ~cb1; // the equal positions among the len <= 63 behind the head
-						if (len < 32) eqlo &= (1u << len) - 1u, eqhi = 0;
-						else eqhi &= (1u << (len - 32)) - 1u;
-						const uint32_t n0 = (uint32_t)__builtin_popcount(eqlo & ~cq2 & ~cq0) + (uint32_t)__builtin_popcount(eqhi & ~cq3 & ~cq1);
-						const uint32_t n1 = (uint32_t)__builtin_popcount(eqlo & ~cq2 & cq0) + (uint32_t)__builtin_popcount(eqhi & ~cq3 & cq1);
-						const uint32_t n2 = (uint32_t)__builtin_popcount(eqlo & cq2 & ~cq0) + (uint32_t)__builtin_popcount(eqhi & cq3 & ~cq1);
-						const uint32_t n3 = (uint32_t)__builtin_popcount(eqlo & cq2 & cq0) + (uint32_t)__builtin_popcount(eqhi & cq3 & cq1);
-						eq = n0 | (n1 << 6) | (n2 << 12) | (n3 << 18);
-					}
-				}
-				PoolRes rs;
-				rs.pos = e, rs.ha = ra, rs.hend = rlen, rs.flag = pool_pack_flag(res, eq, eq_valid);
-				G->res[hk] = rs;
-				hk = NOPOS;
-			}
+			if (!due) break;
 		}
 	}
 	pool_sync();
