@@ -531,24 +531,10 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 	}
 	__syncthreads();
 
-	for (uint32_t t = threadIdx.x; t < total; t += PT_BLOCK) {
+	// what entry t of the piece holds, a its owner (ONE store per entry, whatever it is: 256 consecutive entries by one instruction -- two stores
+	// under complementary masks wrote every line of the table in two pieces)
+	auto write_entry = [&](uint32_t t, uint32_t a) {
 		const uint32_t c = base + t;
-		uint32_t a;
-		if (t < PT_RANKED) {
-			const uint32_t word = t >> 5;
-			a = s_owner[s_before[word] + (uint32_t)__builtin_popcount(s_bits[word] & (0xffffffffu >> (31u - (t & 31u)))) - 1u];
-		} else {
-			// the gap that owns code c: the last one whose first code is <= c (gaps that own nothing share their
-			// successor's first code)
-			uint32_t b = PT_TILE; // invariant: s_first[a] <= c < s_first[b]
-			a = 0;
-			while (b - a > 1) {
-				uint32_t mid = (a + b) >> 1;
-				if (s_first[mid] <= c) a = mid; else b = mid;
-			}
-		}
-		// (ONE store per entry, whatever it is: 256 consecutive entries by one instruction -- two stores under complementary masks wrote
-		// every line of the table in two pieces)
 		const bool is_present = c - s_first[a] >= s_absent[a]; // the K-mer of suffix r itself
 		const uint2 pres = s_present[a];
 		const uint32_t rr = r0 + a;
@@ -556,8 +542,8 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		// is the left (right) neighbour the only suffix sharing a given prefix length with it?
 		// lcp(suffix rr-2, rr-1) and lcp(suffix rr, rr+1) are the neighbouring gaps' h (0 outside the text)
 		const uint32_t gl = s_rec[a + 1], gr = s_rec[a + 2], hll = s_h[a], hrr = s_h[a + 2];
-		uint32_t lL = gL ? rec_lcp_code(c, gl, K) : 0u;
-		uint32_t lR = gR ? rec_lcp_code(c, gr, K) : 0u;
+		const uint32_t xL = rec_lcp_code(c, gl, K), xR = rec_lcp_code(c, gr, K); // (both computed, then selected: no branch around seven instructions)
+		const uint32_t lL = gL ? xL : 0u, lR = gR ? xR : 0u;
 		// (selects: both neighbours sharing l characters -- or l == 0: every suffix does -- is the third case)
 		const bool left = lL > lR, right = lR > lL;
 		const uint32_t l = left ? lL : lR;
@@ -566,6 +552,22 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		const uint32_t uniq = ((left || right) && l != 0) ? (alone ? 1u : 0u) : (n == 1 ? 1u : 0u);
 		const uint2 val = is_present ? pres : make_uint2(idx, DEEP_FINAL | (uniq << 2) | (l << 8));
 		__builtin_nontemporal_store(((unsigned long long)val.y << 32) | val.x, (unsigned long long *)(deep + c));
+	};
+	// (two loops: the ranked entries -- all of them, as a rule -- in one without the binary search's branch and inner loop)
+	const uint32_t ranked = total < PT_RANKED ? total : PT_RANKED;
+	for (uint32_t t = threadIdx.x; t < ranked; t += PT_BLOCK) {
+		const uint32_t word = t >> 5;
+		write_entry(t, s_owner[s_before[word] + (uint32_t)__builtin_popcount(s_bits[word] & (0xffffffffu >> (31u - (t & 31u)))) - 1u]);
+	}
+	for (uint32_t t = PT_RANKED + threadIdx.x; t < total; t += PT_BLOCK) {
+		// the gap that owns code c: the last one whose first code is <= c (gaps that own nothing share their successor's first code)
+		const uint32_t c = base + t;
+		uint32_t a = 0, b = PT_TILE; // invariant: s_first[a] <= c < s_first[b]
+		while (b - a > 1) {
+			const uint32_t mid = (a + b) >> 1;
+			if (s_first[mid] <= c) a = mid; else b = mid;
+		}
+		write_entry(t, a);
 	}
 }
 
