@@ -692,13 +692,21 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 	for (int j = 0; j < NCH; ++j) {
 		const uint32_t w = NCH * lane + j;
 		const uint32_t cur = L.mbits[w], nxt = L.mbits[w + 1], prv = w ? L.mbits[w - 1] : 0u;
-		// a mismatch among the next thr positions / among the thr positions before: smear the bits over thr - 1 more
-		// positions (doubling, then the remainder), then shift by one
-		uint64_t up = ((uint64_t)nxt << 32) | cur, dn = ((uint64_t)cur << 32) | prv;
+		// a mismatch among the next thr positions / among the thr positions before: the bits smeared over thr - 1 more positions (doubling,
+		// then the remainder) -- on 32-bit words with funnel shifts, as k_pool_cold's sweep S does it (64-bit shifts and ors: twice the instructions)
+		uint32_t soon = __builtin_amdgcn_alignbit(nxt, cur, 1), sn = nxt >> 1;   // bit x: position x + 1
+		uint32_t before = __builtin_amdgcn_alignbit(cur, prv, 31), bp = prv << 1; // bit x: position x - 1
 		uint32_t have = 1;
-		while (2 * have <= thr) up |= up >> have, dn |= dn << have, have *= 2;
-		if (have < thr) up |= up >> (thr - have), dn |= dn << (thr - have);
-		const uint32_t soon = (uint32_t)(up >> 1), before = (uint32_t)((dn << 1) >> 32);
+		while (2 * have <= thr) {
+			soon |= __builtin_amdgcn_alignbit(sn, soon, have), sn |= sn >> have;
+			before |= __builtin_amdgcn_alignbit(before, bp, 32 - have), bp |= bp << have;
+			have *= 2;
+		}
+		if (have < thr) {
+			const uint32_t r = thr - have;
+			soon |= __builtin_amdgcn_alignbit(sn, soon, r);
+			before |= __builtin_amdgcn_alignbit(before, bp, 32 - r);
+		}
 		uint32_t live = ~0u; // a chain that stands behind position x >= end - 1 has left the segment
 		const uint32_t x0 = wbase + 32 * w;
 		if (x0 + 1 >= end) live = 0;
