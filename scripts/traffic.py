@@ -2,7 +2,7 @@
 """profiles/traffic.json from the counters of an end state: scripts/traffic.py <pmc summary> <bench line> <name the summary is kept under>.
 HBM-side bytes per launch of pass A = FETCH_SIZE + WRITE_SIZE (KiB, separate --pmc passes), corrected as
 MI355X_MICROARCH.md prescribes for gfx950: wide coalesced streaming reads are counted at half, so half of the window
-stream's bytes (one byte per scanned query nucleotide: two 4-bit texts) are added when the wavefront kernel ran; the
+stream's bytes (0.75 byte per scanned query nucleotide: two bit-sliced texts) are added when a wavefront kernel ran; the
 scattered 8-64 byte probe loads are counted exactly (profiles/micro/r02_fetch_size_calibration.txt)."""
 import json
 import os
@@ -33,7 +33,8 @@ for ln in open(summary):
 if not seen:
     sys.exit("traffic.py: no FETCH_SIZE / WRITE_SIZE of %s in %s" % (kernel, summary))
 raw = (fetch + write) * 1024.0
-stream = line["roofline"]["algorithmic_bytes_per_launch"] / 2.0 if ("coop" in kernel or "pool" in kernel) else 0.0  # 1 B per query nt (k_pool_cold: 0.75 B, bit-sliced)
+# the wavefront kernels stream both texts bit-sliced (12 bytes per 32 symbols): 0.75 byte per scanned query nucleotide (until round 6 k_coop_cold streamed 4-bit symbols: 1 byte)
+stream = 0.75 * line["roofline"]["algorithmic_bytes_per_launch"] / 2.0 if ("coop" in kernel or "pool" in kernel) else 0.0
 cfg = line["config"]
 key = "G%d_L%d_seg0" % (cfg["genomes"], cfg["length"])
 print(json.dumps({
