@@ -83,15 +83,18 @@ __global__ __launch_bounds__(64 * EST_WAVES_FEW) void k_pair_estimate(ScanArgs a
 	// Joined contigs: every separator of the query or of the subject ends the pair's diagonal (the genomes' contigs are cut at different
 	// places), and a wavefront kernel pays a window for every end.  C4 shape of genomes of 100 / 20 contigs, per call: k_pool_cold 117 / 48 ms,
 	// k_coop_cold 87 / 37, the lane scan 54 / 44 (whole genomes: 20 by k_pool_cold); bench set of 100-contig genomes (an end every 24 500
-	// positions): lanes 8.2, k_coop_cold 9.5 ms.  So by the mean distance between the ends: below 32768 positions the lane scan, below
-	// 262144 -- two windows of k_pool_cold -- no candidate of that kernel (C4 shape of 8-contig genomes, an end every 131 000 positions:
-	// k_pool_cold 33.7, k_coop_cold 30.0 ms; profiles/r07_pool/join_routing.txt, join_sweep.txt).
+	// positions): lanes 8.2, k_coop_cold 9.5 ms.  So by the mean distance between the ends: below 20480 positions -- two of k_coop_cold's
+	// windows -- the lane scan, below 262144 -- two windows of k_pool_cold -- no candidate of that kernel (C4 shape of 8-contig genomes, an end
+	// every 131 000 positions: k_pool_cold 33.7, k_coop_cold 30.0 ms; profiles/r07_pool/join_routing.txt, join_sweep.txt).  (32768 until
+	// k_coop_cold's second session of round 6: with that kernel a sixth faster the C4 shape of 40-contig genomes -- an end every 26 000
+	// positions -- takes 41.3 ms by wavefronts against 50.9 by lanes, the bench set of 100-contig genomes -- 24 500 -- 10.6 either way, the C4
+	// shape of 100-contig genomes -- 10 500 -- 71 against 59: profiles/r07_coop/join_threshold.txt.)
 	uint32_t break_dist = ~0u;
 	if (a.qsep && a.self[sub] >= 0) {
 		const uint32_t ends = a.qsep[qidx] + a.qsep[(uint32_t)a.self[sub]];
 		if (ends) break_dist = c.qlen / ends;
 	}
-	const bool coop_cand = a.route && (sum >> 6) < 512u && c.qlen >= (a.route_seg < ANDI_ROUTE_MIN_QLEN ? a.route_seg : ANDI_ROUTE_MIN_QLEN) && break_dist >= 32768u; // (matches of 512 symbols and more on average: k_lane_quad's, always)
+	const bool coop_cand = a.route && (sum >> 6) < 512u && c.qlen >= (a.route_seg < ANDI_ROUTE_MIN_QLEN ? a.route_seg : ANDI_ROUTE_MIN_QLEN) && break_dist >= 20480u; // (matches of 512 symbols and more on average: k_lane_quad's, always)
 	if (coop_cand) { // (wave-uniform)
 		// Unrelated stretches are contiguous: where a sample sees less than a threshold's worth of matching symbols, four
 		// more are taken, 128 symbols apart.  Five short ones in a row come about by chance at the fifth power of the rate of
