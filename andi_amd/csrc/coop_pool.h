@@ -534,7 +534,7 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 					if (mn) {
 						bool seen;
 						const uint32_t r = run_ahead(p, seen);
-						have = coop_probe_multi<false>(c, p, sd, mx, mn, mq, r, seen, pr, long_diag); // (the sorter's records -- k_coop_cold's first try -- cost this kernel 12 more spilled registers: C4 shape 24.7 -> 28.9 ms)
+						have = coop_probe_multi<false>(c, p, sd, mx, mn, mq, r, seen, pr, long_diag); // (the sorter's records were the ordinary trip's own try: what they left open is looked up in the texts)
 					}
 					// (measured: without lane_probe in this loop -- such a probe ending the window at its head instead -- the kernel fits 64 registers
 					// with 19 spilled, but eight wavefronts per SIMD are no faster than six at equal work, and the windows cut short cost
@@ -634,6 +634,20 @@ __device__ __forceinline__ bool pool_resolve(const ScanArgs &a, const PairCtx &c
 						else WHY(CS_WHY_PRE);
 					} else {
 						WHY(CS_WHY_PRE);
+					}
+					if (!have && mn) { // a K-mer with a few occurrences: the sorter's records settle it as a rule (as coop_window's walks)
+						bool long_diag;
+						if (coop_probe_r2(c, p, sd, mx, mn, mq, r, seen, pr, long_diag)) {
+							have = true;
+							if (long_diag && pr.unique) { // the diagonal's occurrence is the longest, longer than the bits at hand show
+								if (wend - p >= 32) {
+									const bool same_side = (p + sd < c.border) == (e + sd <= c.border);
+									res = (!same_side || (Xl && Xl >= 2 * thr)) ? W_BREAK : (W_OK | W_LUCKY | (Xl ? W_HADX : 0u) | (nX << W_NX_SHIFT));
+								} else {
+									have = false; // (the window's end: lane_probe's)
+								}
+							}
+						}
 					}
 					if (on_diag) {
 						pr.unique = true, pr.pos = p + sd, pr.len = r;
