@@ -953,7 +953,8 @@ __device__ __forceinline__ bool pool_window(const ScanArgs &a, const PairCtx &c,
 
 // ------------------------------------------------------------------ the kernel: persistent wavefronts take the segments in order
 #ifndef POOL_OCC
-#define POOL_OCC 6 /* wavefronts per SIMD: 80 registers, 75 spilled on rare paths -- bench set 5.66 / 5.09 / 4.92 ms at 4 / 5 / 6 */
+#define POOL_OCC 7 /* wavefronts per SIMD: 72 registers, 19 spilled -- round 5: bench set 5.66 / 5.09 / 4.92 ms at 4 / 5 / 6; round 6, first session: 7 and 8 a fifth and a third
+                      slower than 6 (45 / 108 spilled); with sweep W's loop split (19 / 34 spilled): C4 shape 19.8 / 19.8 / 22.9 ms at 6 / 7 / 8, C3-like 1.63 / 1.56 / 1.82 */
 #endif
 // One segment: mode G until the chain has a diagonal, windows while it stays on it.
 __device__ __forceinline__ void pool_segment(const ScanArgs &a, PoolLds &L, const PoolScratch *G, uint32_t sub, uint32_t wseg) {
