@@ -568,6 +568,7 @@ __device__ __forceinline__ void subst_flush_pairs(const SubstAcc &acc, lds_u32 *
 // of the diagonal.  Returns true if the chain moved; st is a genuine loop-top state either way.
 template <int NCH, bool EXACT>
 __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c, Chain &ch, CoopLds<NCH> &L, uint32_t end) {
+	static_assert(64 * 32 * NCH < 65536 && 2048 * NCH <= 65536, "two 16-bit sums to a register (subst_flush_pairs, the stretches' equal symbols); offsets into a window are 16 bits");
 	const uint32_t lane = __lane_id(), thr = c.thr, n = (uint32_t)c.E.n;
 	ChainState &st = ch.st;
 	const int64_t dg = (int64_t)st.lastS - (int64_t)st.lastQ;
@@ -1107,7 +1108,7 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		}
 		eq0 += tt - t0 - t1 + t01, eq1 += t0 - t01, eq2 += t1 - t01, eq3 += t01; // (A: neither bit, C: bit 0 alone, G: bit 1 alone, T: both)
 		{
-			const uint32_t v0 = wave_sum(eq0 | (eq2 << 16)), v1 = wave_sum(eq1 | (eq3 << 16)); // (a lane's stretches hold fewer than 1024 symbols: two sums to a register)
+			const uint32_t v0 = wave_sum(eq0 | (eq2 << 16)), v1 = wave_sum(eq1 | (eq3 << 16)); // (the stretches of a window are disjoint: fewer than 2048 NCH <= 16384 symbols in all -- two sums to a register)
 			if (lane == 0) lds_add(&hist[0], v0 & 0xffffu), lds_add(&hist[5], v1 & 0xffffu), lds_add(&hist[10], v0 >> 16), lds_add(&hist[15], v1 >> 16);
 		}
 		wave_sync();
