@@ -380,13 +380,7 @@ __device__ __forceinline__ void pool_stream(const ScanArgs &a, const PairCtx &c,
 				else if (end - 1 - x0 < 32) live = (1u << (end - 1 - x0)) - 1u;
 				const uint32_t hmask = cur & A & ~B & live;
 				const uint32_t nh = (uint32_t)__builtin_popcount(hmask);
-#ifdef SCAN_OPAQUE
-				uint32_t nh_ = nh;
-				asm volatile("" : "+v"(nh_));
-				uint32_t hb = wave_scan_add(nh_); // (inclusive; made exclusive below)
-#else
 				uint32_t hb = wave_scan_add(nh); // (inclusive; made exclusive below)
-#endif
 				const uint32_t total = lane_read(hb, 63);
 				hb -= nh;
 				if (total) {

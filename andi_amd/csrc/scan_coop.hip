@@ -715,9 +715,6 @@ __device__ __forceinline__ bool coop_window(const ScanArgs &a, const PairCtx &c,
 		hmask[j] = cur & soon & ~before & live;
 		nh += (uint32_t)__builtin_popcount(hmask[j]);
 	}
-#ifdef SCAN_OPAQUE
-	asm volatile("" : "+v"(nh)); // (a population count feeding the scan's first step keeps the compiler from fusing its six DPP additions)
-#endif
 	uint32_t hbase = wave_scan_add(nh); // (inclusive; made exclusive below)
 	const uint32_t nheads_all = lane_read(hbase, 63);
 	hbase -= nh;
