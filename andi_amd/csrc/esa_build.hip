@@ -336,11 +336,11 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 // which gap it belongs to.
 #define PT_BLOCK 256
 #ifndef PT_GAPS
-#define PT_GAPS 2 /* gaps per thread: two independent gathers in flight per thread */
+#define PT_GAPS 3 /* gaps per thread (independent loads in flight): bench set 2.91 / 2.33 / 2.24 / 2.54 ms at 1 / 2 / 3 / 4 (round 6; LDS 20.6 KB per block at 3) */
 #endif
 #define PT_TILE (PT_BLOCK * PT_GAPS)
 #define PT_WORDS (PT_TILE / 64) /* 64-bit ballots that cover the tile: gap i = u * PT_BLOCK + thread is bit i & 63 of word i >> 6 */
-#define PT_RANKED 2048          /* entries of a block whose owners are found by rank (the block's piece is seldom longer) */
+#define PT_RANKED 4096          /* entries of a block whose owners are found by rank (the block's piece is seldom longer: 768 gaps; a table a symbol deeper than the text asks for -- subjects that meet a thousand queries -- has four entries per gap) */
 // inclusive prefix sums over the 64 lanes of a wavefront in six DPP additions: shifts by 1, 2, 4, 8 inside the rows
 // of 16 lanes, then lane 15 of a row into the next row, lane 31 into the upper half
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
@@ -525,9 +525,13 @@ __device__ __forceinline__ void probe_table_block(const uint8_t *__restrict__ N0
 		if (off < PT_RANKED) atomicOr(&s_bits[off >> 5], 1u << (off & 31u));
 	}
 	__syncthreads();
-	if (wave == 0) { // set bits before each word of s_bits (64 words: one wavefront)
-		const uint32_t mine = (uint32_t)__builtin_popcount(s_bits[lane]);
-		s_before[lane] = wave_scan_incl(mine) - mine;
+	if (wave == 0) { // set bits before each word of s_bits (64 words per pass of one wavefront)
+		uint32_t carry = 0;
+		for (uint32_t w0 = 0; w0 < PT_RANKED / 32; w0 += 64) {
+			const uint32_t mine = (uint32_t)__builtin_popcount(s_bits[w0 + lane]), incl = wave_scan_incl(mine);
+			s_before[w0 + lane] = carry + incl - mine;
+			carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		}
 	}
 	__syncthreads();
 
