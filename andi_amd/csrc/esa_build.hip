@@ -334,7 +334,9 @@ __device__ __forceinline__ uint32_t rec_lcp_code(uint32_t code, uint32_t a, int 
 // table.  The block writes that piece together, entry t by thread t mod 256 (coalesced,
 // no divergent per-gap loops); a binary search over the gaps' offsets tells an entry
 // which gap it belongs to.
+#ifndef PT_BLOCK
 #define PT_BLOCK 256
+#endif
 #ifndef PT_GAPS
 #define PT_GAPS 3 /* gaps per thread (independent loads in flight): bench set 2.91 / 2.33 / 2.24 / 2.54 ms at 1 / 2 / 3 / 4 (round 6; LDS 20.6 KB per block at 3) */
 #endif
