@@ -1573,7 +1573,7 @@ int andi_hip_scan_rows(andi_hip_ctx *ctx, andi_hip_esa *const *subjects, const i
 	}
 	a.coop = coop && !a.adaptive;
 	a.pool_scratch = nullptr, a.pool_ticket = nullptr, a.pool_waves = 0, a.pool_bytes = 0;
-	a.pool_maxchunks = a.pool_hc = 0, a.pool_first = 0, a.pool_use = 0, a.pool_max_n = 0;
+	a.pool_maxchunks = a.pool_hc = 0, a.pool_first = 0, a.pool_use = 0;
 	{
 		const char *pm = andi_knob(KNOB_POOL_MATCH); // (experiments: mean sampled match from which a routed pair's wavefront kernel is k_pool_cold)
 		a.pool_match = pm && atoi(pm) >= 0 ? (uint32_t)atoi(pm) : 48u;

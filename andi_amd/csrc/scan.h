@@ -129,7 +129,6 @@ struct ScanArgs {
 	uint32_t *pool_ticket;
 	uint32_t pool_waves;
 	size_t pool_bytes;    // host side: what the context holds behind pool_ticket's 4096 bytes
-	size_t pool_max_n;    // host side: the longest subject text of the call (the launch of k_pool_cold packs the subjects' planes first)
 	uint32_t pool_maxchunks, pool_hc; // a scratch's size: rounds of 2048 positions of a window, heads of a window
 	// routed calls: WHICH wavefront kernel -- k_pool_cold where the pairs whose sampled mean match is pool_match ... 4095 (few heads per position:
 	// streaming decides) hold at least half of the wavefront kernel's segments, k_coop_cold otherwise (many heads: its windows in LDS walk them at
@@ -148,8 +147,6 @@ hipError_t andi_launch_pack_symbols(const uint8_t *src, size_t bytes, uint8_t *N
 									int32_t *foreign, hipStream_t st);
 // the bit-sliced form of 4-bit symbols (EsaDev.P): `symbols` of them from N0 (rounded up to blocks of 32) into planes
 hipError_t andi_launch_pack_planes(const uint8_t *N0, size_t symbols, uint32_t *planes, hipStream_t st);
-// ... of the subjects of a scan call (their descriptors on the device): symbols 0 ... n + 64 of each
-hipError_t andi_launch_pack_planes_subjects(const EsaDev *subjects, uint32_t nsub, size_t max_n, hipStream_t st);
 // adaptive mode: sample every pair's match lengths, choose its segment length (and, in a routed call, its pass A), lay out the slots
 hipError_t andi_launch_pair_layout(const ScanArgs &a, hipStream_t st);
 // routed calls: the second lane layout (a2: the pairs pass A by wavefronts handed back); who took what, for the timings

@@ -1176,17 +1176,6 @@ __global__ __launch_bounds__(256) void k_pack_planes(const uint4 *__restrict__ N
 	planes[3 * j] = o[0], planes[3 * j + 1] = o[1], planes[3 * j + 2] = o[2];
 }
 
-__global__ __launch_bounds__(256) void k_pack_planes_subjects(const EsaDev *__restrict__ subjects) {
-	const EsaDev E = subjects[blockIdx.y];
-	if (!E.P || !E.N0) return;
-	const int64_t blocks = ((int64_t)E.n + 1 + 64 + 31) / 32, j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= blocks) return;
-	uint32_t o[3];
-	planes_of(((const uint4 *)E.N0)[j], o);
-	uint32_t *planes = const_cast<uint32_t *>(E.P);
-	planes[3 * j] = o[0], planes[3 * j + 1] = o[1], planes[3 * j + 2] = o[2];
-}
-
 __global__ __launch_bounds__(256) void k_pack_planes_batch(const AndiIndexBatchItem *__restrict__ items) {
 	const AndiIndexBatchItem it = items[blockIdx.y];
 	if (!it.P || !it.N0) return;
@@ -1249,14 +1238,6 @@ hipError_t andi_launch_pack_planes_batch(const AndiIndexBatchItem *d_items, uint
 	const int64_t blocks = (int64_t)((max_n + 1 + 64 + 31) / 32);
 	if (blocks == 0 || count == 0) return hipSuccess;
 	k_pack_planes_batch<<<dim3((unsigned)((blocks + 255) / 256), count), 256, 0, st>>>(d_items);
-	CHECK_LAUNCH();
-	return hipSuccess;
-}
-
-hipError_t andi_launch_pack_planes_subjects(const EsaDev *subjects, uint32_t nsub, size_t max_n, hipStream_t st) {
-	const int64_t blocks = (int64_t)((max_n + 1 + 64 + 31) / 32);
-	if (blocks == 0 || nsub == 0) return hipSuccess;
-	k_pack_planes_subjects<<<dim3((unsigned)((blocks + 255) / 256), nsub), 256, 0, st>>>(subjects);
 	CHECK_LAUNCH();
 	return hipSuccess;
 }
