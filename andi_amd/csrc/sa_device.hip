@@ -79,17 +79,41 @@ __device__ __forceinline__ First16 first16(const uint8_t *__restrict__ S, size_t
 	return f;
 }
 
-// round 0: key of suffix i; the special suffixes are listed
+// round 0: key of suffix i; the special suffixes are listed.  A thread makes the keys of FOUR consecutive suffixes from the 19 symbols they
+// span (first16 per suffix classified every byte sixteen times: 200 vector instructions per suffix, 80 us per 9.8 M characters -- a sixth of
+// the sorter's time; round 6: the bytes' codes once, the keys cut out of the 38 bits they fill)
 __global__ __launch_bounds__(SA_BLOCK) void k_sa_keys0(const uint8_t *__restrict__ S, int32_t n, uint32_t *__restrict__ key,
 														uint32_t *__restrict__ val, int32_t *__restrict__ foreign, uint32_t *__restrict__ special,
 														uint32_t *__restrict__ nspecial) {
-	const int64_t i = (int64_t)blockIdx.x * SA_BLOCK + threadIdx.x;
-	if (i >= n) return;
-	const First16 f = first16(S, (size_t)i);
-	if ((f.bad & 8u) && order_code(S[i]) == 8u) *foreign = 1; // (a byte is reported by the suffix that starts with it)
-	key[i] = f.code;
-	val[i] = (uint32_t)i;
-	if (f.jj < 16) special[atomicAdd(nspecial, 1u)] = (uint32_t)i;
+	const int64_t i0 = 4 * ((int64_t)blockIdx.x * SA_BLOCK + threadIdx.x);
+	if (i0 >= n) return;
+	g_u8p p = (g_u8p)S + i0; // (positions >= n read the NUL padding)
+	const uint64_t w[3] = {ld_u64_unaligned(p), ld_u64_unaligned(p + 8), ld_u64_unaligned(p + 16)};
+	uint64_t Y = 0;           // the 2-bit codes of the 19 symbols, the first on top
+	uint32_t stop = 0, f8 = 0; // bit j: symbol j is no nucleotide (NUL ! # ;) / a byte outside the alphabet
+#pragma unroll
+	for (int j = 0; j < 19; ++j) {
+		const uint32_t c = order_code((uint32_t)(w[j >> 3] >> (8 * (j & 7))) & 0xffu);
+		Y = (Y << 2) | (c & 3u);
+		stop |= (c < 4u ? 1u : 0u) << j, f8 |= (c == 8u ? 1u : 0u) << j;
+	}
+	uint32_t k[4];
+#pragma unroll
+	for (int s = 0; s < 4; ++s) {
+		const uint32_t ms = (stop >> s) & 0xffffu, jj = ms ? (uint32_t)__builtin_ctz(ms) : 16u; // the first of the suffix's 16 symbols that is no nucleotide
+		const uint32_t y = (uint32_t)(Y >> (2 * (3 - s)));
+		k[s] = jj == 0 ? 0u : (jj < 16 ? y & (~0u << (2 * (16 - jj))) : y); // (zeros from that symbol on, as first16)
+		if (i0 + s < n) {
+			if ((f8 >> s) & 1u) *foreign = 1; // (a byte is reported by the suffix that starts with it)
+			if (jj < 16) special[atomicAdd(nspecial, 1u)] = (uint32_t)(i0 + s);
+		}
+	}
+	if (i0 + 3 < n) {
+		*(uint4 *)(key + i0) = make_uint4(k[0], k[1], k[2], k[3]);
+		*(uint4 *)(val + i0) = make_uint4((uint32_t)i0, (uint32_t)i0 + 1u, (uint32_t)i0 + 2u, (uint32_t)i0 + 3u);
+	} else {
+		for (int s = 0; s < 4 && i0 + s < n; ++s) key[i0 + s] = k[s], val[i0 + s] = (uint32_t)(i0 + s);
+	}
 }
 
 // The record of a suffix for the scan index's builder (esa_build.hip: suffix_rec -- the 2-bit code of its first K
@@ -348,7 +372,7 @@ hipError_t andi_sa_device(const uint8_t *S, int32_t n, int32_t *SA, void *worksp
 		uint32_t *key0A = (uint32_t *)keyA, *key0B = (uint32_t *)keyB, *special = hv, *bcount = grp, *boff = rank; // (buffers of the later rounds)
 		const uint32_t nb = ((uint32_t)n + SA_TILE - 1) / SA_TILE;
 		SA_TRY(hipMemsetAsync(d_count, 0, 64, st));
-		k_sa_keys0<<<blocks((uint32_t)n), SA_BLOCK, 0, st>>>(S, n, key0A, valA, d_foreign, special, d_nspecial);
+		k_sa_keys0<<<blocks(((uint32_t)n + 3u) / 4u), SA_BLOCK, 0, st>>>(S, n, key0A, valA, d_foreign, special, d_nspecial);
 		SA_TRY(hipGetLastError());
 		size_t tb = tmp_bytes;
 		SA_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, key0A, key0B, valA, (uint32_t *)SA, n, 0, 32, st));
