@@ -10,8 +10,10 @@
 //      then hops through the answers: each step lands at most 64 positions on), the accounting of 157-190 counts
 //      a gap with all lanes.  The chain is in this mode until it has found a LUCKY anchor: two anchors in a row on
 //      one diagonal.
-//   W  a window of W = 2048 NCH query symbols along that diagonal, two fully coalesced 16-byte loads per lane and
-//      2048 symbols, turned into one bit per position (query symbol != subject symbol).  Behind a mismatch that is
+//   W  a window of W = 2048 NCH query symbols along that diagonal (NCH = 5 on segments of 32768 symbols and more), streamed
+//      with fully coalesced loads -- both texts bit-sliced, 12 bytes per 32 symbols (LogDet / ANI: 4-bit symbols) -- and
+//      turned into one bit per position (query symbol != subject symbol); every mismatch is counted at once as a
+//      single-position gap, by kind (what the chain does not reach is taken back).  Behind a mismatch that is
 //      followed by >= threshold equal symbols the next step is a lucky anchor whose outcome the bits alone decide
 //      ("easy").  A mismatch followed by a shorter run but preceded by a long one is a HEAD: the chain arrives
 //      there in a known (canonical) state, so the walks from ALL heads of the window -- probe, step, probe ... until
